@@ -1,0 +1,82 @@
+// gemm_internal.h — shared parameter block + internal launchers of the two GEMM regimes.
+#pragma once
+#include "common.h"
+
+enum GemmMode : int {
+    GEMM_PLAIN = 0,   // y[r,n] = bf16(acc + bias[n])                              (a5, a10)
+    GEMM_GATEUP = 1,  // act[r,i] = bf16(bf16(silu(bf16(g))) * bf16(u)), W rows gate|up  (a13)
+    GEMM_DOWN = 2,    // y[r,n] = bf16(bf16(acc) * scale[r]) for groups < n_scaled    (a12/a13)
+};
+
+struct GemmParams {
+    const bf16_t* x;      // activations, row r_src at x + r_src*ldx, K contiguous
+    int64_t ldx;
+    const bf16_t* w;      // group g at w + g*w_gstride; [n_rows, K] row-major
+    int64_t w_gstride;
+    const int32_t* offs;  // [G+1] row offsets per group, or nullptr (one group of R rows)
+    const int32_t* src;   // source row of sorted row r, or nullptr (identity)
+    const bf16_t* scale;  // [R] per-row scale (GEMM_DOWN) or nullptr
+    const bf16_t* bias;   // [N] (GEMM_PLAIN) or nullptr
+    bf16_t* y;            // [R, N] rows at y + r*ldy
+    int64_t ldy;
+    int64_t R;            // total rows (all groups)
+    int N;                // output columns (GATEUP: I = act columns; W then has 2I rows)
+    int K;
+    int G;                // number of groups
+    int n_scaled;         // GEMM_DOWN: groups [0, n_scaled) multiply by scale
+};
+
+// weight-streaming kernels for few rows per group (decode); returns GLM_* code
+int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st);
+// LDS-tiled MFMA kernels for many rows per group (prefill)
+int glm_launch_gemm_largem(int mode, const GemmParams& p, hipStream_t st);
+
+__device__ __forceinline__ float glm_silu(float g) { return g / (1.0f + expf(-g)); }
+
+// Locate the (group, row-block) a workgroup owns: combo index `target` enumerates
+// ceil(cnt_g / MB) blocks per group in group order.  Executed by the whole first wave;
+// result broadcast through `sh` (3 ints of LDS).  g = -1 ⇒ no such combo.
+__device__ __forceinline__ void glm_locate_block(const int32_t* __restrict__ offs, int G, int64_t R,
+                                                 int MB, int target, int* sh) {
+    const int tid = threadIdx.x;
+    if (offs == nullptr) {
+        if (tid == 0) {
+            const int64_t m0 = (int64_t)target * MB;
+            if (m0 < R) {
+                sh[0] = 0;
+                sh[1] = (int)m0;
+                sh[2] = (int)((R - m0) < MB ? (R - m0) : MB);
+            } else {
+                sh[0] = -1;
+            }
+        }
+        return;
+    }
+    if (tid >= 64) return;
+    if (tid == 0) sh[0] = -1;
+    int base = 0;
+    for (int b = 0; b < G; b += 64) {
+        const int gi = b + tid;
+        int lo = 0, cnt = 0;
+        if (gi < G) {
+            lo = offs[gi];
+            cnt = offs[gi + 1] - lo;
+        }
+        const int nt = (cnt + MB - 1) / MB;
+        int incl = nt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (tid >= o) incl += v;
+        }
+        const int excl = incl - nt;
+        if (target >= base + excl && target < base + incl) {
+            const int m0 = lo + (target - base - excl) * MB;
+            sh[0] = gi;
+            sh[1] = m0;
+            sh[2] = (lo + cnt - m0) < MB ? (lo + cnt - m0) : MB;
+        }
+        base += __shfl(incl, 63, 64);
+        if (base > target) break;  // uniform
+    }
+}

@@ -1,0 +1,300 @@
+// moe_misc.hip — the small integer/latency-bound pieces of the GLM-4-MoE block for gfx950:
+//   router (a11: GEMV-shaped logits + sigmoid + bias + wave-level top-k + renormalise),
+//   token→expert bucketing (replaces the per-expert mask/where/any host loop, a12),
+//   and the bf16-ordered combine (a12: index_add_ in ascending expert order + shared expert).
+// Compiled with -ffp-contract=off: the rounding points below are the reference's
+// (SURVEY.md §8a R1–R7).
+#include "common.h"
+
+namespace {
+
+constexpr int ROUTER_MAX_E = 256;
+constexpr int ROUTER_EB = 4;  // experts per dot-product pass (x chunk reused 4x)
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// One 256-thread workgroup per token.  x row is staged in LDS (bf16), each wave owns experts
+// w, w+4, ... in blocks of ROUTER_EB; a lane covers 16-byte chunks lane, lane+64, ... of K.
+__global__ __launch_bounds__(256) void router_topk_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ gw, const float* __restrict__ bias,
+    int64_t* __restrict__ topk_idx, bf16_t* __restrict__ topk_w, bf16_t* __restrict__ logits_out,
+    int H, int E, int k, float rsf) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                        // [H]
+    float* lg = reinterpret_cast<float*>(smem + (((size_t)H * 2 + 15) & ~(size_t)15));  // [E]
+    const int64_t t = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nvec = H >> 3;
+    {
+        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(x + t * H);
+        u32x4_t* dst = reinterpret_cast<u32x4_t*>(xs);
+        for (int i = tid; i < nvec; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    // R1: logits = bf16( fp32 dot )
+    const int nblk = (E + ROUTER_EB - 1) / ROUTER_EB;
+    for (int b = wid; b < nblk; b += 4) {
+        const int e0 = b * ROUTER_EB;
+        float acc[ROUTER_EB];
+#pragma unroll
+        for (int j = 0; j < ROUTER_EB; ++j) acc[j] = 0.f;
+        for (int c = lane; c < nvec; c += 64) {
+            const u32x4_t xv = reinterpret_cast<const u32x4_t*>(xs)[c];
+#pragma unroll
+            for (int j = 0; j < ROUTER_EB; ++j) {
+                const int e = e0 + j < E ? e0 + j : E - 1;
+                const u32x4_t wv = reinterpret_cast<const u32x4_t*>(gw + (int64_t)e * H)[c];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[j] = fmaf(bflo(xv[q]), bflo(wv[q]), acc[j]);
+                    acc[j] = fmaf(bfhi(xv[q]), bfhi(wv[q]), acc[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < ROUTER_EB; ++j) {
+            const float s = wave_sum(acc[j]);
+            if (lane == 0 && e0 + j < E) lg[e0 + j] = rbf(s);
+        }
+    }
+    __syncthreads();
+    if (wid != 0) return;
+
+    // wave 0: R2..R7.  lane owns experts lane + 64*i.
+    constexpr int EPL = ROUTER_MAX_E / 64;
+    float sc[EPL], ch[EPL];
+    bool sel[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int e = lane + 64 * i;
+        sel[i] = false;
+        if (e < E) {
+            const float l = lg[e];
+            if (logits_out) logits_out[t * E + e] = f2bf(l);
+            sc[i] = rbf(sigmoid_f(l));  // R2: bf16 sigmoid
+            ch[i] = sc[i] + bias[e];    // R3: fp32 (bias buffer is fp32)
+        } else {
+            sc[i] = 0.f;
+            ch[i] = -INFINITY;
+        }
+    }
+    // R4: k rounds of wave arg-max (ties → lowest expert id; NaN never wins)
+    for (int r = 0; r < k; ++r) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) {
+            const int e = lane + 64 * i;
+            if (e < E && !sel[i] && (ch[i] > bv || bi == 0x7fffffff)) {
+                // first unselected candidate, or strictly better (lower ids are visited first)
+                if (bi == 0x7fffffff || ch[i] > bv) {
+                    bv = ch[i];
+                    bi = e;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            const bool take = (oi != 0x7fffffff) && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi));
+            if (take) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        // bi is wave-uniform now
+#pragma unroll
+        for (int i = 0; i < EPL; ++i)
+            if (lane + 64 * i == bi) sel[i] = true;
+    }
+    // R5/R6: weights = scores (without bias) of the selected experts, renormalised in bf16
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i)
+        if (sel[i]) part += sc[i];
+    const float den = rbf(rbf(wave_sum(part)) + 1e-20f);
+    // output in ascending expert id: position = #selected experts with a smaller id
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const unsigned long long m = __ballot(sel[i]);
+        if (sel[i]) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            topk_idx[t * k + pos] = lane + 64 * i;
+            topk_w[t * k + pos] = f2bf(rbf(sc[i] / den) * rsf);  // R6 then R7
+        }
+        base += __popcll(m);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Token→expert bucketing: one 1024-thread workgroup (counting sort with LDS atomics).
+constexpr int ALIGN_MAX_G = 1024;
+
+__global__ __launch_bounds__(1024) void moe_align_kernel(
+    const int64_t* __restrict__ topk_idx, const bf16_t* __restrict__ topk_w,
+    int32_t* __restrict__ expert_offsets, int32_t* __restrict__ sorted_token,
+    bf16_t* __restrict__ sorted_scale, int32_t* __restrict__ pair_pos, int64_t T, int k, int E,
+    int with_shared) {
+    __shared__ int cnt[ALIGN_MAX_G + 1];
+    __shared__ int cur[ALIGN_MAX_G + 1];
+    const int tid = threadIdx.x;
+    const int64_t P = T * k;
+    for (int e = tid; e <= E; e += 1024) cnt[e] = 0;
+    __syncthreads();
+    for (int64_t p = tid; p < P; p += 1024) {
+        const int64_t e = topk_idx[p];
+        if (e >= 0 && e < E) atomicAdd(&cnt[(int)e], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int e = 0; e < E; ++e) {
+            const int c = cnt[e];
+            cur[e] = run;
+            expert_offsets[e] = run;
+            run += c;
+        }
+        expert_offsets[E] = run;  // == number of valid pairs; start of the shared group
+        cur[E] = run;
+        if (with_shared) expert_offsets[E + 1] = run + (int)T;
+    }
+    __syncthreads();
+    for (int64_t p = tid; p < P; p += 1024) {
+        const int64_t e = topk_idx[p];
+        if (e >= 0 && e < E) {
+            const int pos = atomicAdd(&cur[(int)e], 1);
+            sorted_token[pos] = (int32_t)(p / k);
+            sorted_scale[pos] = topk_w[p];
+            pair_pos[p] = pos;
+        } else {
+            pair_pos[p] = -1;
+        }
+    }
+    if (with_shared) {
+        const int sbase = cur[E];  // unchanged by the loop above (only cur[0..E-1] advance)
+        for (int64_t t = tid; t < T; t += 1024) {
+            sorted_token[sbase + t] = (int32_t)t;
+            sorted_scale[sbase + t] = 0x3F80;  // bf16 1.0
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Combine: out[t] = (((0 + y[p0]) + y[p1]) + ...) + y[shared], one bf16 rounding per add,
+// p0 < p1 < ... = the token's routed rows in ascending expert id (sorted rows ascend with id).
+constexpr int COMBINE_MAX_K = 64;
+
+__global__ __launch_bounds__(256) void moe_combine_kernel(const bf16_t* __restrict__ y, int64_t ldy,
+                                                          const int32_t* __restrict__ pair_pos,
+                                                          bf16_t* __restrict__ out, int k, int H,
+                                                          int64_t shared_base, int vec_ok) {
+    __shared__ int pos[COMBINE_MAX_K];
+    __shared__ int npos;
+    const int64_t t = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int j = 0; j < k; ++j) {
+            const int p = pair_pos[t * k + j];
+            if (p < 0) continue;
+            int i = n++;
+            while (i > 0 && pos[i - 1] > p) {
+                pos[i] = pos[i - 1];
+                --i;
+            }
+            pos[i] = p;
+        }
+        npos = n;
+    }
+    __syncthreads();
+    const int n = npos;
+    if (vec_ok) {
+        const int nvec = H >> 3;
+        for (int c = threadIdx.x; c < nvec; c += 256) {
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+            for (int j = 0; j < n; ++j) {
+                const u32x4_t v = reinterpret_cast<const u32x4_t*>(y + (int64_t)pos[j] * ldy)[c];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[2 * q] = rbf(acc[2 * q] + bflo(v[q]));
+                    acc[2 * q + 1] = rbf(acc[2 * q + 1] + bfhi(v[q]));
+                }
+            }
+            if (shared_base >= 0) {
+                const u32x4_t v = reinterpret_cast<const u32x4_t*>(y + (shared_base + t) * ldy)[c];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[2 * q] = acc[2 * q] + bflo(v[q]);
+                    acc[2 * q + 1] = acc[2 * q + 1] + bfhi(v[q]);
+                }
+            }
+            u32x4_t o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = pack2bf(acc[2 * q], acc[2 * q + 1]);
+            reinterpret_cast<u32x4_t*>(out + t * H)[c] = o;
+        }
+    } else {
+        for (int c = threadIdx.x; c < H; c += 256) {
+            float acc = 0.f;
+            for (int j = 0; j < n; ++j) acc = rbf(acc + bf2f(y[(int64_t)pos[j] * ldy + c]));
+            if (shared_base >= 0) acc = acc + bf2f(y[(shared_base + t) * ldy + c]);
+            out[t * H + c] = f2bf(acc);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int glm_router_topk(const void* x, const void* gate_w,
+                               const float* e_score_correction_bias, int64_t* topk_idx,
+                               void* topk_w, void* logits_out, int64_t T, int H, int E, int k,
+                               float routed_scaling_factor, glm_stream_t stream) {
+    GLM_CHECK_ARG(x && gate_w && e_score_correction_bias && topk_idx && topk_w, GLM_ERR_INVALID,
+                  "glm_router_topk: null pointer");
+    GLM_CHECK_ARG(T >= 0 && H > 0 && E > 0 && k > 0 && k <= E, GLM_ERR_INVALID,
+                  "glm_router_topk: bad shape T=%ld H=%d E=%d k=%d", (long)T, H, E, k);
+    GLM_CHECK_ARG(E <= ROUTER_MAX_E && k <= 64 && H % 8 == 0 && H <= 32768 && glm_aligned16(x) &&
+                      glm_aligned16(gate_w),
+                  GLM_ERR_UNSUPPORTED,
+                  "glm_router_topk: needs E<=256, k<=64, H%%8==0, H<=32768, 16B-aligned x/W (E=%d k=%d H=%d)",
+                  E, k, H);
+    if (T == 0) return GLM_OK;
+    const size_t shm = (((size_t)H * 2 + 15) & ~(size_t)15) + (size_t)E * 4;
+    hipLaunchKernelGGL(router_topk_kernel, dim3((unsigned)T), dim3(256), shm, glm_s(stream),
+                       (const bf16_t*)x, (const bf16_t*)gate_w, e_score_correction_bias, topk_idx,
+                       (bf16_t*)topk_w, (bf16_t*)logits_out, H, E, k, routed_scaling_factor);
+    GLM_CHECK_LAUNCH("glm_router_topk");
+    return GLM_OK;
+}
+
+extern "C" int glm_moe_align(const int64_t* topk_idx, const void* topk_w, int32_t* expert_offsets,
+                             int32_t* sorted_token, void* sorted_scale, int32_t* pair_pos,
+                             int64_t T, int k, int E, int with_shared, glm_stream_t stream) {
+    GLM_CHECK_ARG(topk_idx && topk_w && expert_offsets && sorted_token && sorted_scale && pair_pos,
+                  GLM_ERR_INVALID, "glm_moe_align: null pointer");
+    GLM_CHECK_ARG(T >= 0 && k > 0 && E > 0, GLM_ERR_INVALID, "glm_moe_align: bad shape");
+    GLM_CHECK_ARG(E < ALIGN_MAX_G && T * (int64_t)(k + 1) < (1ll << 31), GLM_ERR_UNSUPPORTED,
+                  "glm_moe_align: needs E<%d and T*(k+1) < 2^31", ALIGN_MAX_G);
+    hipLaunchKernelGGL(moe_align_kernel, dim3(1), dim3(1024), 0, glm_s(stream), topk_idx,
+                       (const bf16_t*)topk_w, expert_offsets, sorted_token, (bf16_t*)sorted_scale,
+                       pair_pos, T, k, E, with_shared);
+    GLM_CHECK_LAUNCH("glm_moe_align");
+    return GLM_OK;
+}
+
+extern "C" int glm_moe_combine(const void* y, int64_t ldy, const int32_t* pair_pos, void* out,
+                               int64_t T, int k, int H, int64_t shared_base, glm_stream_t stream) {
+    GLM_CHECK_ARG(y && pair_pos && out, GLM_ERR_INVALID, "glm_moe_combine: null pointer");
+    GLM_CHECK_ARG(T >= 0 && k > 0 && H > 0 && ldy >= H, GLM_ERR_INVALID, "glm_moe_combine: bad shape");
+    GLM_CHECK_ARG(k <= COMBINE_MAX_K, GLM_ERR_UNSUPPORTED, "glm_moe_combine: k > %d", COMBINE_MAX_K);
+    if (T == 0) return GLM_OK;
+    const int vec_ok = H % 8 == 0 && ldy % 8 == 0 && glm_aligned16(y) && glm_aligned16(out);
+    hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned)T), dim3(256), 0, glm_s(stream),
+                       (const bf16_t*)y, ldy, pair_pos, (bf16_t*)out, k, H, shared_base, vec_ok);
+    GLM_CHECK_LAUNCH("glm_moe_combine");
+    return GLM_OK;
+}

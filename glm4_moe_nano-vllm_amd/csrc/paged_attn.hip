@@ -1,0 +1,386 @@
+// paged_attn.hip — single-token decode attention over the paged KV cache (a8,
+// reference: nanovllm/layers/attention.py:101-107 → flash_attn_with_kvcache).  gfx950 only.
+//
+// Roofline: HBM.  Algorithmic bytes = B * ctx * nkv * hd * 2 (K+V) * 2 B; every KV byte is read
+// exactly once, MFMA/VALU time is <10 % of the stream time, so the design is about keeping
+// 1-KiB-coalesced loads in flight on every CU:
+//
+//   * grid = (kv-split, kv-head, sequence); a workgroup owns ALL nh/nkv query heads of one
+//     kv-head, so a KV row is fetched once for the whole GQA group (12 heads on GLM-4.5-Air).
+//   * 4 waves per workgroup, each wave streams its own interleaved 32-key groups through a
+//     private 2-stage LDS ring filled by LDS-DMA (global_load_lds_dwordx4: one instruction =
+//     4 keys x 256 B, contiguous in HBM).  Waves never synchronise inside the loop — only the
+//     wave's own counted s_waitcnt vmcnt orders DMA → ds_read.
+//   * bank conflicts are removed by permuting the per-lane SOURCE chunk of each DMA (the LDS
+//     image stays lane-linear): K image chunk' = chunk ^ (key & 15) for ds_read_b128 fragment
+//     reads, V image chunk' = chunk ^ ((key & 7) << 1) for ds_read_b64_tr_b16 transposed reads.
+//   * math: S^T = K·Q^T with mfma_f32_16x16x32_bf16 (keys on the MFMA row axis, query heads on
+//     the lane axis), so each lane already holds 8 keys of ONE query head: the softmax needs two
+//     cross-lane maxima per step and P^T feeds the second product O^T = V^T·P^T straight from
+//     registers (k-slot j of lane group g ↔ key 16*(j>>2) + 4*g + (j&3)).
+//   * per-wave online softmax (fp32), merged across the 4 waves through LDS at the end, and
+//     across kv-splits by a small second kernel when num_splits > 1.
+#include "common.h"
+
+namespace {
+
+constexpr int PA_HD = 128;               // head_dim supported by this kernel
+constexpr int PA_ROWB = PA_HD * 2;       // 256 B per (key, kv-head) row
+constexpr int PA_GK = 32;                // keys per wave step
+constexpr int PA_STAGE = 2 * PA_GK * PA_ROWB;  // K image + V image = 16 KiB
+constexpr int PA_NSTAGE = 2;
+constexpr int PA_WAVES = 4;
+constexpr int PA_RING = PA_NSTAGE * PA_STAGE;  // per wave
+constexpr int PA_MAX_BT = 4096;                // block-table entries cached in LDS per workgroup
+constexpr int PA_LDS = PA_WAVES * PA_RING + PA_MAX_BT * 4;
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+// LDS fragment reads as inline asm: hipcc cannot tell a ds_read (in particular the tr16 builtin)
+// from the in-flight LDS-DMA of the OTHER ring stage and would drain vmcnt(0) before it.  The
+// wave's own counted vmcnt orders DMA → read; lds_wait_all() below names every destination so
+// no consumer is scheduled above the lgkmcnt(0) (cdna_hip_programming.md §5.7 form (ii)).
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(u32x4_t& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr16_b64(u32x2_t& dst, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(const lds_void*)p;
+}
+
+// issue the 16 LDS-DMA instructions of one 32-key group into `stage` (wave-private)
+__device__ __forceinline__ void issue_group(const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
+                                            char* stage, int64_t phys_block, int in_block_off,
+                                            int valid_keys /* >=1 */, int block_size, int nkv,
+                                            int kvh, int lane) {
+    const int r4 = lane >> 4, p = lane & 15;
+#pragma unroll
+    for (int i = 0; i < PA_GK / 4; ++i) {
+        const int row = 4 * i + r4;
+        const int key = row < valid_keys ? row : valid_keys - 1;  // clamp: masked keys re-read a valid row
+        const int64_t tok = phys_block * block_size + in_block_off + key;
+        const int64_t rowoff = (tok * nkv + kvh) * PA_HD;  // elements
+        const int chk = p ^ (row & 15);
+        const int chv = p ^ ((row & 7) << 1);
+        glds16(kc + rowoff + chk * 8, stage + i * 1024);
+        glds16(vc + rowoff + chv * 8, stage + PA_GK * PA_ROWB + i * 1024);
+    }
+}
+
+template <int DUMMY>
+__global__ __launch_bounds__(256) void paged_attn_decode_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
+    const int32_t* __restrict__ context_lens, const int32_t* __restrict__ block_tables,
+    int64_t bt_stride, bf16_t* __restrict__ out, float* __restrict__ part_o,
+    float* __restrict__ part_ml, int nh, int nkv, int block_size, float scale_log2e,
+    int num_splits) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int split = blockIdx.x, kvh = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int gq = nh / nkv;  // query heads per kv head (<= 16)
+    const int len = context_lens[b];
+    const int ngroups = (len + PA_GK - 1) / PA_GK;
+    const int gps = (ngroups + num_splits - 1) / num_splits;
+    const int G0 = split * gps;
+    const int G1 = min(ngroups, G0 + gps);
+
+    char* ring = smem + wid * PA_RING;
+    int* bt_lds = reinterpret_cast<int*>(smem + PA_WAVES * PA_RING);
+
+    // block-table slice of this workgroup → LDS (so the loop has no VMEM loads besides the DMA)
+    const int gpb = block_size / PA_GK;  // groups per block
+    const int blk0 = G0 < G1 ? G0 / gpb : 0;
+    const int blk1 = G0 < G1 ? (G1 - 1) / gpb + 1 : 0;
+    for (int i = tid; i < blk1 - blk0; i += 256) bt_lds[i] = block_tables[b * bt_stride + blk0 + i];
+
+    // Q^T fragments (B operand): lane (c,g), k-step ks holds Q[head c][32ks + 8g .. +8)
+    bf16x8_t qf[4];
+    {
+        const bool hv = c < gq;
+        const bf16_t* qrow = q + (b * nh + (int64_t)kvh * gq + (hv ? c : 0)) * PA_HD;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            u32x4_t v = {0, 0, 0, 0};
+            if (hv) v = *reinterpret_cast<const u32x4_t*>(qrow + 32 * ks + 8 * g);
+            qf[ks] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+    __syncthreads();  // bt_lds visible
+
+    f32x4_t acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // loop-invariant LDS offsets of this lane's fragment reads, relative to the stage base
+    unsigned k_rel[4], v_rel[8];
+    {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) k_rel[ks] = c * PA_ROWB + (((4 * ks + g) ^ c) << 4);
+        const int qq = (lane >> 2) & 3, pp = lane & 3;
+        const int row = 4 * g + qq;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt)
+            v_rel[dt] = row * PA_ROWB + (((2 * dt + (pp >> 1)) ^ ((row & 7) << 1)) << 4) + ((pp & 1) << 3);
+    }
+    // make the Q loads land before the first DMA is issued (otherwise hipcc waits vmcnt(0) for
+    // them at their first use, i.e. with two ring stages already in flight)
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
+
+    const int nmine = (G1 - G0 - wid + PA_WAVES - 1) / PA_WAVES;  // groups G0+wid, +4, ...
+    auto issue = [&](int it) {
+        const int gi = G0 + wid + it * PA_WAVES;
+        const int pb = __builtin_amdgcn_readfirstlane(bt_lds[gi / gpb - blk0]);
+        const int valid = min(PA_GK, len - gi * PA_GK);
+        issue_group(kc, vc, ring + (it & 1) * PA_STAGE, pb, (gi % gpb) * PA_GK, valid, block_size,
+                    nkv, kvh, lane);
+    };
+    if (nmine > 0) issue(0);
+    if (nmine > 1) issue(1);
+
+    for (int it = 0; it < nmine; ++it) {
+        char* st = ring + (it & 1) * PA_STAGE;
+        if (it + 1 < nmine) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+        // ---- fragment reads: K (row reads, 16 B) and V (transposed reads, 8 B) ----
+        // K: lane (c,g) reads row 16t+c, chunk (4ks+g)^c.  V: lane 4qq+pp of group g reads row
+        // 16t+4g+qq, chunk (2dt+(pp>>1)) ^ ((row&7)<<1), half pp&1.  t=1 is +4096 B in both.
+        const unsigned sbase = lds_addr(st);
+        u32x4_t kf[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const unsigned a = sbase + k_rel[ks];
+            lds_read_b128<0>(kf[0][ks], a);
+            lds_read_b128<4096>(kf[1][ks], a);
+        }
+        u32x2_t vf[8][2];
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            const unsigned a = sbase + v_rel[dt];
+            lds_read_tr16_b64<PA_GK * PA_ROWB>(vf[dt][0], a);
+            lds_read_tr16_b64<PA_GK * PA_ROWB + 4096>(vf[dt][1], a);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]), "+v"(kf[1][0]),
+                       "+v"(kf[1][1]), "+v"(kf[1][2]), "+v"(kf[1][3]), "+v"(vf[0][0]), "+v"(vf[0][1]),
+                       "+v"(vf[1][0]), "+v"(vf[1][1]), "+v"(vf[2][0]), "+v"(vf[2][1]), "+v"(vf[3][0]),
+                       "+v"(vf[3][1]), "+v"(vf[4][0]), "+v"(vf[4][1]), "+v"(vf[5][0]), "+v"(vf[5][1]),
+                       "+v"(vf[6][0]), "+v"(vf[6][1]), "+v"(vf[7][0]), "+v"(vf[7][1])
+                     :
+                     : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // stage is free again: prefetch the group two steps ahead into it
+        if (it + 2 < nmine) issue(it + 2);
+
+        // ---- S^T = K · Q^T (keys on rows, heads on lanes) ----
+        f32x4_t s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[t][ks]),
+                                                              qf[ks], s[t], 0, 0, 0);
+        }
+        // ---- online softmax for head c over this lane's 8 keys (+ 3 sibling lane groups) ----
+        const int gi = G0 + wid + it * PA_WAVES;
+        const int kbase = gi * PA_GK + 4 * g;
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = s[t][r] * scale_log2e;
+                if (kbase + 16 * t + r >= len) v = -INFINITY;
+                s[t][r] = v;
+                mloc = fmaxf(mloc, v);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);  // finite: every group holds >= 1 valid key
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float psum = 0.f;
+        bf16x8_t pf;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[t][r] - m_new);
+                psum += p;
+                pf[4 * t + r] = (__bf16)p;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        // ---- O^T = alpha * O^T + V^T · P^T ----
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            acc[dt] *= alpha;
+            const u32x4_t vv = {vf[dt][0][0], vf[dt][0][1], vf[dt][1][0], vf[dt][1][1]};
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pf,
+                                                             acc[dt], 0, 0, 0);
+        }
+    }
+
+    // ---- merge the 4 waves through LDS (each wave first parks its partial in its own ring) ----
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    float* myo = reinterpret_cast<float*>(ring);             // [16 heads][128 d] fp32 = 8 KiB
+    float* myml = reinterpret_cast<float*>(ring + 8192);     // [16][2]
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+        *reinterpret_cast<f32x4_t*>(myo + c * PA_HD + 16 * dt + 4 * g) = acc[dt];
+    if (g == 0) {
+        myml[2 * c] = m_run;
+        myml[2 * c + 1] = l_run;
+    }
+    __syncthreads();
+    {
+        const int h = tid >> 4, d0 = (tid & 15) * 8;
+        float mw[PA_WAVES], M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < PA_WAVES; ++w) {
+            mw[w] = reinterpret_cast<const float*>(smem + w * PA_RING + 8192)[2 * h];
+            M = fmaxf(M, mw[w]);
+        }
+        float L = 0.f, o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = 0.f;
+#pragma unroll
+        for (int w = 0; w < PA_WAVES; ++w) {
+            const float f = (mw[w] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw[w] - M);
+            L += f * reinterpret_cast<const float*>(smem + w * PA_RING + 8192)[2 * h + 1];
+            const float* src = reinterpret_cast<const float*>(smem + w * PA_RING) + h * PA_HD + d0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] += f * src[i];
+        }
+        if (h < gq) {
+            const int64_t head = (int64_t)kvh * gq + h;
+            if (num_splits == 1) {
+                const float inv = L > 0.f ? 1.0f / L : 0.f;
+                u32x4_t ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = pack2bf(o[2 * i] * inv, o[2 * i + 1] * inv);
+                *reinterpret_cast<u32x4_t*>(out + (b * nh + head) * PA_HD + d0) = ov;
+            } else {
+                float* po = part_o + ((b * nh + head) * num_splits + split) * PA_HD + d0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) po[i] = o[i];
+                if ((tid & 15) == 0) {
+                    float* pm = part_ml + ((b * nh + head) * num_splits + split) * 2;
+                    pm[0] = M;
+                    pm[1] = L;
+                }
+            }
+        }
+    }
+}
+
+// merge kv-splits: one 128-thread workgroup per (sequence, head)
+__global__ __launch_bounds__(128) void paged_attn_reduce_kernel(const float* __restrict__ part_o,
+                                                                const float* __restrict__ part_ml,
+                                                                bf16_t* __restrict__ out,
+                                                                int num_splits) {
+    const int64_t bh = blockIdx.x;
+    const int d = threadIdx.x;
+    float M = -INFINITY;
+    for (int s = 0; s < num_splits; ++s) M = fmaxf(M, part_ml[(bh * num_splits + s) * 2]);
+    float L = 0.f, o = 0.f;
+    for (int s = 0; s < num_splits; ++s) {
+        const float m = part_ml[(bh * num_splits + s) * 2];
+        const float f = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - M);
+        L += f * part_ml[(bh * num_splits + s) * 2 + 1];
+        o += f * part_o[(bh * num_splits + s) * PA_HD + d];
+    }
+    out[bh * PA_HD + d] = f2bf(L > 0.f ? o / L : 0.f);
+}
+
+int choose_splits(int64_t B, int nkv, int max_ctx) {
+    // aim for >= 256 workgroups (one per CU) without making a split shorter than 4 wave-steps
+    const int64_t base = B * nkv;
+    int s = (int)((256 + base - 1) / base);
+    const int max_by_len = max_ctx > 0 ? (max_ctx + 4 * PA_GK * PA_WAVES - 1) / (4 * PA_GK * PA_WAVES) : 1;
+    if (s > max_by_len) s = max_by_len;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return s;
+}
+
+}  // namespace
+
+extern "C" size_t glm_paged_attn_decode_workspace_bytes(int64_t B, int nh, int hd, int num_splits) {
+    const int s = num_splits <= 0 ? 64 : num_splits;
+    if (s == 1) return 0;
+    return (size_t)B * nh * s * (hd + 2) * sizeof(float);
+}
+
+extern "C" int glm_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache,
+                                     const int32_t* context_lens, const int32_t* block_tables,
+                                     int64_t bt_stride, void* out, int64_t B, int nh, int nkv, int hd,
+                                     int block_size, int64_t n_blocks, float scale, int num_splits,
+                                     int max_context_len, void* workspace, size_t workspace_bytes,
+                                     glm_stream_t stream) {
+    GLM_CHECK_ARG(q && k_cache && v_cache && context_lens && block_tables && out, GLM_ERR_INVALID,
+                  "glm_paged_attn_decode: null pointer");
+    GLM_CHECK_ARG(B >= 0 && nh > 0 && nkv > 0 && nh % nkv == 0 && block_size > 0 && bt_stride > 0,
+                  GLM_ERR_INVALID, "glm_paged_attn_decode: bad shape");
+    GLM_CHECK_ARG(hd == PA_HD && nh / nkv <= 16 && block_size % PA_GK == 0 && bt_stride <= PA_MAX_BT &&
+                      nkv <= 65535 && B <= 65535,
+                  GLM_ERR_UNSUPPORTED,
+                  "glm_paged_attn_decode: needs head_dim=128, nh/nkv<=16, block_size%%32==0, "
+                  "<=%d blocks per sequence (hd=%d group=%d block_size=%d bt_stride=%ld)",
+                  PA_MAX_BT, hd, nh / nkv, block_size, (long)bt_stride);
+    GLM_CHECK_ARG(glm_aligned16(q) && glm_aligned16(k_cache) && glm_aligned16(v_cache) &&
+                      glm_aligned16(out),
+                  GLM_ERR_INVALID, "glm_paged_attn_decode: pointers must be 16-byte aligned");
+    if (B == 0) return GLM_OK;
+    if (max_context_len <= 0) max_context_len = (int)(bt_stride * block_size);
+    int splits = num_splits > 0 ? num_splits : choose_splits(B, nkv, max_context_len);
+    if (splits > 64) splits = 64;
+    float* part_o = nullptr;
+    float* part_ml = nullptr;
+    if (splits > 1) {
+        const size_t need = (size_t)B * nh * splits * (PA_HD + 2) * sizeof(float);
+        GLM_CHECK_ARG(workspace != nullptr && workspace_bytes >= need, GLM_ERR_WORKSPACE,
+                      "glm_paged_attn_decode: workspace %zu < %zu bytes", workspace_bytes, need);
+        part_o = (float*)workspace;
+        part_ml = part_o + (size_t)B * nh * splits * PA_HD;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)paged_attn_decode_kernel<0>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, PA_LDS);
+        if (e != hipSuccess) {
+            glm_set_error("glm_paged_attn_decode: hipFuncSetAttribute(%d B LDS): %s", PA_LDS,
+                          hipGetErrorString(e));
+            return GLM_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipStream_t st = glm_s(stream);
+    const float scale_log2e = scale * 1.4426950408889634f;
+    hipLaunchKernelGGL((paged_attn_decode_kernel<0>), dim3((unsigned)splits, (unsigned)nkv, (unsigned)B),
+                       dim3(256), PA_LDS, st, (const bf16_t*)q, (const bf16_t*)k_cache,
+                       (const bf16_t*)v_cache, context_lens, block_tables, bt_stride, (bf16_t*)out,
+                       part_o, part_ml, nh, nkv, block_size, scale_log2e, splits);
+    GLM_CHECK_LAUNCH("glm_paged_attn_decode");
+    if (splits > 1) {
+        hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3((unsigned)(B * nh)), dim3(128), 0, st, part_o,
+                           part_ml, (bf16_t*)out, splits);
+        GLM_CHECK_LAUNCH("glm_paged_attn_decode(reduce)");
+    }
+    return GLM_OK;
+}

@@ -1,0 +1,350 @@
+"""ctypes binding of libglm4moe_hip.so (include/glm4moe_hip.h) for torch tensors on ROCm.
+
+This is the only place where Python touches the C-ABI: raw ``data_ptr()`` values plus the
+current torch stream go in, nothing comes back but a status code.  There is NO CPU or eager
+fallback: if the shared object is missing, or a tensor is not on the GPU, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get(
+    "GLM4MOE_HIP_LIB", os.path.join(_HERE, "..", "lib", "libglm4moe_hip.so"))
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/glm4moe_hip.h one to one
+_SIGNATURES = {
+    "glm_abi_version": (c_int, []),
+    "glm_last_error": (c_char_p, []),
+    "glm_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "glm_add_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                c_float, c_void_p]),
+    "glm_head_rmsnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int,
+                                 c_int, c_float, c_void_p]),
+    "glm_rope_neox": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                              c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
+                              c_int, c_void_p]),
+    "glm_kv_store": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                             c_int64, c_int, c_int64, c_void_p]),
+    "glm_qkv_split_norm_rope_store": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                              c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                              c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "glm_silu_and_mul": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "glm_paged_attn_decode_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "glm_paged_attn_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                      c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64,
+                                      c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "glm_varlen_attn_prefill": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
+                                        c_int, c_int, c_float, c_void_p]),
+    "glm_router_topk": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    "glm_moe_align": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                              c_int, c_int, c_int, c_void_p]),
+    "glm_grouped_gemm_gateup_silu": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "glm_grouped_gemm_down": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                      c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "glm_moe_combine": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                c_int64, c_void_p]),
+    "glm_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                              c_int, c_int, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load_library(path: str | None = None) -> ctypes.CDLL:
+    """dlopen the HIP library and attach prototypes; raises if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = os.path.abspath(path or LIB_PATH)
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"libglm4moe_hip.so not found at {p}: build it with "
+            "`python glm4_moe_nano-vllm_amd/build.py` (there is no CPU fallback)")
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc: int, name: str) -> None:
+    if rc != 0:
+        msg = load_library().glm_last_error()
+        raise RuntimeError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: torch.Tensor | None) -> int | None:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("glm4moe HIP ops need GPU tensors (no CPU fallback)")
+    return t.data_ptr()
+
+
+def _bf16(t: torch.Tensor, name: str) -> None:
+    if t.dtype != torch.bfloat16:
+        raise TypeError(f"{name}: expected bfloat16, got {t.dtype}")
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}: innermost stride must be 1")
+
+
+# ------------------------------------------------------------------------------------------
+# norms
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    _bf16(x, "x"); _bf16(weight, "weight")
+    H = x.shape[-1]
+    x2 = x.reshape(-1, H)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    y = torch.empty_like(x2)
+    _check(load_library().glm_rmsnorm(_p(x2), _p(weight), _p(y), x2.shape[0], H, eps, _stream()),
+           "glm_rmsnorm")
+    return y.view(x.shape)
+
+
+def add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                eps: float) -> tuple[torch.Tensor, torch.Tensor]:
+    _bf16(x, "x"); _bf16(residual, "residual"); _bf16(weight, "weight")
+    H = x.shape[-1]
+    x2 = x.reshape(-1, H).contiguous()
+    r2 = residual.reshape(-1, H).contiguous()
+    y = torch.empty_like(x2)
+    ro = torch.empty_like(x2)
+    _check(load_library().glm_add_rmsnorm(_p(x2), _p(r2), _p(weight), _p(y), _p(ro), x2.shape[0],
+                                          H, eps, _stream()), "glm_add_rmsnorm")
+    return y.view(x.shape), ro.view(x.shape)
+
+
+def head_rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """x: [T, n_heads, hd] (head stride hd, arbitrary token stride) -> contiguous result."""
+    _bf16(x, "x"); _bf16(weight, "weight")
+    T, nh, hd = x.shape
+    if x.stride(1) != hd:
+        x = x.contiguous()
+    y = torch.empty((T, nh, hd), dtype=x.dtype, device=x.device)
+    _check(load_library().glm_head_rmsnorm(_p(x), x.stride(0), _p(weight), _p(y), nh * hd, T, nh,
+                                           hd, eps, _stream()), "glm_head_rmsnorm")
+    return y
+
+
+# ------------------------------------------------------------------------------------------
+# rotary / kv cache
+def rope_neox(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor,
+              cos_sin_cache: torch.Tensor, rotary_dim: int) -> tuple[torch.Tensor, torch.Tensor]:
+    """q: [T,nh,hd], k: [T,nkv,hd] (head stride hd) -> new contiguous (q, k)."""
+    _bf16(q, "q"); _bf16(k, "k")
+    T, nh, hd = q.shape
+    nkv = k.shape[1]
+    if q.stride(1) != hd:
+        q = q.contiguous()
+    if k.stride(1) != hd:
+        k = k.contiguous()
+    assert positions.dtype == torch.int64 and cos_sin_cache.dtype == torch.float32
+    cs = cos_sin_cache.reshape(cos_sin_cache.shape[0], -1)
+    assert cs.is_contiguous() and cs.shape[1] == rotary_dim
+    qo = torch.empty((T, nh, hd), dtype=q.dtype, device=q.device)
+    ko = torch.empty((T, nkv, hd), dtype=k.dtype, device=k.device)
+    _check(load_library().glm_rope_neox(_p(q), q.stride(0), _p(k), k.stride(0), _p(qo), nh * hd,
+                                        _p(ko), nkv * hd, _p(positions.contiguous()), _p(cs),
+                                        cs.shape[0], T, nh, nkv, hd, rotary_dim, _stream()),
+           "glm_rope_neox")
+    return qo, ko
+
+
+def kv_store(key: torch.Tensor, value: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+             slot_mapping: torch.Tensor) -> None:
+    _bf16(key, "key"); _bf16(value, "value")
+    N, nh, hd = key.shape
+    D = nh * hd
+    assert key.stride(1) == hd and value.stride(1) == hd
+    assert k_cache.stride(1) == D and v_cache.stride(1) == D
+    assert slot_mapping.numel() == N and slot_mapping.dtype == torch.int32
+    n_slots = k_cache.numel() // D
+    _check(load_library().glm_kv_store(_p(key), key.stride(0), _p(value), value.stride(0),
+                                       _p(k_cache), _p(v_cache), _p(slot_mapping), N, D, n_slots,
+                                       _stream()), "glm_kv_store")
+
+
+def qkv_split_norm_rope_store(qkv: torch.Tensor, nh: int, nkv: int, hd: int,
+                              positions: torch.Tensor, cos_sin_cache: torch.Tensor,
+                              rotary_dim: int, q_norm_w: torch.Tensor | None,
+                              k_norm_w: torch.Tensor | None, eps: float,
+                              k_cache: torch.Tensor | None, v_cache: torch.Tensor | None,
+                              slot_mapping: torch.Tensor | None, need_kv_out: bool):
+    """Fused split + (qk-norm) + rotary + cache scatter; returns (q, k|None, v|None)."""
+    _bf16(qkv, "qkv")
+    T = qkv.shape[0]
+    assert qkv.shape[1] == (nh + 2 * nkv) * hd
+    cs = cos_sin_cache.reshape(cos_sin_cache.shape[0], -1)
+    q = torch.empty((T, nh, hd), dtype=qkv.dtype, device=qkv.device)
+    k = torch.empty((T, nkv, hd), dtype=qkv.dtype, device=qkv.device) if need_kv_out else None
+    v = torch.empty((T, nkv, hd), dtype=qkv.dtype, device=qkv.device) if need_kv_out else None
+    store = k_cache is not None and k_cache.numel() > 0 and slot_mapping is not None
+    n_slots = (k_cache.numel() // (nkv * hd)) if store else 0
+    _check(load_library().glm_qkv_split_norm_rope_store(
+        _p(qkv), qkv.stride(0), _p(q), _p(k), _p(v), _p(q_norm_w), _p(k_norm_w), eps,
+        _p(positions), _p(cs), cs.shape[0], rotary_dim,
+        _p(k_cache) if store else None, _p(v_cache) if store else None,
+        _p(slot_mapping) if store else None, n_slots, T, nh, nkv, hd, _stream()),
+        "glm_qkv_split_norm_rope_store")
+    return q, k, v
+
+
+def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
+    _bf16(x, "x")
+    I = x.shape[-1] // 2
+    x2 = x.reshape(-1, 2 * I).contiguous()
+    y = torch.empty((x2.shape[0], I), dtype=x.dtype, device=x.device)
+    _check(load_library().glm_silu_and_mul(_p(x2), _p(y), x2.shape[0], I, _stream()),
+           "glm_silu_and_mul")
+    return y.view(*x.shape[:-1], I)
+
+
+# ------------------------------------------------------------------------------------------
+# attention
+_attn_ws: dict = {}
+
+
+def paged_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                      context_lens: torch.Tensor, block_tables: torch.Tensor, scale: float,
+                      num_splits: int = 0, max_context_len: int = 0) -> torch.Tensor:
+    """q: [B,nh,hd]; caches [n_blocks, block_size, nkv, hd] -> [B,nh,hd]."""
+    _bf16(q, "q"); _bf16(k_cache, "k_cache"); _bf16(v_cache, "v_cache")
+    B, nh, hd = q.shape
+    n_blocks, block_size, nkv, _ = k_cache.shape
+    assert q.is_contiguous() and k_cache.is_contiguous() and v_cache.is_contiguous()
+    assert context_lens.dtype == torch.int32 and block_tables.dtype == torch.int32
+    assert block_tables.stride(1) == 1
+    lib = load_library()
+    need = lib.glm_paged_attn_decode_workspace_bytes(B, nh, hd, num_splits)
+    ws = None
+    if need:
+        key = (q.device, need)
+        ws = _attn_ws.get(key)
+        if ws is None:
+            ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+            _attn_ws[key] = ws
+    out = torch.empty_like(q)
+    _check(lib.glm_paged_attn_decode(_p(q), _p(k_cache), _p(v_cache), _p(context_lens),
+                                     _p(block_tables), block_tables.stride(0), _p(out), B, nh, nkv,
+                                     hd, block_size, n_blocks, scale, num_splits, max_context_len,
+                                     _p(ws), need, _stream()), "glm_paged_attn_decode")
+    return out
+
+
+def varlen_attn_prefill(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, scale,
+                        block_tables=None, block_size=256) -> torch.Tensor:
+    _bf16(q, "q"); _bf16(k, "k"); _bf16(v, "v")
+    Tq, nh, hd = q.shape
+    nkv = k.shape[-2]
+    B = cu_seqlens_q.numel() - 1
+    out = torch.empty((Tq, nh, hd), dtype=q.dtype, device=q.device)
+    q = q.contiguous(); k = k.contiguous(); v = v.contiguous()
+    bts = block_tables.stride(0) if block_tables is not None else 0
+    _check(load_library().glm_varlen_attn_prefill(_p(q), _p(k), _p(v), _p(cu_seqlens_q),
+                                                  _p(cu_seqlens_k), _p(block_tables), bts, _p(out),
+                                                  B, max_seqlen_q, nh, nkv, hd, block_size, scale,
+                                                  _stream()), "glm_varlen_attn_prefill")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# MoE
+def router_topk(x: torch.Tensor, gate_w: torch.Tensor, bias: torch.Tensor, k: int,
+                routed_scaling_factor: float, return_logits: bool = False):
+    _bf16(x, "x"); _bf16(gate_w, "gate_w")
+    assert bias.dtype == torch.float32
+    T, H = x.shape
+    E = gate_w.shape[0]
+    x = x.contiguous()
+    idx = torch.empty((T, k), dtype=torch.int64, device=x.device)
+    w = torch.empty((T, k), dtype=torch.bfloat16, device=x.device)
+    logits = torch.empty((T, E), dtype=torch.bfloat16, device=x.device) if return_logits else None
+    _check(load_library().glm_router_topk(_p(x), _p(gate_w), _p(bias), _p(idx), _p(w), _p(logits),
+                                          T, H, E, k, routed_scaling_factor, _stream()),
+           "glm_router_topk")
+    return (idx, w, logits) if return_logits else (idx, w)
+
+
+def moe_align(topk_idx: torch.Tensor, topk_w: torch.Tensor, E: int, with_shared: bool):
+    T, k = topk_idx.shape
+    G = E + (1 if with_shared else 0)
+    R = T * k + (T if with_shared else 0)
+    dev = topk_idx.device
+    offs = torch.empty(G + 1, dtype=torch.int32, device=dev)
+    tok = torch.empty(R, dtype=torch.int32, device=dev)
+    scale = torch.empty(R, dtype=torch.bfloat16, device=dev)
+    pos = torch.empty(T * k, dtype=torch.int32, device=dev)
+    _check(load_library().glm_moe_align(_p(topk_idx), _p(topk_w), _p(offs), _p(tok), _p(scale),
+                                        _p(pos), T, k, E, 1 if with_shared else 0, _stream()),
+           "glm_moe_align")
+    return offs, tok, scale, pos
+
+
+def grouped_gemm_gateup_silu(x, w13, expert_offsets, sorted_token, R: int) -> torch.Tensor:
+    """x [T,H]; w13 [G, 2I, H] -> act [R, I]."""
+    _bf16(x, "x"); _bf16(w13, "w13")
+    G, I2, H = w13.shape
+    I = I2 // 2
+    assert w13.is_contiguous()
+    act = torch.empty((R, I), dtype=x.dtype, device=x.device)
+    _check(load_library().glm_grouped_gemm_gateup_silu(_p(x), x.stride(0), _p(w13),
+                                                       _p(expert_offsets), _p(sorted_token),
+                                                       _p(act), R, H, I, G, _stream()),
+           "glm_grouped_gemm_gateup_silu")
+    return act
+
+
+def grouped_gemm_down(act, w2, expert_offsets, sorted_scale, n_scaled_groups: int) -> torch.Tensor:
+    """act [R,I]; w2 [G, H, I] -> y [R, H]."""
+    _bf16(act, "act"); _bf16(w2, "w2")
+    G, H, I = w2.shape
+    R = act.shape[0]
+    assert w2.is_contiguous() and act.is_contiguous()
+    y = torch.empty((R, H), dtype=act.dtype, device=act.device)
+    _check(load_library().glm_grouped_gemm_down(_p(act), _p(w2), _p(expert_offsets),
+                                                _p(sorted_scale), n_scaled_groups, _p(y), H, R, H,
+                                                I, G, _stream()), "glm_grouped_gemm_down")
+    return y
+
+
+def moe_combine(y, pair_pos, T: int, k: int, shared_base: int) -> torch.Tensor:
+    H = y.shape[1]
+    out = torch.empty((T, H), dtype=y.dtype, device=y.device)
+    _check(load_library().glm_moe_combine(_p(y), y.stride(0), _p(pair_pos), _p(out), T, k, H,
+                                          shared_base, _stream()), "glm_moe_combine")
+    return out
+
+
+def gemm_bf16(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """y = bf16(x @ w.T + bias); x [..., K], w [N, K]."""
+    _bf16(x, "x"); _bf16(w, "w")
+    K = x.shape[-1]
+    N = w.shape[0]
+    assert w.shape[1] == K and w.is_contiguous()
+    x2 = x.reshape(-1, K)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    _check(load_library().glm_gemm_bf16(_p(x2), x2.stride(0), _p(w), _p(bias), _p(y), N, M, N, K,
+                                        _stream()), "glm_gemm_bf16")
+    return y.view(*x.shape[:-1], N)

@@ -1,0 +1,176 @@
+/*
+ * glm4moe_hip.h — C-ABI of libglm4moe_hip.so: the MI355X (gfx950) kernels behind the
+ * GLM-4-MoE per-layer forward path of nano-vllm.
+ *
+ * The reference has no FFI: its operator surface is Python nn.Modules.  Each
+ * entry point below replaces the device work of one reference operator; the Python modules in
+ * glm4_moe_nano-vllm_amd/nanovllm/ keep the reference's names and call these through ctypes
+ * (INTEGRATION.md shows the binding a maintainer would add to the reference).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *     (PyTorch storage).  The library never allocates, frees, synchronises or reads back:
+ *     every call only enqueues kernels on `stream` (a hipStream_t), so a sequence of calls
+ *     can be captured in a hipGraph.
+ *   - bf16 tensors are passed as `const void*` / `void*` (2-byte elements, row-major,
+ *     innermost stride 1).  "ld*" / "*_stride" arguments are in ELEMENTS.
+ *   - return value: GLM_OK (0) or a negative GLM_ERR_* code; glm_last_error() returns a
+ *     thread-local message for the last failing call.  No exceptions cross the ABI.
+ *   - thread safety: calls are re-entrant; one host thread per stream is the intended use
+ *     (one process per GPU, reference: nanovllm/engine/llm_engine.py:23-30).
+ */
+#ifndef GLM4MOE_HIP_H
+#define GLM4MOE_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* glm_stream_t; /* hipStream_t */
+
+#define GLM_OK               0
+#define GLM_ERR_INVALID     (-1) /* bad pointer / size / alignment */
+#define GLM_ERR_UNSUPPORTED (-2) /* shape outside what the gfx950 kernels implement */
+#define GLM_ERR_LAUNCH      (-3) /* hipGetLastError() != hipSuccess after the launch */
+#define GLM_ERR_WORKSPACE   (-4) /* workspace too small */
+
+/* ABI version (bumped when a signature changes) and last error text. */
+int         glm_abi_version(void);
+const char* glm_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * a2  layers/layernorm.py:17-26  RMSNorm.rms_forward
+ *     y = bf16( bf16(x32 * rsqrt(mean(x32^2) + eps)) * w )         x,y: [T,H] bf16, w: [H] bf16
+ * ------------------------------------------------------------------------------------- */
+int glm_rmsnorm(const void* x, const void* weight, void* y,
+                int64_t T, int H, float eps, glm_stream_t stream);
+
+/* a3  layers/layernorm.py:29-40  RMSNorm.add_rms_forward
+ *     s = f32(x) + f32(residual_in); residual_out = bf16(s); y = bf16(bf16(s*rstd(s)) * w)
+ *     residual_out may alias residual_in or x; y may alias x.                              */
+int glm_add_rmsnorm(const void* x, const void* residual_in, const void* weight,
+                    void* y, void* residual_out,
+                    int64_t T, int H, float eps, glm_stream_t stream);
+
+/* a4  layers/RMSNorm.py:19-33  per-head RMSNorm (weight multiply in fp32, one rounding)
+ *     x: [T, n_heads, hd] with token stride x_token_stride (head stride = hd); y likewise.  */
+int glm_head_rmsnorm(const void* x, int64_t x_token_stride, const void* weight,
+                     void* y, int64_t y_token_stride,
+                     int64_t T, int n_heads, int hd, float eps, glm_stream_t stream);
+
+/* a6  layers/rotary_embedding.py:6-14,39-55  NeoX rotary on the first rotary_dim dims of each
+ *     head, pass-through for the rest.  cos_sin_cache: f32 [max_pos, rotary_dim] = cos|sin.
+ *     q: [T,nh,hd] (token stride q_stride), k: [T,nkv,hd]; outputs contiguous-or-strided
+ *     (q_out may alias q, k_out may alias k).  positions: int64 [T].                        */
+int glm_rope_neox(const void* q, int64_t q_stride, const void* k, int64_t k_stride,
+                  void* q_out, int64_t q_out_stride, void* k_out, int64_t k_out_stride,
+                  const int64_t* positions, const float* cos_sin_cache, int64_t max_pos,
+                  int64_t T, int nh, int nkv, int hd, int rotary_dim, glm_stream_t stream);
+
+/* a7  layers/attention.py:10-42  store_kvcache: cache.view(-1,D)[slot] = k[i].view(D); slot -1
+ *     skipped.  k,v: [N, D] rows with token strides; caches: [n_slots, D] contiguous.       */
+int glm_kv_store(const void* k, int64_t k_stride, const void* v, int64_t v_stride,
+                 void* k_cache, void* v_cache, const int32_t* slot_mapping,
+                 int64_t N, int D, int64_t n_slots, glm_stream_t stream);
+
+/* a4+a6+a7 fused (models/glm4_moe/attention_new.py:329-357): from the packed projection
+ *     qkv [T, (nh+2nkv)*hd] (row stride qkv_stride) produce q_out [T,nh,hd] (contiguous) with
+ *     optional per-head RMSNorm + rotary, k_out/v_out [T,nkv,hd] (contiguous, may be NULL), and
+ *     scatter the rotated K and V rows into the paged cache (k_cache NULL or slot_mapping NULL
+ *     = no store).  q_norm_w / k_norm_w NULL = use_qk_norm off.                             */
+int glm_qkv_split_norm_rope_store(const void* qkv, int64_t qkv_stride,
+                                  void* q_out, void* k_out, void* v_out,
+                                  const void* q_norm_w, const void* k_norm_w, float eps,
+                                  const int64_t* positions, const float* cos_sin_cache,
+                                  int64_t max_pos, int rotary_dim,
+                                  void* k_cache, void* v_cache, const int32_t* slot_mapping,
+                                  int64_t n_slots,
+                                  int64_t T, int nh, int nkv, int hd, glm_stream_t stream);
+
+/* layers/activation.py:12-14  SiluAndMul: y[t,i] = bf16( bf16(silu(x[t,i])) * x[t,I+i] )    */
+int glm_silu_and_mul(const void* x, void* y, int64_t T, int I, glm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a8  layers/attention.py:101-107  flash_attn_with_kvcache decode: one query token per
+ *     sequence over a paged KV cache.
+ *     q: [B,nh,hd] contiguous; caches: [n_blocks, block_size, nkv, hd]; context_lens int32[B]
+ *     (0 ⇒ zero output row); block_tables int32 [B, bt_stride] (-1 padded); out [B,nh,hd].
+ *     workspace: glm_paged_attn_decode_workspace_bytes() bytes (may be NULL when that is 0).
+ *     num_splits: 0 = choose; ≥1 = forced number of KV splits per (sequence, kv-head).       */
+size_t glm_paged_attn_decode_workspace_bytes(int64_t B, int nh, int hd, int num_splits);
+int glm_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache,
+                          const int32_t* context_lens, const int32_t* block_tables,
+                          int64_t bt_stride, void* out,
+                          int64_t B, int nh, int nkv, int hd, int block_size, int64_t n_blocks,
+                          float scale, int num_splits, int max_context_len,
+                          void* workspace, size_t workspace_bytes, glm_stream_t stream);
+
+/* a9  layers/attention.py:85-100  flash_attn_varlen_func(causal=True[, block_table]):
+ *     q: [Tq,nh,hd]; if block_tables == NULL k,v: [Tk,nkv,hd] contiguous, else k,v are the
+ *     paged caches.  cu_seqlens_q/k int32 [B+1].  Causal mask is bottom-right aligned
+ *     (query i of a sequence sees keys 0..(lk-lq)+i).                                        */
+int glm_varlen_attn_prefill(const void* q, const void* k, const void* v,
+                            const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                            const int32_t* block_tables, int64_t bt_stride,
+                            void* out, int64_t B, int max_seqlen_q,
+                            int nh, int nkv, int hd, int block_size, float scale,
+                            glm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * a11 models/glm4_moe/moe.py:28-50  GlmMoeSelectTopk: logits=bf16(x·Wgᵀ); s=bf16(sigmoid);
+ *     choice=f32(s)+bias; top-k (ties → lowest expert id); w=s[idx]; w/=bf16(sum w)+1e-20;
+ *     w*=routed_scaling_factor.  Outputs: topk_idx int64 [T,k] (ascending expert id per row),
+ *     topk_w bf16 [T,k] (same order); logits_out bf16 [T,E] optional (NULL = not written).   */
+int glm_router_topk(const void* x, const void* gate_w, const float* e_score_correction_bias,
+                    int64_t* topk_idx, void* topk_w, void* logits_out,
+                    int64_t T, int H, int E, int k, float routed_scaling_factor,
+                    glm_stream_t stream);
+
+/* Token→expert bucketing for the grouped GEMM (replaces the mask/where/any loop of
+ *     moe.py:135-147).  Rows are grouped by expert id ascending; if with_shared != 0 one more
+ *     group (id E) holding every token once is appended (the shared expert, moe.py:165).
+ *     G = E + (with_shared?1:0), R = T*k + (with_shared?T:0).
+ *     expert_offsets int32 [G+1]; sorted_token int32 [R]; sorted_scale bf16 [R] (routing
+ *     weight of the row; 1.0 for shared rows); pair_pos int32 [T*k] (sorted row of pair).    */
+int glm_moe_align(const int64_t* topk_idx, const void* topk_w,
+                  int32_t* expert_offsets, int32_t* sorted_token, void* sorted_scale,
+                  int32_t* pair_pos, int64_t T, int k, int E, int with_shared,
+                  glm_stream_t stream);
+
+/* a13 (first half) models/glm4_moe/mlp.py:49-53 for every group at once:
+ *     act[r, i] = bf16( bf16(silu(bf16(x[tok(r)]·Wg_gᵀ))) * bf16(x[tok(r)]·Wu_gᵀ) )
+ *     w13: [G, 2I, H] (rows gate|up, mlp.py:118).  expert_offsets NULL ⇒ one group of R rows;
+ *     sorted_token NULL ⇒ tok(r) = r.  x: [T,H] (row stride ldx); act: [R,I] contiguous.    */
+int glm_grouped_gemm_gateup_silu(const void* x, int64_t ldx, const void* w13,
+                                 const int32_t* expert_offsets, const int32_t* sorted_token,
+                                 void* act, int64_t R, int H, int I, int G,
+                                 glm_stream_t stream);
+
+/* a13 (second half) + the per-row scale of moe.py:149:
+ *     y[r, :] = bf16( bf16(act[r]·Wd_gᵀ) * scale[r] ) for groups g < n_scaled_groups,
+ *     y[r, :] = bf16(act[r]·Wd_gᵀ) otherwise (shared expert / dense MLP).
+ *     w2: [G, H, I]; y: [R, H] (row stride ldy).                                            */
+int glm_grouped_gemm_down(const void* act, const void* w2,
+                          const int32_t* expert_offsets, const void* sorted_scale,
+                          int n_scaled_groups, void* y, int64_t ldy,
+                          int64_t R, int H, int I, int G, glm_stream_t stream);
+
+/* a12 models/glm4_moe/moe.py:133,151,171: out[t] = bf16-accumulate of the token's k routed
+ *     rows in ascending expert order (one bf16 rounding per add, starting from 0), then
+ *     + shared row (bf16 add) when shared_base >= 0 (row index shared_base + t of y).       */
+int glm_moe_combine(const void* y, int64_t ldy, const int32_t* pair_pos, void* out,
+                    int64_t T, int k, int H, int64_t shared_base, glm_stream_t stream);
+
+/* a5/a10 layers/linear.py:53,75,152  y = bf16(x·Wᵀ + b): x [M,K] (ldx), W [N,K] contiguous,
+ *     bias [N] bf16 or NULL, y [M,N] (ldy).  Picks the weight-streaming small-M kernel or the
+ *     LDS-tiled MFMA kernel from M.                                                         */
+int glm_gemm_bf16(const void* x, int64_t ldx, const void* w, const void* bias,
+                  void* y, int64_t ldy, int64_t M, int N, int K, glm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLM4MOE_HIP_H */

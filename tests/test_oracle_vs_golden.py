@@ -1,0 +1,102 @@
+"""Pin the CPU oracle against vectors produced by the reference itself
+(tests/golden/gen_golden.py).  Same torch build, same inputs ⇒ bit equality is required."""
+import torch
+
+from oracle import glm4_moe_oracle as O
+from util import layer_weights_from_golden, load_golden
+
+
+def eq(a, b, what):
+    assert a.dtype == b.dtype and a.shape == b.shape, what
+    assert torch.equal(a, b), f"{what}: {int((a != b).sum())} / {a.numel()} elements differ"
+
+
+def test_elementwise_ops():
+    t, m = load_golden("ops")
+    eq(O.rms_forward(t["x"], t["ln_w"], m["eps"]), t["y_rms"], "rms_forward")
+    y, r = O.add_rms_forward(t["x"], t["res"], t["ln_w"], m["eps"])
+    eq(y, t["y_add"], "add_rms y")
+    eq(r, t["r_add"], "add_rms residual")
+    eq(O.head_rmsnorm(t["xh"], t["hn_w"], m["eps"]), t["y_head"], "head_rmsnorm")
+    eq(O.build_cos_sin_cache(64, 1024, m["rope_base"]), t["cos_sin"], "cos_sin_cache")
+    q, k = O.rope_neox(t["pos"], t["q"], t["k"], t["cos_sin"], 64)
+    eq(q, t["q_r"], "rope q")
+    eq(k, t["k_r"], "rope k")
+    q, k = O.rope_neox(t["pos2"], t["q2"], t["k2"], t["cos_sin2"], 16)
+    eq(q, t["q2_r"], "rope(full) q")
+    eq(k, t["k2_r"], "rope(full) k")
+    eq(O.silu_and_mul(t["xs"]), t["y_silu"], "silu_and_mul")
+    eq(O.linear(t["x"], t["lin_w"], t["lin_b"]), t["y_lin"], "linear+bias")
+
+
+def test_router():
+    t, meta = load_golden("router")
+    for tag, m in meta.items():
+        idx, w = O.router(t[f"{tag}.x"], t[f"{tag}.gate_w"], t[f"{tag}.bias"], m["k"], m["rsf"])
+        eq(idx, t[f"{tag}.idx"], f"router[{tag}] idx")
+        eq(w, t[f"{tag}.w"], f"router[{tag}] w")
+
+
+def test_mlp_and_moe():
+    t, _ = load_golden("mlp")
+    eq(O.mlp(t["x"], t["w13"], t["w2"]), t["y"], "mlp")
+    t, cfg = load_golden("moe")
+    E = cfg["n_routed_experts"]
+    w13 = torch.stack([t[f"experts.{e}.gate_up_proj.weight"] for e in range(E)])
+    w2 = torch.stack([t[f"experts.{e}.down_proj.weight"] for e in range(E)])
+    y = O.moe(t["x"], t["gate.weight"], t["gate.e_score_correction_bias"],
+              cfg["num_experts_per_tok"], cfg["routed_scaling_factor"], w13, w2,
+              t["shared_experts.gate_up_proj.weight"], t["shared_experts.down_proj.weight"])
+    eq(y, t["y"], "moe")
+
+
+def _prefill(tag):
+    t, cfg = load_golden(tag)
+    lw = layer_weights_from_golden(t, cfg)
+    kc = torch.zeros(2, 256, 2, 128, dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    meta = O.AttnMeta(True, slot_mapping=t["slot_mapping"], cu_seqlens_q=t["cu_seqlens"],
+                      cu_seqlens_k=t["cu_seqlens"])
+    out, res = O.decoder_layer(t["positions"], t["h"], None, lw, cfg, t["cos_sin"], kc, vc, meta)
+    eq(out, t["out_first"], f"{tag} out (first layer form)")
+    eq(res, t["res_first"], f"{tag} residual (first layer form)")
+    out, res = O.decoder_layer(t["positions"], t["h"], t["res_in"], lw, cfg, t["cos_sin"], kc, vc, meta)
+    eq(out, t["out"], f"{tag} out")
+    eq(res, t["res"], f"{tag} residual")
+    s = t["slot_mapping"].long()
+    eq(kc.view(-1, 256)[s], t["k_rows"], f"{tag} k cache rows")
+    eq(vc.view(-1, 256)[s], t["v_rows"], f"{tag} v cache rows")
+
+
+def test_layer_prefill_moe():
+    _prefill("layer_moe_prefill")
+
+
+def test_layer_prefill_dense():
+    _prefill("layer_dense_prefill")
+
+
+def test_layer_prefill_qknorm():
+    _prefill("layer_moe_prefill_qknorm")
+
+
+def _decode(tag):
+    t, cfg = load_golden(tag)
+    lw = layer_weights_from_golden(t, cfg)
+    kc, vc = t["k_cache_in"].clone(), t["v_cache_in"].clone()
+    meta = O.AttnMeta(False, slot_mapping=t["slot_mapping"], context_lens=t["context_lens"],
+                      block_tables=t["block_tables"])
+    out, res = O.decoder_layer(t["positions"], t["h"], t["res_in"], lw, cfg, t["cos_sin"], kc, vc, meta)
+    eq(out, t["out"], f"{tag} out")
+    eq(res, t["res"], f"{tag} residual")
+    s = t["slot_mapping"].long()
+    eq(kc.view(-1, 256)[s], t["k_rows"], f"{tag} k cache rows")
+    eq(vc.view(-1, 256)[s], t["v_rows"], f"{tag} v cache rows")
+
+
+def test_layer_decode_moe():
+    _decode("layer_moe_decode")
+
+
+def test_layer_decode_qknorm():
+    _decode("layer_moe_decode_qknorm")
