@@ -1,0 +1,376 @@
+"""GPU parity tests: every HIP kernel, called through the C-ABI, against the CPU oracle on
+seeded inputs and against the golden vectors minted from the reference.
+
+Tolerances (stated per test): elementwise ops with no reduction are BIT-EXACT; ops behind an
+fp32 reduction (norms, GEMMs) may differ from the CPU's summation order by one bf16 ulp on a
+small fraction of elements; attention is compared with rtol 1.6e-2 / atol 4e-3 (bf16 output,
+P rounded to bf16 before P·V as in flash-attn; parity unpinned at that boundary).
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import glm4_moe_oracle as O
+from util import assert_close_bf16, load_golden
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from nanovllm import hip_ops
+    hip_ops.load_library()
+    return hip_ops
+
+
+def dev(t):
+    return t.cuda() if t is not None else None
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=BF):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def assert_mixed(a, e, rtol, atol, what=""):
+    a, e = a.detach().cpu().float(), e.detach().cpu().float()
+    err = (a - e).abs()
+    lim = atol + rtol * e.abs()
+    bad = err > lim
+    assert not bool(bad.any()), (f"{what}: {int(bad.sum())}/{a.numel()} outside tolerance, "
+                                 f"max err {float(err.max()):.4g}, max ref {float(e.abs().max()):.4g}")
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,H", [(1, 128), (5, 4096), (33, 64), (7, 100), (3, 8192), (2, 16384)])
+def test_rmsnorm(ops, T, H):
+    x, r, w = rnd(T, H, seed=1), rnd(T, H, seed=2), (1 + rnd(H, seed=3, scale=0.1).float()).to(BF)
+    eps = 1e-5
+    assert_close_bf16(ops.rmsnorm(dev(x), dev(w), eps), O.rms_forward(x, w, eps), 1, 0.02, what="rmsnorm")
+    y, ro = ops.add_rmsnorm(dev(x), dev(r), dev(w), eps)
+    ye, re = O.add_rms_forward(x, r, w, eps)
+    assert torch.equal(ro.cpu(), re), "residual_out must be bit-exact (single fp32 add, one rounding)"
+    assert_close_bf16(y, ye, 1, 0.02, what="add_rmsnorm")
+
+
+def test_elementwise_golden(ops):
+    t, m = load_golden("ops")
+    eps = m["eps"]
+    assert_close_bf16(ops.rmsnorm(dev(t["x"]), dev(t["ln_w"]), eps), t["y_rms"], 1, 0.02, what="rms golden")
+    y, r = ops.add_rmsnorm(dev(t["x"]), dev(t["res"]), dev(t["ln_w"]), eps)
+    assert torch.equal(r.cpu(), t["r_add"])
+    assert_close_bf16(y, t["y_add"], 1, 0.02, what="add_rms golden")
+    assert_close_bf16(ops.head_rmsnorm(dev(t["xh"]), dev(t["hn_w"]), eps), t["y_head"], 1, 0.02, what="head golden")
+    q, k = ops.rope_neox(dev(t["pos"]), dev(t["q"]), dev(t["k"]), dev(t["cos_sin"]), 64)
+    assert torch.equal(q.cpu(), t["q_r"]) and torch.equal(k.cpu(), t["k_r"]), "rope must be bit-exact"
+    q, k = ops.rope_neox(dev(t["pos2"]), dev(t["q2"]), dev(t["k2"]), dev(t["cos_sin2"]), 16)
+    assert torch.equal(q.cpu(), t["q2_r"]) and torch.equal(k.cpu(), t["k2_r"]), "rope(scalar path) bit-exact"
+    assert_close_bf16(ops.silu_and_mul(dev(t["xs"])), t["y_silu"], 1, 0.01, what="silu golden")
+    assert_close_bf16(ops.gemm_bf16(dev(t["x"]), dev(t["lin_w"]), dev(t["lin_b"])), t["y_lin"], 1, 0.03, what="linear golden")
+
+
+def test_head_rmsnorm_strided(ops):
+    T, nh, hd = 9, 6, 128
+    big = rnd(T, (nh + 4) * hd, seed=5)
+    x = big[:, : nh * hd].view(T, nh, hd)  # token stride (nh+4)*hd
+    w = (1 + rnd(hd, seed=6, scale=0.1).float()).to(BF)
+    assert_close_bf16(ops.head_rmsnorm(dev(big)[:, : nh * hd].view(T, nh, hd), dev(w), 1e-6),
+                      O.head_rmsnorm(x, w, 1e-6), 1, 0.02, what="head_rmsnorm strided")
+    xs = rnd(4, 3, 24, seed=7)  # hd=24: scalar fallback
+    ws = (1 + rnd(24, seed=8, scale=0.1).float()).to(BF)
+    assert_close_bf16(ops.head_rmsnorm(dev(xs), dev(ws), 1e-6), O.head_rmsnorm(xs, ws, 1e-6), 1, 0.03, what="head scalar")
+
+
+def test_silu_and_mul(ops):
+    for T, I in [(3, 1408), (5, 100), (1, 8)]:
+        x = rnd(T, 2 * I, seed=T, scale=3.0)
+        assert_close_bf16(ops.silu_and_mul(dev(x)), O.silu_and_mul(x), 1, 0.01, what=f"silu {T}x{I}")
+
+
+def test_kv_store(ops):
+    N, nkv, hd, nslots = 7, 2, 128, 3 * 256
+    qkv = rnd(N, (4 + 2 * nkv) * hd, seed=11)
+    k = qkv[:, 4 * hd: (4 + nkv) * hd].view(N, nkv, hd)
+    v = qkv[:, (4 + nkv) * hd:].view(N, nkv, hd)
+    slots = torch.tensor([5, -1, 700, 256, 0, 767, -1], dtype=torch.int32)
+    kc, vc = rnd(3, 256, nkv, hd, seed=12), rnd(3, 256, nkv, hd, seed=13)
+    kce, vce = kc.clone(), vc.clone()
+    O.store_kvcache(k, v, kce, vce, slots)
+    kcd, vcd = dev(kc), dev(vc)
+    qd = dev(qkv)
+    ops.kv_store(qd[:, 4 * hd: (4 + nkv) * hd].view(N, nkv, hd), qd[:, (4 + nkv) * hd:].view(N, nkv, hd),
+                 kcd, vcd, dev(slots))
+    assert torch.equal(kcd.cpu(), kce) and torch.equal(vcd.cpu(), vce)
+
+
+@pytest.mark.parametrize("qknorm", [False, True])
+def test_qkv_split_norm_rope_store(ops, qknorm):
+    T, nh, nkv, hd, rd = 11, 12, 2, 128, 64
+    qkv = rnd(T, (nh + 2 * nkv) * hd, seed=21)
+    pos = torch.randint(0, 1024, (T,), generator=torch.Generator().manual_seed(22))
+    cs = O.build_cos_sin_cache(rd, 1024, 10000.0)
+    qn = (1 + rnd(hd, seed=23, scale=0.1).float()).to(BF) if qknorm else None
+    kn = (1 + rnd(hd, seed=24, scale=0.1).float()).to(BF) if qknorm else None
+    slots = torch.tensor([3, 258, -1, 0, 511, 100, 101, 102, -1, 300, 7], dtype=torch.int32)
+    kc, vc = rnd(2, 256, nkv, hd, seed=25), rnd(2, 256, nkv, hd, seed=26)
+    # oracle composition (attention_new.py:329-357 + layers/attention.py:75)
+    q, k, v = qkv.split([nh * hd, nkv * hd, nkv * hd], dim=-1)
+    q, k, v = q.reshape(T, nh, hd), k.reshape(T, nkv, hd), v.reshape(T, nkv, hd)
+    if qknorm:
+        q, k = O.head_rmsnorm(q, qn, 1e-5), O.head_rmsnorm(k, kn, 1e-5)
+    qe, ke = O.rope_neox(pos, q, k, cs, rd)
+    kce, vce = kc.clone(), vc.clone()
+    O.store_kvcache(ke, v, kce, vce, slots)
+    kcd, vcd = dev(kc), dev(vc)
+    qo, ko, vo = ops.qkv_split_norm_rope_store(dev(qkv), nh, nkv, hd, dev(pos), dev(cs), rd, dev(qn), dev(kn),
+                                               1e-5, kcd, vcd, dev(slots), True)
+    assert torch.equal(vo.cpu(), v), "v pass-through must be bit-exact"
+    assert torch.equal(vcd.cpu(), vce), "v cache scatter must be bit-exact"
+    if qknorm:  # one fp32 reduction in front of the rotary: allow 1 ulp
+        assert_close_bf16(qo, qe, 1, 0.02, what="q")
+        assert_close_bf16(ko, ke, 1, 0.02, what="k")
+        assert_close_bf16(kcd, kce, 1, 0.02, what="k cache")
+    else:
+        assert torch.equal(qo.cpu(), qe) and torch.equal(ko.cpu(), ke), "split+rope must be bit-exact"
+        assert torch.equal(kcd.cpu(), kce), "k cache scatter must be bit-exact"
+
+
+# ------------------------------------------------------------------------------------------
+def _paged_case(lens, nh, nkv, seed, block_size=256, hd=128, extra_blocks=2):
+    g = torch.Generator().manual_seed(seed)
+    B = len(lens)
+    nb = [max(1, (n + block_size - 1) // block_size) for n in lens]
+    total = sum(nb) + extra_blocks
+    perm = torch.randperm(total, generator=g)
+    maxb = max(nb)
+    bt = torch.full((B, maxb), -1, dtype=torch.int32)
+    c = 0
+    for b in range(B):
+        for j in range(nb[b]):
+            bt[b, j] = int(perm[c]); c += 1
+    kc = torch.randn(total, block_size, nkv, hd, generator=g).to(BF)
+    vc = torch.randn(total, block_size, nkv, hd, generator=g).to(BF)
+    q = torch.randn(B, nh, hd, generator=g).to(BF)
+    return q, kc, vc, torch.tensor(lens, dtype=torch.int32), bt
+
+
+@pytest.mark.parametrize("lens,nh,nkv", [
+    ([300, 256, 5], 4, 2), ([1, 31, 32, 33, 1000], 24, 2), ([0, 64, 0, 700], 8, 8),
+    ([2048, 129], 96, 8), ([17], 16, 1)])
+@pytest.mark.parametrize("splits", [0, 1, 3])
+def test_paged_attn_decode(ops, lens, nh, nkv, splits):
+    q, kc, vc, cl, bt = _paged_case(lens, nh, nkv, seed=len(lens) * 7 + nh)
+    scale = 128 ** -0.5
+    ref = O.attn_decode_paged(q, kc, vc, cl, bt, scale)
+    out = ops.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(cl), dev(bt), scale, num_splits=splits)
+    assert torch.isfinite(out.float()).all()
+    for b, n in enumerate(lens):
+        if n == 0:
+            assert float(out[b].float().abs().max()) == 0.0, "context_len 0 must give a zero row"
+    assert_mixed(out, ref, 1.6e-2, 4e-3, f"paged decode lens={lens} splits={splits}")
+
+
+def test_paged_attn_decode_spiky_scores(ops):
+    """Force the online-softmax rescale: one key far above the rest late in the sequence."""
+    q, kc, vc, cl, bt = _paged_case([777], 12, 1, seed=99)
+    blk, off = int(bt[0, 2]), 600 - 512
+    kc[blk, off] = (q[0, 3].float() * 4.0).to(BF)  # huge score for head 3 at key 600
+    scale = 128 ** -0.5
+    ref = O.attn_decode_paged(q, kc, vc, cl, bt, scale)
+    for s in (1, 2):
+        out = ops.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(cl), dev(bt), scale, num_splits=s)
+        assert_mixed(out, ref, 1.6e-2, 4e-3, "spiky")
+
+
+# ------------------------------------------------------------------------------------------
+def _check_router(ops, x, gw, bias, k, rsf, what, allow_flip_rows=0.0):
+    idx, w, logits = ops.router_topk(dev(x), dev(gw), dev(bias), k, rsf, return_logits=True)
+    idx, w, logits = idx.cpu(), w.cpu(), logits.cpu()
+    ridx, rw = O.router(x, gw, bias, k, rsf)
+    rlogits, rscores, rchoice = O.router_scores(x, gw, bias)
+    T = x.shape[0]
+    assert bool((idx[:, 1:] > idx[:, :-1]).all()), "indices must be strictly ascending per row"
+    n_unexplained, n_flip = 0, 0
+    for t in range(T):
+        same = set(idx[t].tolist()) == set(ridx[t].tolist())
+        if same:
+            order = torch.argsort(ridx[t])
+            if not torch.equal(w[t], rw[t][order]):
+                # weights may differ by one ulp only if a selected score's sigmoid rounded differently
+                assert_close_bf16(w[t], rw[t][order], 1, 1.0, what=f"{what} row {t} weights")
+            continue
+        logits_differ = not torch.equal(logits[t], rlogits[t])
+        sel = torch.zeros(gw.shape[0], dtype=torch.bool); sel[ridx[t]] = True
+        tie = float(rchoice[t][sel].min()) == float(rchoice[t][~sel].max())
+        if logits_differ or tie:
+            n_flip += 1
+        else:
+            n_unexplained += 1
+    assert n_unexplained == 0, f"{what}: {n_unexplained} rows with a different expert set and identical logits/no tie"
+    assert n_flip <= allow_flip_rows * T, f"{what}: {n_flip}/{T} rows differ through rounding flips/ties"
+    return logits, rlogits
+
+
+def test_router_golden(ops):
+    t, meta = load_golden("router")
+    for tag, m in meta.items():
+        x, gw, bias = t[f"{tag}.x"], t[f"{tag}.gate_w"], t[f"{tag}.bias"]
+        if tag == "ties":
+            # bf16-quantised scores with zero bias tie; torch.topk's choice among equals is
+            # unspecified, ours is the lowest id: the selected VALUES must agree exactly.
+            idx, w = ops.router_topk(dev(x), dev(gw), dev(bias), m["k"], m["rsf"])
+            _, rscores, rchoice = O.router_scores(x, gw, bias)
+            got = torch.sort(rchoice.gather(1, idx.cpu()), dim=1)[0]
+            exp = torch.sort(rchoice.gather(1, t[f"{tag}.idx"]), dim=1)[0]
+            assert torch.equal(got, exp), "tie case: selected score multiset differs"
+            assert torch.equal(torch.sort(w.cpu().float(), dim=1)[0], torch.sort(t[f"{tag}.w"].float(), dim=1)[0])
+        else:
+            # at most one row per case may differ, and only where the bf16 logit itself sits on a
+            # rounding boundary (fp32 summation order; _check_router proves that is the cause)
+            _check_router(ops, x, gw, bias, m["k"], m["rsf"], f"router golden {tag}",
+                          allow_flip_rows=1.0 / x.shape[0])
+
+
+def test_router_air_shape(ops):
+    """E=64, k=8, H=4096 (config 3 dims), 256 tokens: bit-exact expert sets except rows where the
+    bf16 logit itself rounded differently (fp32 summation order) — those must stay below 3 %."""
+    T, H, E, k = 256, 4096, 64, 8
+    x = rnd(T, H, seed=31)
+    gw = rnd(E, H, seed=32, scale=0.02)
+    bias = (torch.rand(E, generator=torch.Generator().manual_seed(33)) * 0.2 - 0.1).float()
+    logits, rlogits = _check_router(ops, x, gw, bias, k, 1.0, "router air", allow_flip_rows=0.03)
+    assert float((logits != rlogits).float().mean()) < 2e-3, "too many logit rounding flips"
+
+
+def test_moe_align(ops):
+    T, k, E = 37, 4, 16
+    g = torch.Generator().manual_seed(41)
+    idx = torch.stack([torch.randperm(E, generator=g)[:k].sort()[0] for _ in range(T)]).to(torch.int64)
+    w = rnd(T, k, seed=42).abs()
+    for shared in (True, False):
+        offs, tok, scale, pos = [a.cpu() for a in ops.moe_align(dev(idx), dev(w), E, shared)]
+        counts = torch.bincount(idx.flatten(), minlength=E)
+        exp_offs = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)])
+        assert torch.equal(offs[: E + 1].long(), exp_offs)
+        for e in range(E):
+            seg = range(int(offs[e]), int(offs[e + 1]))
+            toks = sorted(int(tok[r]) for r in seg)
+            assert toks == sorted(torch.where((idx == e).any(dim=1))[0].tolist())
+        flat_pos = pos.view(T, k)
+        for t in range(T):
+            for j in range(k):
+                r = int(flat_pos[t, j])
+                assert int(offs[int(idx[t, j])]) <= r < int(offs[int(idx[t, j]) + 1])
+                assert int(tok[r]) == t and scale[r] == w[t, j]
+        assert len(set(pos.tolist())) == T * k
+        if shared:
+            assert int(offs[E + 1]) == T * k + T
+            assert tok[T * k:].tolist() == list(range(T))
+            assert bool((scale[T * k:].float() == 1.0).all())
+
+
+def _moe_hip(ops, x, gate_w, bias, k, rsf, w13, w2, sw13, sw2, topk=None):
+    xd = dev(x)
+    if topk is None:
+        idx, w = ops.router_topk(xd, dev(gate_w), dev(bias), k, rsf)
+    else:
+        idx, w = dev(topk[0]), dev(topk[1])
+    E = w13.shape[0]
+    T = x.shape[0]
+    W13 = dev(torch.cat([w13, sw13.unsqueeze(0)]).contiguous())
+    W2 = dev(torch.cat([w2, sw2.unsqueeze(0)]).contiguous())
+    offs, tok, scale, pos = ops.moe_align(idx, w, E, True)
+    R = T * k + T
+    act = ops.grouped_gemm_gateup_silu(xd, W13, offs, tok, R)
+    y = ops.grouped_gemm_down(act, W2, offs, scale, E)
+    return ops.moe_combine(y, pos, T, k, T * k), (idx, w, offs, tok, scale, pos, act, y)
+
+
+def test_moe_golden(ops):
+    t, cfg = load_golden("moe")
+    E = cfg["n_routed_experts"]
+    w13 = torch.stack([t[f"experts.{e}.gate_up_proj.weight"] for e in range(E)])
+    w2 = torch.stack([t[f"experts.{e}.down_proj.weight"] for e in range(E)])
+    out, (idx, w, *_rest) = _moe_hip(ops, t["x"], t["gate.weight"], t["gate.e_score_correction_bias"],
+                                     cfg["num_experts_per_tok"], cfg["routed_scaling_factor"], w13, w2,
+                                     t["shared_experts.gate_up_proj.weight"], t["shared_experts.down_proj.weight"])
+    gi = torch.sort(t["idx"], dim=1)[0]
+    assert torch.equal(idx.cpu(), gi), "golden expert sets must match bit-exactly"
+    assert_mixed(out, t["y"], 2 ** -6, 2 ** -6 * float(t["y"].float().abs().max()), "moe golden")
+
+
+@pytest.mark.parametrize("T,E,k,H,I", [(32, 64, 8, 512, 128), (5, 8, 2, 256, 192), (130, 4, 2, 128, 64), (3, 16, 4, 1024, 352)])
+def test_moe_block_vs_oracle(ops, T, E, k, H, I):
+    """Expert arithmetic isolated from the router: same (idx, w) on both sides."""
+    x = rnd(T, H, seed=51)
+    w13, w2 = rnd(E, 2 * I, H, seed=52, scale=H ** -0.5), rnd(E, H, I, seed=53, scale=I ** -0.5)
+    sw13, sw2 = rnd(2 * I, H, seed=54, scale=H ** -0.5), rnd(H, I, seed=55, scale=I ** -0.5)
+    g = torch.Generator().manual_seed(56)
+    idx = torch.stack([torch.randperm(E, generator=g)[:k].sort()[0] for _ in range(T)]).to(torch.int64)
+    w = (torch.rand(T, k, generator=g) + 0.1).to(BF)
+    ref = O.moe(x, None, None, k, 1.0, w13, w2, sw13, sw2, topk=(idx, w))
+    out, (_, _, offs, tok, scale, pos, act, y) = _moe_hip(ops, x, None, None, k, 1.0, w13, w2, sw13, sw2, topk=(idx, w))
+    # per-row check of the two GEMMs against the per-expert oracle MLP
+    offs, tok = offs.cpu(), tok.cpu()
+    W13 = torch.cat([w13, sw13.unsqueeze(0)])
+    for e in range(E + 1):
+        rows = slice(int(offs[e]), int(offs[e + 1]))
+        if rows.start == rows.stop:
+            continue
+        xe = x[tok[rows].long()]
+        a_ref = O.silu_and_mul(O.linear(xe, W13[e]))
+        assert_close_bf16(act[rows], a_ref, 2, 0.06, atol=1e-3, what=f"act expert {e}")
+    assert_mixed(out, ref, 2 ** -6, 2 ** -6 * float(ref.float().abs().max()), "moe block")
+
+
+def test_moe_combine_order_is_reference_order(ops):
+    """bf16 accumulation in ascending expert id, then + shared: bit-exact given the same rows."""
+    T, k, H = 9, 4, 256
+    R = T * k + T
+    y = rnd(R, H, seed=61, scale=3.0)
+    g = torch.Generator().manual_seed(62)
+    pos = torch.stack([torch.randperm(T * k, generator=g)[:k] for _ in range(T)])
+    # make rows unique across tokens
+    pos = torch.randperm(T * k, generator=g).view(T, k).to(torch.int32)
+    out = ops.moe_combine(dev(y), dev(pos.flatten().contiguous()), T, k, T * k).cpu()
+    exp = torch.zeros(T, H, dtype=BF)
+    for t in range(T):
+        acc = torch.zeros(H, dtype=BF)
+        for p in sorted(pos[t].tolist()):
+            acc = acc + y[p]
+        exp[t] = acc + y[T * k + t]
+    assert torch.equal(out, exp)
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,bias", [
+    (1, 64, 128, False), (5, 72, 4096, True), (32, 4096, 1408, False), (33, 512, 176, True),
+    (32, 14336, 512, True), (32, 1024, 12288, False), (64, 256, 704, False), (7, 4096, 4096, True),
+    (16, 151552 // 8, 256, False)])
+def test_gemm_bf16_small_m(ops, M, N, K, bias):
+    x = rnd(M, K, seed=71)
+    w = rnd(N, K, seed=72, scale=K ** -0.5)
+    b = rnd(N, seed=73) if bias else None
+    ref = O.linear(x, w, b)
+    out = ops.gemm_bf16(dev(x), dev(w), dev(b))
+    # outputs are O(1); results that cancel to ~0 are compared absolutely (atol = 2^-9)
+    assert_close_bf16(out, ref, 1, 0.05, atol=2 ** -9, what=f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_bf16_strided_input(ops):
+    M, N, K = 12, 256, 384
+    big = rnd(M, K + 64, seed=74)
+    w = rnd(N, K, seed=75, scale=K ** -0.5)
+    out = ops.gemm_bf16(dev(big)[:, :K], dev(w), None)
+    assert_close_bf16(out, O.linear(big[:, :K], w), 1, 0.05, what="gemm strided")
+
+
+def test_error_reporting(ops):
+    x = rnd(4, 100).cuda()  # K % 8 != 0 is unsupported by the streaming kernel
+    w = rnd(8, 100).cuda()
+    with pytest.raises(RuntimeError, match="gemm"):
+        ops.gemm_bf16(x, w, None)
+    with pytest.raises(RuntimeError, match="GPU tensors"):
+        ops.rmsnorm(rnd(2, 8), rnd(8), 1e-5)
