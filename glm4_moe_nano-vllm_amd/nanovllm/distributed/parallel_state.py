@@ -1,0 +1,47 @@
+"""Tensor-parallel group.  The reference ships a stub that always answers world_size=1
+(distributed/parallel_state.py:1-9), so its Column/Row/QKV linears never shard.  Here the same
+accessor returns the REAL group: one process per GPU, torch.distributed ("nccl" = RCCL over
+xGMI on ROCm; "gloo" in CPU tests), TP group = the whole world (single node, ≤ 8 ranks,
+config.py:23)."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class TPGroup:
+    """Minimal coordinator: world_size / rank plus the one collective the layer needs
+    (all-reduce at RowParallel sites, layers/linear.py:153-154)."""
+
+    def __init__(self, group=None):
+        self._group = group
+
+    @property
+    def world_size(self) -> int:
+        return dist.get_world_size(self._group) if dist.is_available() and dist.is_initialized() else 1
+
+    @property
+    def rank(self) -> int:
+        return dist.get_rank(self._group) if dist.is_available() and dist.is_initialized() else 0
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world_size > 1:
+            dist.all_reduce(t, group=self._group)
+        return t
+
+
+_TP_GROUP = TPGroup()
+
+
+def get_tp_group() -> TPGroup:
+    return _TP_GROUP
+
+
+def set_tp_group(group) -> None:
+    """Bind the TP coordinator to a specific process group (default: the world)."""
+    global _TP_GROUP
+    _TP_GROUP = TPGroup(group)
+
+
+def tensor_model_parallel_all_reduce(t: torch.Tensor) -> torch.Tensor:
+    return get_tp_group().all_reduce(t)

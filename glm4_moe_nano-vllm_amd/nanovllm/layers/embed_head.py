@@ -1,0 +1,63 @@
+"""Vocabulary-parallel embedding and LM head — reference: layers/embed_head.py:9-68.
+The embedding lookup stays a torch op (plumbing); the LM head projection is the streaming HIP
+GEMM.  TP size/rank come from the TP group (the reference asks torch.distributed directly,
+embed_head.py:17-18, which requires an initialised process group even for tp=1)."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch import nn
+
+from nanovllm import hip_ops
+from nanovllm.distributed.parallel_state import get_tp_group
+from nanovllm.utils.context import get_context
+
+
+class VocabParallelEmbedding(nn.Module):
+
+    def __init__(self, num_embeddings: int, embedding_dim: int):
+        super().__init__()
+        self.tp_rank = get_tp_group().rank
+        self.tp_size = get_tp_group().world_size
+        assert num_embeddings % self.tp_size == 0
+        self.num_embeddings = num_embeddings
+        self.num_embeddings_per_partition = num_embeddings // self.tp_size
+        self.vocab_start_idx = self.num_embeddings_per_partition * self.tp_rank
+        self.vocab_end_idx = self.vocab_start_idx + self.num_embeddings_per_partition
+        self.weight = nn.Parameter(torch.empty(self.num_embeddings_per_partition, embedding_dim))
+        self.weight.weight_loader = self.weight_loader
+
+    def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor):
+        shard = param.data.size(0)
+        param.data.copy_(loaded_weight.narrow(0, self.tp_rank * shard, shard))
+
+    def forward(self, x: torch.Tensor):
+        if self.tp_size > 1:
+            mask = (x >= self.vocab_start_idx) & (x < self.vocab_end_idx)
+            x = mask * (x - self.vocab_start_idx)
+        y = F.embedding(x, self.weight)
+        if self.tp_size > 1:
+            y = mask.unsqueeze(1) * y
+            get_tp_group().all_reduce(y)
+        return y
+
+
+class ParallelLMHead(VocabParallelEmbedding):
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, bias: bool = False,
+                 quant_config: dict = None):
+        assert not bias
+        super().__init__(num_embeddings, embedding_dim)
+
+    def forward(self, x: torch.Tensor):
+        context = get_context()
+        if context.is_prefill:
+            last_indices = context.cu_seqlens_q[1:] - 1
+            x = x[last_indices.long()].contiguous()
+        logits = hip_ops.gemm_bf16(x, self.weight.data, None)
+        if self.tp_size > 1:
+            all_logits = [torch.empty_like(logits) for _ in range(self.tp_size)] if self.tp_rank == 0 else None
+            dist.gather(logits, all_logits, 0)
+            logits = torch.cat(all_logits, -1) if self.tp_rank == 0 else None
+        return logits

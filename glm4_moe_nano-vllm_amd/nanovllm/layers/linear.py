@@ -1,0 +1,117 @@
+"""Linear layers with the reference's sharding API — reference: layers/linear.py:14-155.
+Weights are [out, in] bf16; forward is glm_gemm_bf16 (weight-streaming MFMA kernel for decode
+batches, LDS-tiled MFMA kernel for prefill).  TP size/rank come from the real group
+(distributed/parallel_state.py); RowParallel all-reduces over RCCL when tp > 1."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from nanovllm import hip_ops
+from nanovllm.distributed.parallel_state import get_tp_group
+
+
+def divide(numerator, denominator):
+    assert numerator % denominator == 0
+    return numerator // denominator
+
+
+class LinearBase(nn.Module):
+
+    def __init__(self, input_size: int, output_size: int, bias: bool = False,
+                 tp_dim: int | None = None):
+        super().__init__()
+        self.tp_dim = tp_dim
+        self.tp_rank = get_tp_group().rank
+        self.tp_size = get_tp_group().world_size
+        self.weight = nn.Parameter(torch.empty(output_size, input_size))
+        self.weight.weight_loader = self.weight_loader
+        if bias:
+            self.bias = nn.Parameter(torch.empty(output_size))
+            self.bias.weight_loader = self.weight_loader
+        else:
+            self.register_parameter("bias", None)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def _gemm(self, x: torch.Tensor, with_bias: bool = True) -> torch.Tensor:
+        b = self.bias.data if (with_bias and self.bias is not None) else None
+        return hip_ops.gemm_bf16(x, self.weight.data, b)
+
+
+class ReplicatedLinear(LinearBase):
+
+    def __init__(self, input_size: int, output_size: int, bias: bool = False):
+        super().__init__(input_size, output_size, bias)
+
+    def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor):
+        param.data.copy_(loaded_weight)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._gemm(x)
+
+
+class ColumnParallelLinear(LinearBase):
+
+    def __init__(self, input_size: int, output_size: int, bias: bool = False):
+        tp_size = get_tp_group().world_size
+        super().__init__(input_size, divide(output_size, tp_size), bias, 0)
+
+    def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor):
+        shard = param.data.size(self.tp_dim)
+        param.data.copy_(loaded_weight.narrow(self.tp_dim, self.tp_rank * shard, shard))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._gemm(x)
+
+
+class MergedColumnParallelLinear(ColumnParallelLinear):
+
+    def __init__(self, input_size: int, output_sizes: list[int], bias: bool = False):
+        self.output_sizes = output_sizes
+        super().__init__(input_size, sum(output_sizes), bias)
+
+    def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor, loaded_shard_id: int):
+        offset = sum(self.output_sizes[:loaded_shard_id]) // self.tp_size
+        size = self.output_sizes[loaded_shard_id] // self.tp_size
+        dst = param.data.narrow(self.tp_dim, offset, size)
+        dst.copy_(loaded_weight.chunk(self.tp_size, self.tp_dim)[self.tp_rank])
+
+
+class QKVParallelLinear(ColumnParallelLinear):
+
+    def __init__(self, hidden_size: int, head_size: int, total_num_heads: int,
+                 total_num_kv_heads: int | None = None, bias: bool = False):
+        tp_size = get_tp_group().world_size
+        total_num_kv_heads = total_num_kv_heads or total_num_heads
+        self.head_size = head_size
+        self.num_heads = divide(total_num_heads, tp_size)
+        self.num_kv_heads = divide(total_num_kv_heads, tp_size)
+        output_size = (total_num_heads + 2 * total_num_kv_heads) * self.head_size
+        super().__init__(hidden_size, output_size, bias)
+
+    def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor, loaded_shard_id: str):
+        assert loaded_shard_id in ["q", "k", "v"]
+        q_rows = self.num_heads * self.head_size
+        kv_rows = self.num_kv_heads * self.head_size
+        offset, size = {"q": (0, q_rows), "k": (q_rows, kv_rows), "v": (q_rows + kv_rows, kv_rows)}[loaded_shard_id]
+        dst = param.data.narrow(self.tp_dim, offset, size)
+        dst.copy_(loaded_weight.chunk(self.tp_size, self.tp_dim)[self.tp_rank])
+
+
+class RowParallelLinear(LinearBase):
+
+    def __init__(self, input_size: int, output_size: int, bias: bool = False):
+        tp_size = get_tp_group().world_size
+        super().__init__(divide(input_size, tp_size), output_size, bias, 1)
+
+    def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor):
+        shard = param.data.size(self.tp_dim)
+        param.data.copy_(loaded_weight.narrow(self.tp_dim, self.tp_rank * shard, shard))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y = self._gemm(x, with_bias=self.tp_rank == 0)
+        if self.tp_size > 1:
+            get_tp_group().all_reduce(y)
+        return y

@@ -1,0 +1,53 @@
+"""One GLM-4-MoE decoder layer = THE hot path — reference: models/glm4_moe/decode_layer.py:10-100.
+MoE block iff layer_idx >= first_k_dense_replace, dense SiLU MLP otherwise; the MLP output is
+returned un-added (the next layer's fused add-RMSNorm consumes it)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from nanovllm.layers.layernorm import RMSNorm
+from nanovllm.utils.loader import load_one
+from .attention_new import Glm4MoeAttention
+from .mlp import Glm4MoeMLP
+from .moe import Glm4MoeMoE
+
+
+class Glm4MoeDecoderLayer(nn.Module):
+
+    def __init__(self, config, prefix: str = "") -> None:
+        super().__init__()
+        self.self_attn = Glm4MoeAttention(config, prefix=f"{prefix}.self_attn")
+        try:
+            layer_idx = int(prefix.split(sep=".")[-1])
+        except ValueError:
+            layer_idx = 0
+        self.layer_idx = layer_idx
+        if config.n_routed_experts is not None and layer_idx >= config.first_k_dense_replace:
+            self.mlp = Glm4MoeMoE(config)
+        else:
+            self.mlp = Glm4MoeMLP(hidden_size=config.hidden_size,
+                                  intermediate_size=config.intermediate_size,
+                                  hidden_act=config.hidden_act, prefix=f"{prefix}.mlp")
+        self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def load_weights(self, model_path: str, prefix: str):
+        for name, mod in (("input_layernorm", self.input_layernorm),
+                          ("post_attention_layernorm", self.post_attention_layernorm)):
+            w = load_one(model_path, f"{prefix}.{name}.weight")
+            if w is not None:
+                mod.weight.data.copy_(w)
+        self.self_attn.load_weights(model_path, f"{prefix}.self_attn")
+        self.mlp.load_weights(model_path, f"{prefix}.mlp")
+
+    def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor,
+                residual: torch.Tensor | None):
+        if residual is None:
+            hidden_states, residual = self.input_layernorm(hidden_states), hidden_states
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(hidden_states, positions)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        hidden_states = self.mlp(hidden_states)
+        return hidden_states, residual

@@ -1,0 +1,111 @@
+"""Sigmoid top-k router and the MoE block — reference: models/glm4_moe/moe.py:13-176.
+
+The reference loops over all experts in Python with three host syncs per expert
+(moe.py:135-151) and re-reads a debug file from disk on every call (:153-157).  Here one
+forward is five HIP launches with no host sync (graph-capturable):
+  glm_router_topk → glm_moe_align → glm_grouped_gemm_gateup_silu → glm_grouped_gemm_down →
+  glm_moe_combine,
+with the shared expert riding as group E of the grouped GEMMs.  Expert weights live in two
+stacked buffers ([E+1, 2I, H] and [E+1, H, I]); `experts[i].gate_up_proj.weight` etc. are views
+into them, so the reference's attribute/state-dict surface is unchanged."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from nanovllm import hip_ops
+from nanovllm.distributed.parallel_state import get_tp_group
+from nanovllm.utils.loader import load_prefixed
+from .mlp import Glm4MoeMLP
+
+
+class GlmMoeSelectTopk(nn.Module):
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.top_k = config.num_experts_per_tok
+        self.n_routed_experts = config.n_routed_experts
+        assert config.n_group == 1
+        assert config.topk_group == 1
+        self.routed_scaling_factor = config.routed_scaling_factor
+        self.weight = nn.Parameter(torch.empty((self.n_routed_experts, config.hidden_size)))
+        self.register_buffer("e_score_correction_bias",
+                             torch.zeros((self.n_routed_experts), dtype=torch.float32))
+
+    def forward(self, hidden_states: torch.Tensor):
+        h = hidden_states.view(-1, self.config.hidden_size)
+        # indices come back in ascending expert id per row (torch.topk(sorted=False) leaves
+        # the order unspecified; moe.py:39)
+        return hip_ops.router_topk(h, self.weight.data, self.e_score_correction_bias, self.top_k,
+                                   float(self.routed_scaling_factor))
+
+
+class Glm4MoeMoE(nn.Module):
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        mk = lambda: Glm4MoeMLP(hidden_size=config.hidden_size,
+                                intermediate_size=config.moe_intermediate_size,
+                                hidden_act=config.hidden_act, reduce_results=False)
+        self.experts = nn.ModuleList([mk() for _ in range(config.n_routed_experts)])
+        self.gate = GlmMoeSelectTopk(config)
+        self.shared_experts = mk()
+        self._w13 = None
+        self._w2 = None
+        self._stack(copy=False)
+
+    # ---- stacked expert storage ---------------------------------------------------------
+    def _mlps(self):
+        return list(self.experts) + [self.shared_experts]
+
+    def _stack(self, copy: bool) -> None:
+        mlps = self._mlps()
+        w13_0, w2_0 = mlps[0].gate_up_proj.weight, mlps[0].down_proj.weight
+        w13 = torch.empty((len(mlps), *w13_0.shape), dtype=w13_0.dtype, device=w13_0.device)
+        w2 = torch.empty((len(mlps), *w2_0.shape), dtype=w2_0.dtype, device=w2_0.device)
+        for i, m in enumerate(mlps):
+            if copy:
+                w13[i].copy_(m.gate_up_proj.weight.data)
+                w2[i].copy_(m.down_proj.weight.data)
+            m.gate_up_proj.weight.data = w13[i]
+            m.down_proj.weight.data = w2[i]
+        self._w13, self._w2 = w13, w2
+
+    def _stacked(self):
+        first = self.experts[0].gate_up_proj.weight
+        if self._w13 is None or first.data_ptr() != self._w13.data_ptr():
+            self._stack(copy=True)  # parameters were moved/replaced (e.g. .to(device)): re-tie
+        return self._w13, self._w2
+
+    # ---- weights ------------------------------------------------------------------------
+    def load_weights(self, path: str, prefix: str):
+        sd = load_prefixed(path, prefix)
+        if not sd:
+            raise ValueError(f"No tensors with prefix '{prefix}' found in '{path}'")
+        if f"{prefix}.gate.weight" in sd:
+            self.gate.weight.data.copy_(sd[f"{prefix}.gate.weight"])
+        if f"{prefix}.gate.e_score_correction_bias" in sd:
+            self.gate.e_score_correction_bias.copy_(sd[f"{prefix}.gate.e_score_correction_bias"])
+        self._stacked()
+        for i, expert in enumerate(self.experts):
+            expert.load_weights(path, f"{prefix}.experts.{i}")
+        self.shared_experts.load_weights(path, f"{prefix}.shared_experts")
+
+    # ---- forward ------------------------------------------------------------------------
+    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        shape = hidden_states.shape
+        h = hidden_states.view(-1, shape[-1])
+        T = h.shape[0]
+        E, k = self.config.n_routed_experts, self.config.num_experts_per_tok
+        w13, w2 = self._stacked()
+        topk_idx, topk_w = self.gate(h)
+        offs, tok, scale, pos = hip_ops.moe_align(topk_idx, topk_w, E, True)
+        R = T * k + T
+        act = hip_ops.grouped_gemm_gateup_silu(h, w13, offs, tok, R)
+        y = hip_ops.grouped_gemm_down(act, w2, offs, scale, E)
+        out = hip_ops.moe_combine(y, pos, T, k, T * k)
+        if get_tp_group().world_size > 1:
+            get_tp_group().all_reduce(out)
+        return out.view(shape)

@@ -60,3 +60,33 @@ def assert_close_bf16(actual, expected, max_ulp=1, frac_inexact=0.02, atol=0.0, 
         f"(max {int(d.max())} ulp, max abs {float((a.float() - e.float()).abs().max()):.4g})")
     frac = float((d > 0).float().mean())
     assert frac <= frac_inexact, f"{what}: {frac:.4%} of elements inexact (allowed {frac_inexact:.2%})"
+
+
+# ---------------------------------------------------------------------------------------------
+# product-side helpers (GPU): build the nanovllm modules from a golden fixture
+def build_product_layer(t: dict, cfg: dict, prefix: str, device="cuda"):
+    """Instantiate nanovllm.models.glm4_moe.decode_layer.Glm4MoeDecoderLayer the way the
+    reference's runner does (default dtype bf16, default device cuda; model_runner.py:30-31)
+    and load the fixture's weights through the ordinary state-dict surface."""
+    import types
+    from nanovllm.layers.rotary_embedding import get_rope
+    from nanovllm.models.glm4_moe.decode_layer import Glm4MoeDecoderLayer
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    get_rope.cache_clear()
+    try:
+        with torch.device(device):
+            layer = Glm4MoeDecoderLayer(types.SimpleNamespace(**cfg), prefix=prefix)
+    finally:
+        torch.set_default_dtype(old)
+    sd = {k[len("layer."):]: v for k, v in t.items() if k.startswith("layer.")}
+    missing, unexpected = layer.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("cos_sin" in m for m in missing), missing
+    return layer
+
+
+def router_margin(choice: torch.Tensor, k: int) -> torch.Tensor:
+    """Per row: k-th largest minus (k+1)-th largest routing score (fp32)."""
+    s = torch.sort(choice.float(), dim=-1, descending=True)[0]
+    return s[:, k - 1] - s[:, k]
