@@ -277,7 +277,49 @@ def measure_kernels(model, cfg, ops, B, ctx, world, iters, dev):
         ops.gemm_bf16(o_in, a.o_proj.weight.data, None)
     m, md = timeit(f_o, iters)
     rec("gemm_o", m, md, H * nh * hd * 2, "H*nh*hd*2 B of W_o")
+    # ---- prefill shape of the same config: T = 16384 tokens (max_num_batched_tokens,
+    # config.py:9) → 131072 routed pairs + 16384 shared rows; MFMA-bound ----
+    try:
+        res.update(measure_prefill_gemm(layers[0], cfg, ops, world, dev))
+    except torch.OutOfMemoryError:
+        pass
     return res
+
+
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense
+
+
+def measure_prefill_gemm(layer, cfg, ops, world, dev, T=16384, iters=3):
+    import torch
+    H, E, k, I = cfg.hidden_size, cfg.n_routed_experts, cfg.num_experts_per_tok, cfg.moe_intermediate_size // world
+    x = torch.randn(T, H, device=dev).to(torch.bfloat16)
+    idx, w = layer.mlp.gate(x)
+    offs, tok, scale, pos = ops.moe_align(idx, w, E, True)
+    w13, w2 = layer.mlp._stacked()
+    R = T * k + T
+    out = {}
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / iters * 1e3
+
+    act = ops.grouped_gemm_gateup_silu(x, w13, offs, tok, R)
+    for name, fn, flops in (
+            ("grouped_gemm_gateup_silu@prefill16k", lambda: ops.grouped_gemm_gateup_silu(x, w13, offs, tok, R), 2.0 * R * 2 * I * H),
+            ("grouped_gemm_down@prefill16k", lambda: ops.grouped_gemm_down(act, w2, offs, scale, E), 2.0 * R * H * I)):
+        us = timed(fn)
+        tf = flops / (us * 1e-6) / 1e12
+        out[name] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel_us_mean": round(us, 1),
+                     "algorithmic_flops": flops, "flops_model": f"2*R*N*K with R={R} rows (T={T}, k={k}, +shared)"}
+    return out
 
 
 def cpu_baseline(model, cfg, kv, block_tables, context_lens, positions, slot_mapping, B, L):

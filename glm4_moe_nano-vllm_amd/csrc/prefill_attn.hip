@@ -1,11 +1,270 @@
-// prefill_attn.hip — varlen causal prefill attention (a9).  Placeholder entry point until the
-// flash-style kernel lands; fails loudly instead of computing anything else.
+// prefill_attn.hip — varlen causal prefill attention (a9, reference:
+// nanovllm/layers/attention.py:85-100 → flash_attn_varlen_func(causal=True[, block_table])).
+// gfx950 only, head_dim 128.
+//
+// Flash-style: the score matrix is never materialised.  A workgroup owns 64 query rows of one
+// (sequence, query head); its 4 waves take 16 rows each and walk the key tiles (64 keys) that the
+// bottom-right-aligned causal mask leaves visible.  K/V tiles are staged once per workgroup by
+// LDS-DMA with the same source-side swizzles as the decode kernel (K: chunk ^ (key & 15) for
+// ds_read_b128 row reads, V: chunk ^ ((key & 7) << 1) for ds_read_b64_tr_b16 transposed reads),
+// double-buffered.  Math per wave is the decode kernel's: S^T = K·Q^T with keys on the MFMA row
+// axis and the wave's 16 query rows on the lane axis, fp32 online softmax per lane column, then
+// O^T += V^T·P^T straight from registers.
+//
+// K/V come either from contiguous [Tk, nkv, hd] tensors or from the paged cache through
+// block_tables (prefix-cache hit, attention.py:86-87).
 #include "common.h"
+
+namespace {
+
+constexpr int FA_HD = 128, FA_ROWB = 256;
+constexpr int FA_BQ = 64, FA_BK = 64;
+constexpr int FA_TILE = FA_BK * FA_ROWB;   // 16 KiB per K or V tile
+constexpr int FA_STAGE = 2 * FA_TILE;
+constexpr int FA_MAX_BT = 4096;
+constexpr int FA_LDS = 2 * FA_STAGE + FA_MAX_BT * 4;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_void_t*)gsrc, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(u32x4_t& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr16_b64(u32x2_t& dst, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(const lds_void_t*)p;
+}
+
+template <bool PAGED>
+__global__ __launch_bounds__(256) void prefill_attn_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
+    const int32_t* __restrict__ block_tables, int64_t bt_stride, bf16_t* __restrict__ out, int nh,
+    int nkv, int block_size, float scale_log2e) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* bt_lds = reinterpret_cast<int*>(smem + 2 * FA_STAGE);
+    const int qt = blockIdx.x, head = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int q0 = cu_q[b], lq = cu_q[b + 1] - q0;
+    const int k0 = cu_k[b], lk = cu_k[b + 1] - k0;
+    const int qbase = qt * FA_BQ;
+    if (qbase >= lq) return;  // uniform
+    const int kvh = head / (nh / nkv);
+    const int off = lk - lq;  // causal: query i sees keys j <= i + off
+    // keys visible to this workgroup's last row
+    const int kend = min(lk, min(lq, qbase + FA_BQ) + off);  // exclusive
+    const int ntiles = (kend + FA_BK - 1) / FA_BK;
+
+    if (PAGED) {
+        const int nblk = (kend + block_size - 1) / block_size;
+        for (int i = tid; i < nblk; i += 256) bt_lds[i] = block_tables[b * bt_stride + i];
+    }
+
+    // Q^T fragments: lane (c,g) = query row qbase + 16*wid + c, k-step ks → hd [32ks+8g, +8)
+    const int qi = qbase + 16 * wid + c;
+    bf16x8_t qf[4];
+    {
+        const bool ok = qi < lq;
+        const bf16_t* qrow = q + ((int64_t)(q0 + (ok ? qi : 0)) * nh + head) * FA_HD;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            u32x4_t t = {0, 0, 0, 0};
+            if (ok) t = *reinterpret_cast<const u32x4_t*>(qrow + 32 * ks + 8 * g);
+            qf[ks] = __builtin_bit_cast(bf16x8_t, t);
+        }
+    }
+    __syncthreads();
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
+
+    // staging: wave w issues instructions i=0..3 for K and V; instruction covers tile rows
+    // (4w+i)*4 .. +3 (4 keys x 256 B); lane → row +(lane>>4), position lane&15
+    auto stage = [&](int buf, int t) {
+        char* kd = smem + buf * FA_STAGE + wid * 4 * 1024;
+        char* vd = kd + FA_TILE;
+        const int r4 = lane >> 4, pch = lane & 15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wid * 4 + i) * 4 + r4;
+            int key = t * FA_BK + row;
+            key = key < lk ? key : lk - 1;  // masked keys re-read a valid row
+            int64_t tok;
+            if (PAGED) {
+                const int pb = bt_lds[key / block_size];
+                tok = (int64_t)pb * block_size + key % block_size;
+            } else {
+                tok = (int64_t)k0 + key;
+            }
+            const int64_t ro = (tok * nkv + kvh) * FA_HD;
+            glds16(k + ro + ((pch ^ (row & 15)) << 3), kd + i * 1024);
+            glds16(v + ro + ((pch ^ ((row & 7) << 1)) << 3), vd + i * 1024);
+        }
+    };
+
+    unsigned k_rel[4], v_rel[8];
+    {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) k_rel[ks] = c * FA_ROWB + (((4 * ks + g) ^ c) << 4);
+        const int qq = (lane >> 2) & 3, pp = lane & 3;
+        const int row = 4 * g + qq;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt)
+            v_rel[dt] = FA_TILE + row * FA_ROWB + (((2 * dt + (pp >> 1)) ^ ((row & 7) << 1)) << 4) + ((pp & 1) << 3);
+    }
+
+    f32x4_t acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const int jmax = qi + off;  // last visible key of this lane's query row
+
+    if (ntiles > 0) stage(0, 0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) {
+            stage(cur ^ 1, t + 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const unsigned sb = lds_addr(smem + cur * FA_STAGE);
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {  // 32 keys at a time
+            u32x4_t kf[2][4];
+            u32x2_t vf[8][2];
+            const unsigned hb = sb + hlf * 32 * FA_ROWB;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                lds_read_b128<0>(kf[0][ks], hb + k_rel[ks]);
+                lds_read_b128<4096>(kf[1][ks], hb + k_rel[ks]);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                lds_read_tr16_b64<0>(vf[dt][0], hb + v_rel[dt]);
+                lds_read_tr16_b64<4096>(vf[dt][1], hb + v_rel[dt]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]), "+v"(kf[1][0]),
+                           "+v"(kf[1][1]), "+v"(kf[1][2]), "+v"(kf[1][3]), "+v"(vf[0][0]), "+v"(vf[0][1]),
+                           "+v"(vf[1][0]), "+v"(vf[1][1]), "+v"(vf[2][0]), "+v"(vf[2][1]), "+v"(vf[3][0]),
+                           "+v"(vf[3][1]), "+v"(vf[4][0]), "+v"(vf[4][1]), "+v"(vf[5][0]), "+v"(vf[5][1]),
+                           "+v"(vf[6][0]), "+v"(vf[6][1]), "+v"(vf[7][0]), "+v"(vf[7][1])
+                         :
+                         : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4_t s[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                s[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[tt][ks]),
+                                                                   qf[ks], s[tt], 0, 0, 0);
+            }
+            const int kb = t * FA_BK + hlf * 32 + 4 * g;
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = kb + 16 * tt + r;
+                    float x = s[tt][r] * scale_log2e;
+                    if (j > jmax || j >= lk) x = -INFINITY;
+                    s[tt][r] = x;
+                    mloc = fmaxf(mloc, x);
+                }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run, mloc);
+            // a fully masked 32-key slab for this row keeps m_new = -inf: use 0 as the reference
+            // point so that exp2(-inf - 0) = 0 and no NaN appears
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+            float psum = 0.f;
+            bf16x8_t pf;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(s[tt][r] - m_use);
+                    psum += pv;
+                    pf[4 * tt + r] = (__bf16)pv;
+                }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                acc[dt] *= alpha;
+                const u32x4_t vv = {vf[dt][0][0], vf[dt][0][1], vf[dt][1][0], vf[dt][1][1]};
+                acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pf,
+                                                                 acc[dt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_barrier();  // everyone is done with buf[cur] before it is refilled
+    }
+
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (qi < lq) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        bf16_t* orow = out + ((int64_t)(q0 + qi) * nh + head) * FA_HD;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            u32x2_t o = {pack2bf(acc[dt][0] * inv, acc[dt][1] * inv), pack2bf(acc[dt][2] * inv, acc[dt][3] * inv)};
+            *reinterpret_cast<u32x2_t*>(orow + 16 * dt + 4 * g) = o;
+        }
+    }
+}
+
+}  // namespace
+
 extern "C" int glm_varlen_attn_prefill(const void* q, const void* k, const void* v,
                                        const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
                                        const int32_t* block_tables, int64_t bt_stride, void* out,
                                        int64_t B, int max_seqlen_q, int nh, int nkv, int hd,
                                        int block_size, float scale, glm_stream_t stream) {
-    glm_set_error("glm_varlen_attn_prefill: not implemented yet");
-    return GLM_ERR_UNSUPPORTED;
+    GLM_CHECK_ARG(q && k && v && cu_seqlens_q && cu_seqlens_k && out, GLM_ERR_INVALID,
+                  "glm_varlen_attn_prefill: null pointer");
+    GLM_CHECK_ARG(B >= 0 && nh > 0 && nkv > 0 && nh % nkv == 0 && max_seqlen_q >= 0, GLM_ERR_INVALID,
+                  "glm_varlen_attn_prefill: bad shape");
+    GLM_CHECK_ARG(hd == FA_HD && nh <= 65535 && B <= 65535 &&
+                      (block_tables == nullptr || (block_size > 0 && bt_stride > 0 && bt_stride <= FA_MAX_BT)),
+                  GLM_ERR_UNSUPPORTED,
+                  "glm_varlen_attn_prefill: needs head_dim=128 and <=%d blocks per sequence (hd=%d)", FA_MAX_BT, hd);
+    GLM_CHECK_ARG(glm_aligned16(q) && glm_aligned16(k) && glm_aligned16(v) && glm_aligned16(out),
+                  GLM_ERR_INVALID, "glm_varlen_attn_prefill: pointers must be 16-byte aligned");
+    if (B == 0 || max_seqlen_q == 0) return GLM_OK;
+    static bool attr_set[2] = {false, false};
+    const int paged = block_tables != nullptr;
+    if (!attr_set[paged]) {
+        const void* fn = paged ? (const void*)prefill_attn_kernel<true> : (const void*)prefill_attn_kernel<false>;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS);
+        if (e != hipSuccess) {
+            glm_set_error("glm_varlen_attn_prefill: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return GLM_ERR_LAUNCH;
+        }
+        attr_set[paged] = true;
+    }
+    const dim3 grid((unsigned)((max_seqlen_q + FA_BQ - 1) / FA_BQ), (unsigned)nh, (unsigned)B);
+    const float sl2 = scale * 1.4426950408889634f;
+    if (paged)
+        hipLaunchKernelGGL((prefill_attn_kernel<true>), grid, dim3(256), FA_LDS, glm_s(stream), (const bf16_t*)q,
+                           (const bf16_t*)k, (const bf16_t*)v, cu_seqlens_q, cu_seqlens_k, block_tables,
+                           bt_stride, (bf16_t*)out, nh, nkv, block_size, sl2);
+    else
+        hipLaunchKernelGGL((prefill_attn_kernel<false>), grid, dim3(256), FA_LDS, glm_s(stream), (const bf16_t*)q,
+                           (const bf16_t*)k, (const bf16_t*)v, cu_seqlens_q, cu_seqlens_k, block_tables,
+                           bt_stride, (bf16_t*)out, nh, nkv, block_size, sl2);
+    GLM_CHECK_LAUNCH("glm_varlen_attn_prefill");
+    return GLM_OK;
 }

@@ -374,3 +374,63 @@ def test_error_reporting(ops):
         ops.gemm_bf16(x, w, None)
     with pytest.raises(RuntimeError, match="GPU tensors"):
         ops.rmsnorm(rnd(2, 8), rnd(8), 1e-5)
+
+
+# ------------------------------------------------------------------------------------------
+# prefill regime: LDS-tiled MFMA GEMM (avg rows/group >= 96) and varlen causal attention
+@pytest.mark.parametrize("M,N,K,bias", [(96, 64, 64, False), (128, 200, 4096, True), (200, 4096, 1408, False),
+                                        (1000, 384, 352, True), (130, 14336 // 4, 512, True)])
+def test_gemm_bf16_large_m(ops, M, N, K, bias):
+    x = rnd(M, K, seed=81)
+    w = rnd(N, K, seed=82, scale=K ** -0.5)
+    b = rnd(N, seed=83) if bias else None
+    out = ops.gemm_bf16(dev(x), dev(w), dev(b))
+    assert_close_bf16(out, O.linear(x, w, b), 1, 0.05, atol=2 ** -9, what=f"gemm(large) {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("T,E,k,H,I", [(600, 4, 2, 256, 128), (1024, 8, 2, 128, 352), (300, 2, 1, 512, 64)])
+def test_moe_block_large_t(ops, T, E, k, H, I):
+    x = rnd(T, H, seed=91)
+    w13, w2 = rnd(E, 2 * I, H, seed=92, scale=H ** -0.5), rnd(E, H, I, seed=93, scale=I ** -0.5)
+    sw13, sw2 = rnd(2 * I, H, seed=94, scale=H ** -0.5), rnd(H, I, seed=95, scale=I ** -0.5)
+    g = torch.Generator().manual_seed(96)
+    idx = torch.stack([torch.randperm(E, generator=g)[:k].sort()[0] for _ in range(T)]).to(torch.int64)
+    w = (torch.rand(T, k, generator=g) + 0.1).to(BF)
+    ref = O.moe(x, None, None, k, 1.0, w13, w2, sw13, sw2, topk=(idx, w))
+    out, (_, _, offs, tok, scale, pos, act, y) = _moe_hip(ops, x, None, None, k, 1.0, w13, w2, sw13, sw2, topk=(idx, w))
+    offs, tok = offs.cpu(), tok.cpu()
+    W13 = torch.cat([w13, sw13.unsqueeze(0)])
+    for e in range(E + 1):
+        rows = slice(int(offs[e]), int(offs[e + 1]))
+        if rows.start == rows.stop:
+            continue
+        a_ref = O.silu_and_mul(O.linear(x[tok[rows].long()], W13[e]))
+        # gate, up and bf16(silu) can each flip one ulp (fp32 summation order): <= 3 ulp stacked
+        assert_close_bf16(act[rows], a_ref, 3, 0.06, atol=1e-3, what=f"act(large) expert {e}")
+    assert_mixed(out, ref, 2 ** -6, 2 ** -6 * float(ref.float().abs().max()), "moe block (large T)")
+
+
+@pytest.mark.parametrize("lens_q,lens_k,nh,nkv,paged", [
+    ([21, 16], [21, 16], 4, 2, False), ([64], [64], 2, 1, False), ([65, 1, 200], [65, 1, 200], 12, 2, False),
+    ([300], [300], 24, 2, False), ([5, 40], [300, 296], 4, 2, True), ([130], [513], 8, 8, True)])
+def test_varlen_attn_prefill(ops, lens_q, lens_k, nh, nkv, paged):
+    g = torch.Generator().manual_seed(sum(lens_k) + nh)
+    hd, bs = 128, 256
+    Tq = sum(lens_q)
+    q = torch.randn(Tq, nh, hd, generator=g).to(BF)
+    cu_q = torch.tensor([0] + list(torch.tensor(lens_q).cumsum(0)), dtype=torch.int32)
+    cu_k = torch.tensor([0] + list(torch.tensor(lens_k).cumsum(0)), dtype=torch.int32)
+    scale = hd ** -0.5
+    if paged:
+        _, kc, vc, _, bt = _paged_case(lens_k, nh, nkv, seed=5)
+        ref = O.attn_prefill_varlen(q, kc, vc, cu_q, cu_k, scale, bt)
+        out = ops.varlen_attn_prefill(dev(q), dev(kc), dev(vc), dev(cu_q), dev(cu_k), max(lens_q), scale,
+                                      dev(bt), bs)
+    else:
+        Tk = sum(lens_k)
+        k = torch.randn(Tk, nkv, hd, generator=g).to(BF)
+        v = torch.randn(Tk, nkv, hd, generator=g).to(BF)
+        ref = O.attn_prefill_varlen(q, k, v, cu_q, cu_k, scale)
+        out = ops.varlen_attn_prefill(dev(q), dev(k), dev(v), dev(cu_q), dev(cu_k), max(lens_q), scale)
+    assert torch.isfinite(out.float()).all()
+    assert_mixed(out, ref, 1.6e-2, 4e-3, f"prefill attn q={lens_q} k={lens_k}")
