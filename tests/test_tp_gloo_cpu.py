@@ -1,0 +1,123 @@
+"""Tensor-parallel sharding of the product's layers, world_size 2 over gloo on CPU.
+
+The HIP kernels cannot run here, so each rank evaluates its shard with the ORACLE's linear/MLP
+math on the weights the product's weight_loader selected, and reduces through the product's TP
+group (distributed/parallel_state.py).  What is verified is the part that has to be correct by
+construction for the multi-GPU bench: which rows/columns each rank owns, where the all-reduce
+sits (RowParallel sites only, reference layers/linear.py:153-154), vocab-parallel embedding, and
+that TP=2 reproduces the TP=1 oracle within bf16 summation tolerance."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        for p in (ROOT, os.path.join(ROOT, "glm4_moe_nano-vllm_amd"), os.path.join(ROOT, "tests")):
+            sys.path.insert(0, p)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.set_default_dtype(torch.bfloat16)
+        torch.set_num_threads(2)
+        from oracle import glm4_moe_oracle as O
+        from nanovllm.distributed.parallel_state import get_tp_group
+        from nanovllm.layers.linear import (MergedColumnParallelLinear, QKVParallelLinear,
+                                            RowParallelLinear)
+        from nanovllm.layers.embed_head import VocabParallelEmbedding
+        from nanovllm.models.glm4_moe.mlp import Glm4MoeMLP
+
+        tp = get_tp_group()
+        assert tp.world_size == world and tp.rank == rank
+        g = torch.Generator().manual_seed(0)  # identical "checkpoint" on every rank
+        H, nh, nkv, hd, I, T = 64, 4, 2, 16, 48, 9
+        x = torch.randn(T, H, generator=g).to(torch.bfloat16)
+        wq, wk, wv = (torch.randn(n * hd, H, generator=g).to(torch.bfloat16) * 0.2 for n in (nh, nkv, nkv))
+        wo = torch.randn(H, nh * hd, generator=g).to(torch.bfloat16) * 0.2
+        w_gate, w_up = (torch.randn(I, H, generator=g).to(torch.bfloat16) * 0.2 for _ in range(2))
+        w_down = torch.randn(H, I, generator=g).to(torch.bfloat16) * 0.2
+
+        # --- attention projections: column-parallel QKV by heads, row-parallel O + all-reduce ---
+        qkv = QKVParallelLinear(H, hd, nh, nkv, bias=False)
+        for w, sid in ((wq, "q"), (wk, "k"), (wv, "v")):
+            qkv.weight_loader(qkv.weight, w, sid)
+        assert qkv.weight.shape == ((nh + 2 * nkv) * hd // world, H)
+        nq, nk = nh // world, nkv // world
+        assert torch.equal(qkv.weight[: nq * hd], wq[rank * nq * hd:(rank + 1) * nq * hd])
+        assert torch.equal(qkv.weight[nq * hd:(nq + nk) * hd], wk[rank * nk * hd:(rank + 1) * nk * hd])
+        o = RowParallelLinear(nh * hd, H, bias=False)
+        o.weight_loader(o.weight, wo)
+        assert torch.equal(o.weight, wo[:, rank * nq * hd:(rank + 1) * nq * hd])
+        # per-head "attention" stand-in = identity on q: local heads only, as the KV cache is sharded
+        q_local = O.linear(x, qkv.weight.data)[:, : nq * hd]
+        y = tp.all_reduce(O.linear(q_local, o.weight.data))
+        y_ref = O.linear(O.linear(x, wq), wo)
+        assert torch.allclose(y.float(), y_ref.float(), rtol=3e-2, atol=3e-2 * float(y_ref.float().abs().max()))
+
+        # --- expert / dense MLP: gate|up column-parallel, down row-parallel ---
+        mlp = Glm4MoeMLP(H, I, "silu")
+        assert mlp.gate_up_proj.weight.shape == (2 * I // world, H) and mlp.down_proj.weight.shape == (H, I // world)
+        mlp.gate_up_proj.weight_loader(mlp.gate_up_proj.weight, w_gate, 0)
+        mlp.gate_up_proj.weight_loader(mlp.gate_up_proj.weight, w_up, 1)
+        mlp.down_proj.weight_loader(mlp.down_proj.weight, w_down)
+        Il = I // world
+        assert torch.equal(mlp.gate_up_proj.weight[:Il], w_gate[rank * Il:(rank + 1) * Il])
+        assert torch.equal(mlp.gate_up_proj.weight[Il:], w_up[rank * Il:(rank + 1) * Il])
+        part = O.mlp(x, mlp.gate_up_proj.weight.data, mlp.down_proj.weight.data)
+        full = tp.all_reduce(part.clone())
+        ref = O.mlp(x, torch.cat([w_gate, w_up]), w_down)
+        assert torch.allclose(full.float(), ref.float(), rtol=3e-2, atol=3e-2 * float(ref.float().abs().max()))
+
+        # --- vocab-parallel embedding (pure torch in the product: runs on CPU as is) ---
+        V = 50
+        emb_w = torch.randn(V, H, generator=g).to(torch.bfloat16)
+        emb = VocabParallelEmbedding(V, H)
+        emb.weight_loader(emb.weight, emb_w)
+        ids = torch.tensor([0, 24, 25, 49, 7])
+        assert torch.equal(emb(ids), emb_w[ids])
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
+@pytest.mark.timeout(180)
+def test_tp2_sharding_over_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(30)
+    for rank, msg in results:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_tp_group_defaults_to_single_rank():
+    sys.path.insert(0, os.path.join(ROOT, "glm4_moe_nano-vllm_amd"))
+    from nanovllm.distributed.parallel_state import get_tp_group
+    g = get_tp_group()
+    assert g.world_size == 1 and g.rank == 0
+    t = torch.ones(3)
+    assert g.all_reduce(t) is t
