@@ -37,17 +37,32 @@ def _newest_header() -> float:
     return max(os.path.getmtime(h) for h in hs)
 
 
-def _compile(name: str, force: bool) -> str:
+def _compile(name: str, force: bool, extra=(), tag: str = "") -> str:
     src = os.path.join(CSRC, name + ".hip")
-    obj = os.path.join(OBJ, name + ".o")
+    obj = os.path.join(OBJ, name + tag + ".o")
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
             and os.path.getmtime(obj) >= _newest_header()):
         return obj
-    cmd = [_hipcc(), *FLAGS, "-c", src, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *extra, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {name}.hip:\n{r.stdout}\n{r.stderr}")
     return obj
+
+
+def build_variant(tag: str, defines: list[str]) -> str:
+    """Timing-only variant library lib/libglm4moe_hip<tag>.so with extra -D flags (ablations)."""
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    extra = [f"-D{d}" for d in defines]
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(lambda n: _compile(n, True, extra, tag), SOURCES))
+    out = os.path.join(LIBDIR, f"libglm4moe_hip{tag}.so")
+    r = subprocess.run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out, *objs],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return out
 
 
 def build_lib(force: bool = False, verbose: bool = True) -> str:
@@ -69,4 +84,8 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build_lib(force="--force" in sys.argv)
+    if "--variant" in sys.argv:  # python build.py --variant _abl1 GLM_ABLATE=1
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    else:
+        build_lib(force="--force" in sys.argv)

@@ -12,7 +12,7 @@ void glm_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int glm_abi_version(void) { return 1; }
+extern "C" int glm_abi_version(void) { return 2; }
 extern "C" const char* glm_last_error(void) { return g_err; }
 
 namespace {
@@ -27,15 +27,15 @@ int dispatch(int mode, const GemmParams& p, hipStream_t st) {
 }
 }  // namespace
 
-extern "C" int glm_gemm_bf16(const void* x, int64_t ldx, const void* w, const void* bias, void* y,
-                             int64_t ldy, int64_t M, int N, int K, glm_stream_t stream) {
+extern "C" int glm_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
+                             void* y, int64_t ldy, int64_t M, int N, int K, glm_stream_t stream) {
     GLM_CHECK_ARG(x && w && y, GLM_ERR_INVALID, "glm_gemm_bf16: null pointer");
-    GLM_CHECK_ARG(M >= 0 && N > 0 && K > 0 && ldx >= K && ldy >= N, GLM_ERR_INVALID,
+    GLM_CHECK_ARG(M >= 0 && N > 0 && K > 0 && ldx >= K && ldy >= N && ldw >= K, GLM_ERR_INVALID,
                   "glm_gemm_bf16: bad shape M=%ld N=%d K=%d ldx=%ld ldy=%ld", (long)M, N, K, (long)ldx, (long)ldy);
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.x = (const bf16_t*)x; p.ldx = ldx;
-    p.w = (const bf16_t*)w; p.w_gstride = 0;
+    p.w = (const bf16_t*)w; p.w_gstride = 0; p.ldw = ldw;
     p.bias = (const bf16_t*)bias;
     p.y = (bf16_t*)y; p.ldy = ldy;
     p.R = M; p.N = N; p.K = K; p.G = 1;
@@ -43,30 +43,34 @@ extern "C" int glm_gemm_bf16(const void* x, int64_t ldx, const void* w, const vo
 }
 
 extern "C" int glm_grouped_gemm_gateup_silu(const void* x, int64_t ldx, const void* w13,
+                                            int64_t w13_group_stride, int64_t w13_row_stride,
                                             const int32_t* expert_offsets, const int32_t* sorted_token,
                                             void* act, int64_t R, int H, int I, int G,
                                             glm_stream_t stream) {
     GLM_CHECK_ARG(x && w13 && act, GLM_ERR_INVALID, "glm_grouped_gemm_gateup_silu: null pointer");
-    GLM_CHECK_ARG(R >= 0 && H > 0 && I > 0 && G >= 1 && ldx >= H, GLM_ERR_INVALID,
-                  "glm_grouped_gemm_gateup_silu: bad shape");
+    GLM_CHECK_ARG(R >= 0 && H > 0 && I > 0 && G >= 1 && ldx >= H && w13_row_stride >= H &&
+                      (G == 1 || w13_group_stride >= (int64_t)2 * I * w13_row_stride),
+                  GLM_ERR_INVALID, "glm_grouped_gemm_gateup_silu: bad shape");
     GLM_CHECK_ARG(expert_offsets != nullptr || G == 1, GLM_ERR_INVALID,
                   "glm_grouped_gemm_gateup_silu: expert_offsets required when G > 1");
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.x = (const bf16_t*)x; p.ldx = ldx;
-    p.w = (const bf16_t*)w13; p.w_gstride = (int64_t)2 * I * H;
+    p.w = (const bf16_t*)w13; p.w_gstride = w13_group_stride; p.ldw = w13_row_stride;
     p.offs = expert_offsets; p.src = sorted_token;
     p.y = (bf16_t*)act; p.ldy = I;
     p.R = R; p.N = I; p.K = H; p.G = G;
     return dispatch(GEMM_GATEUP, p, glm_s(stream));
 }
 
-extern "C" int glm_grouped_gemm_down(const void* act, const void* w2, const int32_t* expert_offsets,
+extern "C" int glm_grouped_gemm_down(const void* act, const void* w2, int64_t w2_group_stride,
+                                     int64_t w2_row_stride, const int32_t* expert_offsets,
                                      const void* sorted_scale, int n_scaled_groups, void* y,
                                      int64_t ldy, int64_t R, int H, int I, int G, glm_stream_t stream) {
     GLM_CHECK_ARG(act && w2 && y, GLM_ERR_INVALID, "glm_grouped_gemm_down: null pointer");
-    GLM_CHECK_ARG(R >= 0 && H > 0 && I > 0 && G >= 1 && ldy >= H, GLM_ERR_INVALID,
-                  "glm_grouped_gemm_down: bad shape");
+    GLM_CHECK_ARG(R >= 0 && H > 0 && I > 0 && G >= 1 && ldy >= H && w2_row_stride >= I &&
+                      (G == 1 || w2_group_stride >= (int64_t)H * w2_row_stride),
+                  GLM_ERR_INVALID, "glm_grouped_gemm_down: bad shape");
     GLM_CHECK_ARG(expert_offsets != nullptr || G == 1, GLM_ERR_INVALID,
                   "glm_grouped_gemm_down: expert_offsets required when G > 1");
     GLM_CHECK_ARG(n_scaled_groups == 0 || sorted_scale != nullptr, GLM_ERR_INVALID,
@@ -74,7 +78,7 @@ extern "C" int glm_grouped_gemm_down(const void* act, const void* w2, const int3
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.x = (const bf16_t*)act; p.ldx = I;
-    p.w = (const bf16_t*)w2; p.w_gstride = (int64_t)H * I;
+    p.w = (const bf16_t*)w2; p.w_gstride = w2_group_stride; p.ldw = w2_row_stride;
     p.offs = expert_offsets; p.src = nullptr;
     p.scale = (const bf16_t*)sorted_scale; p.n_scaled = n_scaled_groups;
     p.y = (bf16_t*)y; p.ldy = ldy;

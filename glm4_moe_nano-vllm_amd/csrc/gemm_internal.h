@@ -11,8 +11,9 @@ enum GemmMode : int {
 struct GemmParams {
     const bf16_t* x;      // activations, row r_src at x + r_src*ldx, K contiguous
     int64_t ldx;
-    const bf16_t* w;      // group g at w + g*w_gstride; [n_rows, K] row-major
+    const bf16_t* w;      // group g at w + g*w_gstride; row n at + n*ldw, K contiguous
     int64_t w_gstride;
+    int64_t ldw;
     const int32_t* offs;  // [G+1] row offsets per group, or nullptr (one group of R rows)
     const int32_t* src;   // source row of sorted row r, or nullptr (identity)
     const bf16_t* scale;  // [R] per-row scale (GEMM_DOWN) or nullptr

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void gemm_largem_kernel(const GemmParams p, in
         } else {
             wr = min(ntile * LM_BN + row, p.N - 1);
         }
-        wsrc[i] = wg + (int64_t)wr * K + ch * 8;
+        wsrc[i] = wg + (int64_t)wr * p.ldw + ch * 8;
         const int mr = row < mcnt ? row : 0;
         const int64_t srow = p.src ? (int64_t)p.src[m0 + mr] : (int64_t)(m0 + mr);
         xsrc[i] = p.x + srow * p.ldx + ch * 8;
@@ -238,7 +238,7 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
 }  // namespace
 
 int glm_launch_gemm_largem(int mode, const GemmParams& p, hipStream_t st) {
-    GLM_CHECK_ARG(p.K % 8 == 0 && p.N % 4 == 0 && p.ldx % 8 == 0 && p.ldy % 4 == 0 &&
+    GLM_CHECK_ARG(p.K % 8 == 0 && p.N % 4 == 0 && p.ldx % 8 == 0 && p.ldy % 4 == 0 && p.ldw % 8 == 0 &&
                       glm_aligned16(p.x) && glm_aligned16(p.w) && (((uintptr_t)p.y) & 7) == 0,
                   GLM_ERR_UNSUPPORTED,
                   "gemm_largem: needs K%%8==0, N%%4==0, ldx%%8==0, ldy%%4==0, 16B-aligned x/W (K=%d N=%d)",

@@ -13,6 +13,9 @@
 //   * each weight register is refilled for the NEXT chunk right after its last MFMA, so one
 //     full chunk (8 x 1 KiB per wave) stays in flight across the barrier; the activation loads
 //     are issued before it in program order, so waiting for them never drains the stream.
+//     (Measured alternatives that lost on the same box: B fragments straight from L2 without LDS
+//     and barriers, 298 vs 267 us for the grouped gate|up; two-chunk-deep weight registers at
+//     half the resident waves, 281 us.)
 //   * waves of a workgroup either own different weight rows (WS=1, grouped experts: 64/128
 //     rows per workgroup) or different K slices of the same rows (WS>1, dense projections with
 //     few rows: keeps >= 256 workgroups); K-slice partials are reduced through LDS.
@@ -20,6 +23,7 @@
 //     scan over expert_offsets — no host sync, graph-capturable (the reference's per-expert
 //     Python loop with .any()/where host syncs is moe.py:135-151).
 #include "gemm_internal.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -34,160 +38,25 @@ __device__ __forceinline__ u32x4_t gload16(const void* p) {
         (const __attribute__((address_space(1))) void*)p);
 }
 
-constexpr int SM_KS = 4;           // k-steps (of 32) per chunk
+// Timing-only ablation builds (tools/ablate_smallm.sh): bit 0 no MFMA, bit 1 no x staging,
+// bit 2 no B-fragment LDS reads, bit 3 no barrier.  Results are wrong in those builds.
+#ifndef GLM_ABLATE
+#define GLM_ABLATE 0
+#endif
+
+#ifndef GLM_SM_KS
+#define GLM_SM_KS 4
+#endif
+constexpr int SM_KS = GLM_SM_KS;   // k-steps (of 32) per chunk
 constexpr int SM_KC = 32 * SM_KS;  // 128 elements = 256 B per row per chunk
+constexpr int SM_XROWB = SM_KC * 2;  // bytes per activation row per chunk in LDS
+constexpr int SM_CPR = SM_KC / 8;    // 16-B chunks per row
 
-// One workgroup's work for a block of at most 16*MT rows of group `grp` (rows m0 .. m0+mcnt).
-// MT is a template parameter so that the chunk loop is straight-line code: every load is
-// unconditional (clamped address + select), the last chunk is peeled, and hipcc can place
-// counted vmcnt waits instead of draining at control-flow joins.
-template <int MODE, int NWAVES, int WS, int RT, int MT, int XSTRIDE>
-__device__ __forceinline__ void smallm_body(const GemmParams& p, char* smem, int grp, int m0, int mcnt) {
-    constexpr int NT = NWAVES * 64;
-    constexpr int WR = NWAVES / WS;
-    constexpr int MBT = 16 * MT;                          // rows staged by this instantiation
-    constexpr int XV = (WS * MBT * 16 + NT - 1) / NT;     // 16-B vectors staged per thread per chunk
-    constexpr bool XFULL = (WS * MBT * 16) % NT == 0;     // every (thread, i) maps to a vector
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ws = wid % WS, wr = wid / WS;
-    const int c = lane & 15, g4 = lane >> 4;
-    const int K = p.K;
-    const int nchunks = (K + SM_KC - 1) / SM_KC;
-    const int cps = (nchunks + WS - 1) / WS;  // chunks per K slice
-
-    // ---- weight row pointers of this wave (A operand: lane (c,g4) = row c, k-offset 8*g4) ----
-    const bf16_t* wg = p.w + (int64_t)grp * p.w_gstride;
-    const bf16_t* wrow[RT];
-    int ncol0;  // first output column of this wave
-    if (MODE == GEMM_GATEUP) {
-        ncol0 = (blockIdx.x * WR + wr) * 16;
-        const int r = min(ncol0 + c, p.N - 1);
-        wrow[0] = wg + (int64_t)r * K;
-        wrow[RT - 1] = wg + (int64_t)(p.N + r) * K;
-    } else {
-        ncol0 = (blockIdx.x * WR + wr) * (16 * RT);
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const int r = min(ncol0 + 16 * rt + c, p.N - 1);
-            wrow[rt] = wg + (int64_t)r * K;
-        }
-    }
-
-    // ---- activation staging: vector v = tid + i*NT ↔ (slice, row, 16-B chunk) ----
-    const bf16_t* xrow[XV];
-#pragma unroll
-    for (int i = 0; i < XV; ++i) {
-        const int v = tid + i * NT;
-        const int row = (v >> 4) % MBT;
-        const int rr = row < mcnt ? row : 0;  // padding rows re-read row 0 (their columns are never stored)
-        const int64_t srow = p.src ? (int64_t)p.src[m0 + rr] : (int64_t)(m0 + rr);
-        xrow[i] = p.x + srow * p.ldx;
-    }
-    u32x4_t xr[XV];
-    auto x_load = [&](int ci) {
-#pragma unroll
-        for (int i = 0; i < XV; ++i) {
-            const int v = tid + i * NT;
-            const int sl = (v / (MBT * 16)) % WS, ch = v & 15;
-            const int k = (sl * cps + ci) * SM_KC + ch * 8;
-            // out-of-range K reads a zero page: selecting the ADDRESS keeps the loaded data
-            // free of consumers until the LDS store (a data select would wait right here)
-            const bf16_t* src = k < K ? xrow[i] + k : reinterpret_cast<const bf16_t*>(g_zero_page);
-            xr[i] = gload16(src);
-        }
-    };
-    auto x_store = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < XV; ++i) {
-            const int v = tid + i * NT;
-            const int sl = v / (MBT * 16), row = (v >> 4) % MBT, ch = v & 15;
-            if (XFULL || v < WS * MBT * 16)
-                *reinterpret_cast<u32x4_t*>(smem + buf * XSTRIDE + (sl * MBT + row) * 256 +
-                                            ((ch ^ (row & 15)) << 4)) = xr[i];
-        }
-    };
-
-    const int cbeg = ws * cps;
-    u32x4_t wreg[RT][SM_KS];
-    auto w_load = [&](int ci, int rt, int ks) {
-        const int k = (cbeg + ci) * SM_KC + 32 * ks + 8 * g4;
-        const bf16_t* src = k < K ? wrow[rt] + k : reinterpret_cast<const bf16_t*>(g_zero_page);
-        wreg[rt][ks] = gload16(src);
-    };
-
-    f32x4_t acc[RT][MT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[rt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    // ---- prologue ----
-    x_load(0);
-#pragma unroll
-    for (int ks = 0; ks < SM_KS; ++ks)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) w_load(0, rt, ks);
-    x_store(0);
-    __syncthreads();
-
-    auto step = [&](int ci, auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value;
-        const int cur = ci & 1;
-        if (MORE) {
-            x_load(ci + 1);  // oldest VMEM op of the iteration: its wait never drains the W stream
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const char* xb = smem + cur * XSTRIDE + ws * MBT * 256;
-#pragma unroll
-        for (int ks = 0; ks < SM_KS; ++ks) {
-            bf16x8_t bfr[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                bfr[mt] = *reinterpret_cast<const bf16x8_t*>(xb + (16 * mt + c) * 256 +
-                                                              (((4 * ks + g4) ^ c) << 4));
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[rt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8_t, wreg[rt][ks]), bfr[mt], acc[rt][mt], 0, 0, 0);
-            if (MORE) {
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) w_load(ci + 1, rt, ks);
-            }
-        }
-        if (MORE) x_store(cur ^ 1);
-        __syncthreads();
-    };
-    for (int ci = 0; ci + 1 < cps; ++ci) step(ci, std::true_type{});
-    step(cps - 1, std::false_type{});
-
-    // ---- K-slice reduction through LDS (WS > 1): slice 0 accumulates the others ----
-    if (WS > 1) {
-        float* red = reinterpret_cast<float*>(smem);  // x buffers are dead after the last barrier
-        if (ws != 0) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    *reinterpret_cast<f32x4_t*>(red + ((((wr * (WS - 1) + (ws - 1)) * RT + rt) * MT + mt) * 64 + lane) * 4) =
-                        acc[rt][mt];
-        }
-        __syncthreads();
-        if (ws != 0) return;
-#pragma unroll
-        for (int s = 1; s < WS; ++s)
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[rt][mt] += *reinterpret_cast<const f32x4_t*>(
-                        red + ((((wr * (WS - 1) + (s - 1)) * RT + rt) * MT + mt) * 64 + lane) * 4);
-    }
-
-    // ---- epilogue: lane (c,g4) holds, per (rt, mt), columns n..n+3 of token row 16*mt + c ----
+// epilogue shared by both variants: lane (c,g4) holds, per (rt, mt), columns n..n+3 of token
+// row 16*mt + c
+template <int MODE, int RT, int MT>
+__device__ __forceinline__ void smallm_epilogue(const GemmParams& p, f32x4_t (&acc)[RT][MT], int grp, int m0,
+                                                int mcnt, int ncol0, int c, int g4) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int row = 16 * mt + c;
@@ -229,10 +98,183 @@ __device__ __forceinline__ void smallm_body(const GemmParams& p, char* smem, int
     }
 }
 
+// One workgroup's work for a block of at most 16*MT rows of group `grp` (rows m0 .. m0+mcnt).
+// MT is a template parameter so that the chunk loop is straight-line code: every load is
+// unconditional (clamped address + select), the last chunk is peeled, and hipcc can place
+// counted vmcnt waits instead of draining at control-flow joins.
+template <int MODE, int NWAVES, int WS, int RT, int MT, int XSTRIDE>
+__device__ __forceinline__ void smallm_body(const GemmParams& p, char* smem, int grp, int m0, int mcnt) {
+    constexpr int NT = NWAVES * 64;
+    constexpr int WR = NWAVES / WS;
+    constexpr int MBT = 16 * MT;                          // rows staged by this instantiation
+    constexpr int XV = (WS * MBT * SM_CPR + NT - 1) / NT;  // 16-B vectors staged per thread per chunk
+    constexpr bool XFULL = (WS * MBT * SM_CPR) % NT == 0;  // every (thread, i) maps to a vector
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ws = wid % WS, wr = wid / WS;
+    const int c = lane & 15, g4 = lane >> 4;
+    const int K = p.K;
+    const int nchunks = (K + SM_KC - 1) / SM_KC;
+    const int cps = (nchunks + WS - 1) / WS;  // chunks per K slice
+
+    // ---- weight row pointers of this wave (A operand: lane (c,g4) = row c, k-offset 8*g4) ----
+    const bf16_t* wg = p.w + (int64_t)grp * p.w_gstride;
+    const bf16_t* wrow[RT];
+    int ncol0;  // first output column of this wave
+    if (MODE == GEMM_GATEUP) {
+        ncol0 = (blockIdx.x * WR + wr) * 16;
+        const int r = min(ncol0 + c, p.N - 1);
+        wrow[0] = wg + (int64_t)r * p.ldw;
+        wrow[RT - 1] = wg + (int64_t)(p.N + r) * p.ldw;
+    } else {
+        ncol0 = (blockIdx.x * WR + wr) * (16 * RT);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int r = min(ncol0 + 16 * rt + c, p.N - 1);
+            wrow[rt] = wg + (int64_t)r * p.ldw;
+        }
+    }
+
+    // ---- activation staging: vector v = tid + i*NT ↔ (slice, row, 16-B chunk) ----
+    const bf16_t* xrow[XV];
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        const int v = tid + i * NT;
+        const int row = (v / SM_CPR) % MBT;
+        const int rr = row < mcnt ? row : 0;  // padding rows re-read row 0 (their columns are never stored)
+        const int64_t srow = p.src ? (int64_t)p.src[m0 + rr] : (int64_t)(m0 + rr);
+        xrow[i] = p.x + srow * p.ldx;
+    }
+    u32x4_t xr[XV];
+    auto x_load = [&](int ci) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int v = tid + i * NT;
+            const int sl = (v / (MBT * SM_CPR)) % WS, ch = v % SM_CPR;
+            const int k = (sl * cps + ci) * SM_KC + ch * 8;
+            // out-of-range K reads a zero page: selecting the ADDRESS keeps the loaded data
+            // free of consumers until the LDS store (a data select would wait right here)
+            const bf16_t* src = k < K ? xrow[i] + k : reinterpret_cast<const bf16_t*>(g_zero_page);
+            xr[i] = gload16(src);
+        }
+    };
+    auto x_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int v = tid + i * NT;
+            const int sl = v / (MBT * SM_CPR), row = (v / SM_CPR) % MBT, ch = v % SM_CPR;
+            if (XFULL || v < WS * MBT * SM_CPR)
+                *reinterpret_cast<u32x4_t*>(smem + buf * XSTRIDE + (sl * MBT + row) * SM_XROWB +
+                                            ((ch ^ (row & 15)) << 4)) = xr[i];
+        }
+    };
+
+    const int cbeg = ws * cps;
+    // weight registers: each one is refilled for the NEXT chunk right after its last MFMA, so a
+    // full chunk (8 x 1 KiB per wave) stays in flight across the barrier.  (A 2-chunk-deep
+    // variant was measured slower: it costs ~45 VGPRs, i.e. half the resident waves.)
+    u32x4_t wreg[RT][SM_KS];
+    auto w_load = [&](int ci, int rt, int ks) {
+        const int k = (cbeg + ci) * SM_KC + 32 * ks + 8 * g4;
+        const bf16_t* src = k < K ? wrow[rt] + k : reinterpret_cast<const bf16_t*>(g_zero_page);
+        wreg[rt][ks] = gload16(src);
+    };
+
+    f32x4_t acc[RT][MT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[rt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue ----
+    x_load(0);
+#pragma unroll
+    for (int ks = 0; ks < SM_KS; ++ks)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) w_load(0, rt, ks);
+    x_store(0);
+    __syncthreads();
+
+    auto step = [&](int ci, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        const int cur = ci & 1;
+        if (MORE && !(GLM_ABLATE & 2)) {
+            x_load(ci + 1);  // oldest VMEM op of the iteration: its wait never drains the W stream
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const char* xb = smem + cur * XSTRIDE + ws * MBT * SM_XROWB;
+        // all B fragments of the chunk first: the MFMA → refill sequence below then runs without
+        // LDS round trips in between, so the next chunk's weight loads are issued as early as possible
+        bf16x8_t bfr[SM_KS][MT];
+#pragma unroll
+        for (int ks = 0; ks < SM_KS; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (GLM_ABLATE & 4) {
+                    const u32x4_t z = {(unsigned)ci, 0, 0, 0};
+                    bfr[ks][mt] = __builtin_bit_cast(bf16x8_t, z);
+                } else {
+                    bfr[ks][mt] = *reinterpret_cast<const bf16x8_t*>(xb + (16 * mt + c) * SM_XROWB +
+                                                                      (((4 * ks + g4) ^ c) << 4));
+                }
+            }
+#pragma unroll
+        for (int ks = 0; ks < SM_KS; ++ks) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (GLM_ABLATE & 1) {
+                        const u32x4_t bb = __builtin_bit_cast(u32x4_t, bfr[ks][mt]);
+                        acc[rt][mt][0] += __uint_as_float((wreg[rt][ks][0] ^ wreg[rt][ks][1] ^ wreg[rt][ks][2] ^
+                                                           wreg[rt][ks][3] ^ bb[0]) & 0x3fffffffu);
+                    } else {
+                        acc[rt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_t, wreg[rt][ks]), bfr[ks][mt], acc[rt][mt], 0, 0, 0);
+                    }
+                }
+            if (MORE) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) w_load(ci + 1, rt, ks);
+            }
+        }
+        if (MORE && !(GLM_ABLATE & 2)) x_store(cur ^ 1);
+        if (!(GLM_ABLATE & 8)) __syncthreads();
+    };
+    for (int ci = 0; ci + 1 < cps; ++ci) step(ci, std::true_type{});
+    step(cps - 1, std::false_type{});
+
+    // ---- K-slice reduction through LDS (WS > 1): slice 0 accumulates the others ----
+    if (WS > 1) {
+        float* red = reinterpret_cast<float*>(smem);  // x buffers are dead after the last barrier
+        if (ws != 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    *reinterpret_cast<f32x4_t*>(red + ((((wr * (WS - 1) + (ws - 1)) * RT + rt) * MT + mt) * 64 + lane) * 4) =
+                        acc[rt][mt];
+        }
+        __syncthreads();
+        if (ws != 0) return;
+#pragma unroll
+        for (int s = 1; s < WS; ++s)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[rt][mt] += *reinterpret_cast<const f32x4_t*>(
+                        red + ((((wr * (WS - 1) + (s - 1)) * RT + rt) * MT + mt) * 64 + lane) * 4);
+    }
+
+    smallm_epilogue<MODE, RT, MT>(p, acc, grp, m0, mcnt, ncol0, c, g4);
+}
+
 template <int MODE, int NWAVES, int WS, int RT, int MTMAX>
 __global__ __launch_bounds__(NWAVES * 64) void gemm_smallm_kernel(const GemmParams p) {
     constexpr int MB = 16 * MTMAX;
-    constexpr int XBUF = WS * MB * 256;  // bytes per x buffer (sized for MTMAX)
+    constexpr int XBUF = WS * MB * SM_XROWB;  // bytes per x buffer (sized for MTMAX)
     static_assert(MODE != GEMM_GATEUP || RT == 2, "gate|up needs two row tiles");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sh = reinterpret_cast<int*>(smem + 2 * XBUF);
@@ -251,7 +293,7 @@ template <int MODE, int NWAVES, int WS, int RT, int MTMAX>
 int launch_cfg(const GemmParams& p, hipStream_t st) {
     constexpr int WR = NWAVES / WS;
     constexpr int MB = 16 * MTMAX;
-    constexpr int XBUF = WS * MB * 256;
+    constexpr int XBUF = WS * MB * SM_XROWB;
     constexpr int REDB = WS > 1 ? WR * (WS - 1) * RT * MTMAX * 64 * 16 : 0;
     constexpr int LDS = (2 * XBUF > REDB ? 2 * XBUF : REDB) + 16;
     static_assert(REDB <= 2 * XBUF, "reduction scratch must fit in the x buffers");
@@ -280,22 +322,22 @@ int launch_cfg(const GemmParams& p, hipStream_t st) {
 }  // namespace
 
 int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
-    GLM_CHECK_ARG(p.K % 8 == 0 && p.N % 4 == 0 && p.ldx % 8 == 0 && p.ldy % 4 == 0 &&
+    GLM_CHECK_ARG(p.K % 8 == 0 && p.N % 4 == 0 && p.ldx % 8 == 0 && p.ldy % 4 == 0 && p.ldw % 8 == 0 &&
                       glm_aligned16(p.x) && glm_aligned16(p.w) && (((uintptr_t)p.y) & 7) == 0,
                   GLM_ERR_UNSUPPORTED,
-                  "gemm_smallm: needs K%%8==0, N%%4==0, ldx%%8==0, ldy%%4==0, 16B-aligned x/W (K=%d N=%d)",
+                  "gemm_smallm: needs K%%8==0, N%%4==0, ldx/ldw%%8==0, ldy%%4==0, 16B-aligned x/W (K=%d N=%d)",
                   p.K, p.N);
-    if (mode == GEMM_GATEUP) return launch_cfg<GEMM_GATEUP, 4, 1, 2, 4>(p, st);
-    if (mode == GEMM_DOWN) return launch_cfg<GEMM_DOWN, 4, 1, 2, 4>(p, st);
+    // grouped experts: 32-row blocks (at decode batch sizes only the shared expert ever fills one;
+    // a group with more rows re-reads its weights once per extra block)
+    if (mode == GEMM_GATEUP) return launch_cfg<GEMM_GATEUP, 4, 1, 2, 2>(p, st);
+    if (mode == GEMM_DOWN) return launch_cfg<GEMM_DOWN, 4, 1, 2, 2>(p, st);
     // dense projection: choose the K-split so that the grid covers the chip
-    const int64_t rows_max = p.offs ? 64 : p.R;
+    const int64_t rows = p.offs ? 64 : p.R;
     const int tiles32 = (p.N + 31) / 32;
-    if (p.G > 1 || tiles32 * ((rows_max + 63) / 64) >= 1024) {
-        return launch_cfg<GEMM_PLAIN, 4, 1, 2, 4>(p, st);
-    }
-    if (rows_max <= 32) {
-        if (tiles32 >= 384) return launch_cfg<GEMM_PLAIN, 4, 4, 2, 2>(p, st);
-        return launch_cfg<GEMM_PLAIN, 8, 8, 1, 2>(p, st);
-    }
-    return launch_cfg<GEMM_PLAIN, 4, 4, 2, 4>(p, st);
+#if GLM_SM_KS != 4  // experimental chunk widths: the K-split configs would exceed the LDS
+    return launch_cfg<GEMM_PLAIN, 4, 1, 2, 4>(p, st);
+#endif
+    if (p.G > 1 || rows > 32 || tiles32 >= 1024) return launch_cfg<GEMM_PLAIN, 4, 1, 2, 4>(p, st);
+    if (tiles32 >= 384) return launch_cfg<GEMM_PLAIN, 4, 4, 2, 2>(p, st);
+    return launch_cfg<GEMM_PLAIN, 8, 8, 1, 2>(p, st);
 }

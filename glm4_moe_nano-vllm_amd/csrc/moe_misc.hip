@@ -13,9 +13,12 @@ constexpr int ROUTER_EB = 4;  // experts per dot-product pass (x chunk reused 4x
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// One 256-thread workgroup per token.  x row is staged in LDS (bf16), each wave owns experts
-// w, w+4, ... in blocks of ROUTER_EB; a lane covers 16-byte chunks lane, lane+64, ... of K.
-__global__ __launch_bounds__(256) void router_topk_kernel(
+// One 1024-thread workgroup (16 waves) per token: the op is latency-bound (0.5 MB of gate weights
+// from L2), so the 64 expert dot products are spread over as many waves as a workgroup can hold.
+// x row is staged in LDS (bf16); wave w owns expert blocks w, w+16, ... of ROUTER_EB experts; a
+// lane covers 16-byte chunks lane, lane+64, ... of K.
+constexpr int ROUTER_NT = 1024;
+__global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ gw, const float* __restrict__ bias,
     int64_t* __restrict__ topk_idx, bf16_t* __restrict__ topk_w, bf16_t* __restrict__ logits_out,
     int H, int E, int k, float rsf) {
@@ -28,13 +31,13 @@ __global__ __launch_bounds__(256) void router_topk_kernel(
     {
         const u32x4_t* src = reinterpret_cast<const u32x4_t*>(x + t * H);
         u32x4_t* dst = reinterpret_cast<u32x4_t*>(xs);
-        for (int i = tid; i < nvec; i += 256) dst[i] = src[i];
+        for (int i = tid; i < nvec; i += ROUTER_NT) dst[i] = src[i];
     }
     __syncthreads();
 
     // R1: logits = bf16( fp32 dot )
     const int nblk = (E + ROUTER_EB - 1) / ROUTER_EB;
-    for (int b = wid; b < nblk; b += 4) {
+    for (int b = wid; b < nblk; b += ROUTER_NT / 64) {
         const int e0 = b * ROUTER_EB;
         float acc[ROUTER_EB];
 #pragma unroll
@@ -79,19 +82,20 @@ __global__ __launch_bounds__(256) void router_topk_kernel(
             ch[i] = -INFINITY;
         }
     }
-    // R4: k rounds of wave arg-max (ties → lowest expert id; NaN never wins)
+    // R4: k rounds of wave arg-max (ties → lowest expert id).  NaN scores are demoted to -inf so the
+    // comparisons stay a total order and every lane agrees on the winner.
+#pragma unroll
+    for (int i = 0; i < EPL; ++i)
+        if (!(ch[i] == ch[i])) ch[i] = -INFINITY;
     for (int r = 0; r < k; ++r) {
         float bv = -INFINITY;
-        int bi = 0x7fffffff;
+        int bi = 0x7fffffff;  // "no candidate"
 #pragma unroll
         for (int i = 0; i < EPL; ++i) {
-            const int e = lane + 64 * i;
-            if (e < E && !sel[i] && (ch[i] > bv || bi == 0x7fffffff)) {
-                // first unselected candidate, or strictly better (lower ids are visited first)
-                if (bi == 0x7fffffff || ch[i] > bv) {
-                    bv = ch[i];
-                    bi = e;
-                }
+            const int e = lane + 64 * i;  // ascending ids: strict > keeps the lowest id on ties
+            if (e < E && !sel[i] && (bi == 0x7fffffff || ch[i] > bv)) {
+                bv = ch[i];
+                bi = e;
             }
         }
 #pragma unroll
@@ -122,8 +126,10 @@ __global__ __launch_bounds__(256) void router_topk_kernel(
         const unsigned long long m = __ballot(sel[i]);
         if (sel[i]) {
             const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-            topk_idx[t * k + pos] = lane + 64 * i;
-            topk_w[t * k + pos] = f2bf(rbf(sc[i] / den) * rsf);  // R6 then R7
+            if (pos < k) {
+                topk_idx[t * k + pos] = lane + 64 * i;
+                topk_w[t * k + pos] = f2bf(rbf(sc[i] / den) * rsf);  // R6 then R7
+            }
         }
         base += __popcll(m);
     }
@@ -264,7 +270,7 @@ extern "C" int glm_router_topk(const void* x, const void* gate_w,
                   E, k, H);
     if (T == 0) return GLM_OK;
     const size_t shm = (((size_t)H * 2 + 15) & ~(size_t)15) + (size_t)E * 4;
-    hipLaunchKernelGGL(router_topk_kernel, dim3((unsigned)T), dim3(256), shm, glm_s(stream),
+    hipLaunchKernelGGL(router_topk_kernel, dim3((unsigned)T), dim3(ROUTER_NT), shm, glm_s(stream),
                        (const bf16_t*)x, (const bf16_t*)gate_w, e_score_correction_bias, topk_idx,
                        (bf16_t*)topk_w, (bf16_t*)logits_out, H, E, k, routed_scaling_factor);
     GLM_CHECK_LAUNCH("glm_router_topk");

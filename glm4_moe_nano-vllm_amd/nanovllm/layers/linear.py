@@ -24,7 +24,8 @@ class LinearBase(nn.Module):
         self.tp_dim = tp_dim
         self.tp_rank = get_tp_group().rank
         self.tp_size = get_tp_group().world_size
-        self.weight = nn.Parameter(torch.empty(output_size, input_size))
+        # [out, in] view of row-padded storage (hip_ops.padded_weight): same API, better HBM spread
+        self.weight = nn.Parameter(hip_ops.padded_weight(output_size, input_size))
         self.weight.weight_loader = self.weight_loader
         if bias:
             self.bias = nn.Parameter(torch.empty(output_size))

@@ -63,8 +63,8 @@ class Glm4MoeMoE(nn.Module):
     def _stack(self, copy: bool) -> None:
         mlps = self._mlps()
         w13_0, w2_0 = mlps[0].gate_up_proj.weight, mlps[0].down_proj.weight
-        w13 = torch.empty((len(mlps), *w13_0.shape), dtype=w13_0.dtype, device=w13_0.device)
-        w2 = torch.empty((len(mlps), *w2_0.shape), dtype=w2_0.dtype, device=w2_0.device)
+        w13 = hip_ops.padded_weight(*w13_0.shape, len(mlps), dtype=w13_0.dtype, device=w13_0.device)
+        w2 = hip_ops.padded_weight(*w2_0.shape, len(mlps), dtype=w2_0.dtype, device=w2_0.device)
         for i, m in enumerate(mlps):
             if copy:
                 w13[i].copy_(m.gate_up_proj.weight.data)

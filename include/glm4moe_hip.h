@@ -142,9 +142,12 @@ int glm_moe_align(const int64_t* topk_idx, const void* topk_w,
 
 /* a13 (first half) models/glm4_moe/mlp.py:49-53 for every group at once:
  *     act[r, i] = bf16( bf16(silu(bf16(x[tok(r)]·Wg_gᵀ))) * bf16(x[tok(r)]·Wu_gᵀ) )
- *     w13: [G, 2I, H] (rows gate|up, mlp.py:118).  expert_offsets NULL ⇒ one group of R rows;
+ *     w13: [G, 2I, H] (rows gate|up, mlp.py:118) with element strides (w13_group_stride,
+ *     w13_row_stride, 1): a padded row pitch (e.g. H+64) keeps the 16 rows a wave streams off
+ *     the same HBM channels (measured +19 %% at H=4096).  expert_offsets NULL ⇒ one group of R rows;
  *     sorted_token NULL ⇒ tok(r) = r.  x: [T,H] (row stride ldx); act: [R,I] contiguous.    */
 int glm_grouped_gemm_gateup_silu(const void* x, int64_t ldx, const void* w13,
+                                 int64_t w13_group_stride, int64_t w13_row_stride,
                                  const int32_t* expert_offsets, const int32_t* sorted_token,
                                  void* act, int64_t R, int H, int I, int G,
                                  glm_stream_t stream);
@@ -152,8 +155,10 @@ int glm_grouped_gemm_gateup_silu(const void* x, int64_t ldx, const void* w13,
 /* a13 (second half) + the per-row scale of moe.py:149:
  *     y[r, :] = bf16( bf16(act[r]·Wd_gᵀ) * scale[r] ) for groups g < n_scaled_groups,
  *     y[r, :] = bf16(act[r]·Wd_gᵀ) otherwise (shared expert / dense MLP).
- *     w2: [G, H, I]; y: [R, H] (row stride ldy).                                            */
+ *     w2: [G, H, I] with element strides (w2_group_stride, w2_row_stride, 1); y: [R, H]
+ *     (row stride ldy).                                            */
 int glm_grouped_gemm_down(const void* act, const void* w2,
+                          int64_t w2_group_stride, int64_t w2_row_stride,
                           const int32_t* expert_offsets, const void* sorted_scale,
                           int n_scaled_groups, void* y, int64_t ldy,
                           int64_t R, int H, int I, int G, glm_stream_t stream);
@@ -164,10 +169,10 @@ int glm_grouped_gemm_down(const void* act, const void* w2,
 int glm_moe_combine(const void* y, int64_t ldy, const int32_t* pair_pos, void* out,
                     int64_t T, int k, int H, int64_t shared_base, glm_stream_t stream);
 
-/* a5/a10 layers/linear.py:53,75,152  y = bf16(x·Wᵀ + b): x [M,K] (ldx), W [N,K] contiguous,
+/* a5/a10 layers/linear.py:53,75,152  y = bf16(x·Wᵀ + b): x [M,K] (ldx), W [N,K] (row pitch ldw),
  *     bias [N] bf16 or NULL, y [M,N] (ldy).  Picks the weight-streaming small-M kernel or the
  *     LDS-tiled MFMA kernel from M.                                                         */
-int glm_gemm_bf16(const void* x, int64_t ldx, const void* w, const void* bias,
+int glm_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
                   void* y, int64_t ldy, int64_t M, int N, int K, glm_stream_t stream);
 
 #ifdef __cplusplus

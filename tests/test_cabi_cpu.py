@@ -39,7 +39,7 @@ def test_binding_table_matches_header(lib_path):
     from nanovllm import hip_ops
     assert sorted(hip_ops.EXPORTED_SYMBOLS) == declared_symbols()
     lib = hip_ops.load_library(lib_path)
-    assert lib.glm_abi_version() == 1
+    assert lib.glm_abi_version() == 2
 
 
 def test_host_only_entry_points(lib_path):
@@ -50,7 +50,7 @@ def test_host_only_entry_points(lib_path):
     # argument validation happens before any launch: usable without a GPU
     rc = lib.glm_rmsnorm(None, None, None, 4, 128, 1e-5, None)
     assert rc == -1 and b"null pointer" in lib.glm_last_error()
-    rc = lib.glm_gemm_bf16(ctypes.c_void_p(16), 8, ctypes.c_void_p(16), None, ctypes.c_void_p(16), 4, 4, 4, 16, None)
+    rc = lib.glm_gemm_bf16(ctypes.c_void_p(16), 8, ctypes.c_void_p(16), 16, None, ctypes.c_void_p(16), 4, 4, 4, 16, None)
     assert rc == -1 and b"bad shape" in lib.glm_last_error()
 
 

@@ -434,3 +434,31 @@ def test_varlen_attn_prefill(ops, lens_q, lens_k, nh, nkv, paged):
         out = ops.varlen_attn_prefill(dev(q), dev(k), dev(v), dev(cu_q), dev(cu_k), max(lens_q), scale)
     assert torch.isfinite(out.float()).all()
     assert_mixed(out, ref, 1.6e-2, 4e-3, f"prefill attn q={lens_q} k={lens_k}")
+
+
+def test_padded_weight_pitch(ops):
+    """Row-padded weight storage behind [out, in] / [G, 2I, H] views gives identical results."""
+    M, N, K = 32, 512, 4096
+    x = rnd(M, K, seed=101)
+    w = rnd(N, K, seed=102, scale=K ** -0.5)
+    wp = ops.padded_weight(N, K, dtype=BF, device="cuda")
+    assert wp.shape == (N, K) and wp.stride(0) == K + 64
+    wp.copy_(w)
+    assert torch.equal(ops.gemm_bf16(dev(x), wp, None), ops.gemm_bf16(dev(x), dev(w), None))
+    big = rnd(200, K, seed=103)
+    assert torch.equal(ops.gemm_bf16(dev(big), wp, None), ops.gemm_bf16(dev(big), dev(w), None))
+    # grouped: padded stacks
+    T, E, k, H, I = 16, 4, 2, 2048, 64
+    xs = rnd(T, H, seed=104)
+    w13 = rnd(E + 1, 2 * I, H, seed=105, scale=H ** -0.5)
+    w13p = ops.padded_weight(2 * I, H, E + 1, dtype=BF, device="cuda")
+    assert w13p.stride(1) == H + 64
+    w13p.copy_(w13)
+    g = torch.Generator().manual_seed(106)
+    idx = torch.stack([torch.randperm(E, generator=g)[:k].sort()[0] for _ in range(T)]).to(torch.int64)
+    wts = (torch.rand(T, k, generator=g) + 0.1).to(BF)
+    offs, tok, scale, pos = ops.moe_align(dev(idx), dev(wts), E, True)
+    R = T * k + T
+    a1 = ops.grouped_gemm_gateup_silu(dev(xs), w13p, offs, tok, R)
+    a2 = ops.grouped_gemm_gateup_silu(dev(xs), dev(w13), offs, tok, R)
+    assert torch.equal(a1, a2)
