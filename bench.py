@@ -172,6 +172,7 @@ def main():
         cpu_base = cpu_baseline(model, cfg, kv, block_tables, context_lens, positions, slot_mapping, B, L)
 
     if rank == 0:
+        attach_pmc_traffic(kernels)
         dom = kernels.get("grouped_gemm_gateup_silu")
         line = {
             "metric": "decode tokens/sec/GPU GLM-4-MoE bs=32 seq=4096; grouped-GEMM MFMA util %",
@@ -190,6 +191,23 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def attach_pmc_traffic(kernels: dict) -> None:
+    """`traffic` = HBM bytes per launch from the PMC counters.  The counters need their own
+    `rocprofv3 --pmc` passes (FETCH_SIZE and WRITE_SIZE cannot share a pass), so they are taken
+    from the newest committed summary under profiles/ (same workload, TP=1) rather than re-measured
+    inside this run; null when no summary covers the kernel."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
+    if not files:
+        return
+    with open(files[-1]) as f:
+        pmc = json.load(f)
+    for name, rec in kernels.items():
+        if name in pmc and rec.get("bound") == "hbm":
+            rec["traffic"] = pmc[name]["hbm_bytes_corrected"]
+            rec["traffic_source"] = os.path.relpath(files[-1], ROOT)
 
 
 def measure_kernels(model, cfg, ops, B, ctx, world, iters, dev):
