@@ -6,18 +6,19 @@
 //   * out^T = W · x^T: weight rows on the MFMA row axis (A), tokens on the column axis (B), so a
 //     lane's 4 accumulator registers are 4 consecutive output columns of one token (8-B stores)
 //     and gate/up sit in the same lanes for the fused SiLU·mul epilogue.
-//   * 256(n) x 128(m) x 64(k) workgroup tile, 8 waves as 4(n) x 2(m), each wave 64x64 = 4x4 MFMA
-//     tiles of mfma_f32_16x16x32_bf16 (64 accumulator registers); two waves per SIMD alternate
-//     between their LDS-read and MFMA phases.
-//   * both operand tiles are staged by LDS-DMA (global_load_lds_dwordx4: 8 rows x 128 B per
-//     instruction, 6 instructions per wave per K tile); the LDS image is lane-linear, bank
-//     conflicts of the 16-row fragment reads are removed by permuting the SOURCE chunk:
-//     chunk' = chunk ^ ((row >> 1) & 7) (rows are 128 B = half a bank row).
+//   * 8 waves as 4(n) x 2(m); two tile configurations of the same kernel: 256(n) x 256(m) x 32(k)
+//     with a 4-stage LDS ring (wave tile 64x128, 128 accumulator registers; 12 LDS reads + 4 DMA
+//     per 32 MFMAs) for large groups, 256 x 128 x 64 with a 3-stage ring (wave tile 64x64) for
+//     smaller ones.  Measured at T=16384: 942 vs 851 TFLOP/s on the same box.
+//   * both operand tiles are staged by LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction);
+//     the LDS image is lane-linear, bank conflicts of the 16-row ds_read_b128 fragment reads are
+//     removed by permuting the SOURCE chunk: chunk' = chunk ^ ((row >> 1) & 7) for 128-B rows,
+//     chunk ^ ((row >> 1) & 2) for 64-B rows (found by enumerating the b128 lane groups).
 //   * token rows of the B operand are gathered through sorted_token (per-lane source address of
 //     the DMA), so the grouped GEMM needs no pre-gathered activation copy.
-//   * 3-stage LDS ring (3 x 48 KiB), prefetch distance 2, raw s_barriers and a COUNTED
-//     s_waitcnt vmcnt(6): the DMA of the newest tile stays in flight across the barriers.
-//     Fragment reads are inline asm (hipcc would drain the DMA before them).
+//   * LDS ring with prefetch distance NSTAGE-1, raw s_barriers and COUNTED s_waitcnt vmcnt: the
+//     DMA of the newest tiles stays in flight across the barriers.  Fragment reads are inline asm
+//     (hipcc would drain the DMA before them).
 //   * two phases per K tile (loads | MFMAs) and waves 4-7 staggered one barrier behind waves 0-3,
 //     so the two waves of each SIMD alternate between feeding the matrix pipe and issuing loads
 //     (all 8 waves in lockstep left the pipe idle ~60 % of the cycles: 830 TFLOP/s).
@@ -25,18 +26,39 @@
 //     blocks x all n-tiles (n-tile major): the workgroups co-resident on an XCD form a supertile
 //     whose operand panels are shared through that XCD's L2.
 #include "gemm_internal.h"
+#include <stdlib.h>
+
 
 namespace {
 
-constexpr int LM_BM = 128;                               // token rows per tile (MFMA column axis)
-constexpr int LM_BN = 256;                               // weight rows per tile (MFMA row axis)
-constexpr int LM_BK = 64;
-constexpr int LM_BAND = 8;                               // row blocks per L2 supertile band
-constexpr int LM_WT = LM_BN * LM_BK * 2;                 // 32 KiB weight tile
-constexpr int LM_XT = LM_BM * LM_BK * 2;                 // 16 KiB activation tile
-constexpr int LM_STAGE = LM_WT + LM_XT;                  // 48 KiB
-constexpr int LM_NSTAGE = 3;
-constexpr int LM_LDS = LM_NSTAGE * LM_STAGE + 16;
+constexpr int LM_BN = 256;    // weight rows per tile (MFMA row axis); 4 waves x 64 rows
+constexpr int LM_BAND = 8;    // row blocks per L2 supertile band
+
+// Tile configurations (the kernel is written once over these):
+//   CfgA 256(n) x 128(m) x 64(k), 3-stage ring, wave tile 64x64  (16 LDS reads + 6 DMA per 32 MFMA)
+//   CfgB 256(n) x 256(m) x 32(k), 4-stage ring, wave tile 64x128 (12 LDS reads + 4 DMA per 32 MFMA)
+template <int BM_, int BK_, int NSTAGE_>
+struct LmCfg {
+    static constexpr int BM = BM_, BK = BK_, NSTAGE = NSTAGE_;
+    static constexpr int RB = BK * 2;              // bytes per tile row
+    static constexpr int CPR = RB / 16;            // 16-B chunks per row
+    static constexpr int RPI = 1024 / RB;          // rows per DMA instruction
+    static constexpr int W_DMA = LM_BN / RPI / 8;  // weight DMA instructions per wave per tile
+    static constexpr int X_DMA = BM / RPI / 8;     // activation DMA instructions per wave per tile
+    static constexpr int DPW = W_DMA + X_DMA;
+    static constexpr int KS = BK / 32;             // MFMA k-steps per tile
+    static constexpr int MT = BM / 2 / 16;         // 16-token MFMA tiles per wave (2 waves along m)
+    static constexpr int WT = LM_BN * RB;          // weight tile bytes
+    static constexpr int XT = BM * RB;
+    static constexpr int STAGE = WT + XT;
+    static constexpr int LDS = NSTAGE * STAGE + 16;
+    static constexpr int DIST = NSTAGE - 1;        // prefetch distance in tiles
+    static constexpr int NF = KS * (4 + MT);       // fragment registers (u32x4) per tile
+    // source-chunk permutation that makes the 16-row ds_read_b128 fragment reads conflict free
+    __device__ static constexpr int swz(int row) { return RB == 128 ? ((row >> 1) & 7) : ((row >> 1) & 2); }
+};
+using LmCfgA = LmCfg<128, 64, 3>;
+using LmCfgB = LmCfg<256, 32, 4>;
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
@@ -52,18 +74,33 @@ __device__ __forceinline__ void lds_read_b128(u32x4_t& dst, unsigned addr) {
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(uintptr_t)(const lds_void_t*)p;
 }
+// wait for all LDS reads; every fragment register is named so that no consumer moves above it
+__device__ __forceinline__ void lds_wait(u32x4_t (&f)[12]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]),
+                   "+v"(f[8]), "+v"(f[9]), "+v"(f[10]), "+v"(f[11])
+                 :
+                 : "memory");
+}
+__device__ __forceinline__ void lds_wait(u32x4_t (&f)[16]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]),
+                   "+v"(f[8]), "+v"(f[9]), "+v"(f[10]), "+v"(f[11]), "+v"(f[12]), "+v"(f[13]), "+v"(f[14]), "+v"(f[15])
+                 :
+                 : "memory");
+}
+// counted wait: leave the newest `tiles` tiles' DMA (DPW instructions each) in flight
+template <int DPW>
+__device__ __forceinline__ void dma_wait_leave(int tiles) {
+    if (tiles <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(DPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * DPW) : "memory");
+}
 
-#define LM_WAIT8(a)                                                                                   \
-    asm volatile("s_waitcnt lgkmcnt(0)"                                                               \
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), \
-                   "+v"(a[7])                                                                         \
-                 :                                                                                    \
-                 : "memory")
-
-template <int MODE>
+template <int MODE, class C>
 __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, int n_tiles, int total_wg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* sh = reinterpret_cast<int*>(smem + LM_NSTAGE * LM_STAGE);
+    int* sh = reinterpret_cast<int*>(smem + C::NSTAGE * C::STAGE);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wid & 3, wm = wid >> 2;
@@ -79,25 +116,24 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
     const int rem = bid % (LM_BAND * n_tiles);
     const int ntile = rem / LM_BAND;
     const int combo = band * LM_BAND + rem % LM_BAND;
-    glm_locate_block(p.offs, p.G, p.R, LM_BM, combo, sh);
+    glm_locate_block(p.offs, p.G, p.R, C::BM, combo, sh);
     __syncthreads();
     const int grp = sh[0];
     if (grp < 0) return;
     const int m0 = sh[1], mcnt = sh[2];
     const int K = p.K;
-    const int nk = (K + LM_BK - 1) / LM_BK;
+    const int nk = (K + C::BK - 1) / C::BK;
 
-    // ---- DMA sources.  One instruction = 8 tile rows x 8 chunks; lane → row +(lane>>3), LDS
-    // position lane&7 holds global chunk (lane&7) ^ ((row>>1)&7).  Wave w issues weight
-    // instructions 4w..4w+3 (rows 32w..32w+31) and activation instructions 2w, 2w+1. ----
-    const bf16_t* wsrc[4];
-    const bf16_t* xsrc[2];
-    int wch[4], xch[2];
+    // ---- DMA sources.  One instruction = RPI tile rows x CPR chunks (1 KiB); lane → row
+    // +(lane / CPR), LDS position lane % CPR holds global chunk (lane % CPR) ^ swz(row). ----
+    const bf16_t* wsrc[C::W_DMA];
+    const bf16_t* xsrc[C::X_DMA];
+    int wch[C::W_DMA], xch[C::X_DMA];
     const bf16_t* wg = p.w + (int64_t)grp * p.w_gstride;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wid * 4 + i) * 8 + (lane >> 3);  // 0..255
-        const int ch = (lane & 7) ^ ((row >> 1) & 7);
+    for (int i = 0; i < C::W_DMA; ++i) {
+        const int row = (wid * C::W_DMA + i) * C::RPI + lane / C::CPR;  // 0..255
+        const int ch = (lane % C::CPR) ^ C::swz(row);
         wch[i] = ch;
         int wr;
         if (MODE == GEMM_GATEUP) {
@@ -109,9 +145,9 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         wsrc[i] = wg + (int64_t)wr * p.ldw + ch * 8;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wid * 2 + i) * 8 + (lane >> 3);  // 0..127
-        const int ch = (lane & 7) ^ ((row >> 1) & 7);
+    for (int i = 0; i < C::X_DMA; ++i) {
+        const int row = (wid * C::X_DMA + i) * C::RPI + lane / C::CPR;  // 0..BM-1
+        const int ch = (lane % C::CPR) ^ C::swz(row);
         xch[i] = ch;
         const int mr = row < mcnt ? row : 0;
         const int64_t srow = p.src ? (int64_t)p.src[m0 + mr] : (int64_t)(m0 + mr);
@@ -119,102 +155,95 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
     }
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_lm);
     auto stage = [&](int slot, int kt) {
-        char* wdst = smem + slot * LM_STAGE + wid * 4 * 1024;
-        char* xdst = smem + slot * LM_STAGE + LM_WT + wid * 2 * 1024;
-        const int k0 = kt * LM_BK;
+        char* wdst = smem + slot * C::STAGE + wid * C::W_DMA * 1024;
+        char* xdst = smem + slot * C::STAGE + C::WT + wid * C::X_DMA * 1024;
+        const int k0 = kt * C::BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(k0 + wch[i] * 8 < K ? wsrc[i] + k0 : zero, wdst + i * 1024);
+        for (int i = 0; i < C::W_DMA; ++i) glds16(k0 + wch[i] * 8 < K ? wsrc[i] + k0 : zero, wdst + i * 1024);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16(k0 + xch[i] * 8 < K ? xsrc[i] + k0 : zero, xdst + i * 1024);
+        for (int i = 0; i < C::X_DMA; ++i) glds16(k0 + xch[i] * 8 < K ? xsrc[i] + k0 : zero, xdst + i * 1024);
     };
 
     // ---- fragment read offsets relative to the stage base: lane (c,g4) reads row +c, chunk 4ks+g4
-    unsigned wrel[2][4], xrel[2][4];
+    unsigned rel[C::NF];  // per k-step: 4 weight fragments then MT activation fragments
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        int wrow;
-        if (MODE == GEMM_GATEUP) wrow = (t < 2 ? wn * 32 + 16 * t : 128 + wn * 32 + 16 * (t - 2)) + c;
-        else wrow = wn * 64 + 16 * t + c;
-        const int xrow = wm * 64 + 16 * t + c;
+    for (int ks = 0; ks < C::KS; ++ks) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            wrel[ks][t] = wrow * 128 + (((4 * ks + g4) ^ ((wrow >> 1) & 7)) << 4);
-            xrel[ks][t] = LM_WT + xrow * 128 + (((4 * ks + g4) ^ ((xrow >> 1) & 7)) << 4);
+        for (int t = 0; t < 4; ++t) {
+            int wrow;
+            if (MODE == GEMM_GATEUP) wrow = (t < 2 ? wn * 32 + 16 * t : 128 + wn * 32 + 16 * (t - 2)) + c;
+            else wrow = wn * 64 + 16 * t + c;
+            rel[ks * (4 + C::MT) + t] = wrow * C::RB + (((4 * ks + g4) ^ C::swz(wrow)) << 4);
+        }
+#pragma unroll
+        for (int t = 0; t < C::MT; ++t) {
+            const int xrow = wm * (C::BM / 2) + 16 * t + c;
+            rel[ks * (4 + C::MT) + 4 + t] = C::WT + xrow * C::RB + (((4 * ks + g4) ^ C::swz(xrow)) << 4);
         }
     }
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[4][C::MT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < C::MT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // ---- main loop: two phases per K tile, waves 4-7 run ONE BARRIER BEHIND waves 0-3 ----
-    //   phase 1: LDS fragment reads of tile kt (16 x b128) + DMA issue of tile kt+2 + counted
-    //            wait for this wave's share of tile kt+1, then barrier
-    //   phase 2: 32 MFMAs, then barrier
+    //   phase 1: LDS fragment reads of tile kt + DMA issue of tile kt+DIST + counted wait for
+    //            this wave's share of tile kt+1, then barrier
+    //   phase 2: the tile's MFMAs, then barrier
     // The two waves that share a SIMD (w, w+4) are therefore always in opposite phases: one feeds
     // the matrix pipe while the other issues loads (in lockstep the pipe idles ~60 % of the time).
-    // Ordering under the stagger (X' = the other group's program point at the same hardware barrier):
+    // Ordering under the stagger (the other group sits one barrier earlier/later):
     //   RAW  tile kt+1 is read in phase 1 of kt+1, i.e. after this group's B2(kt) = other group's
     //        B1(kt) (or later); every wave waited for its share of kt+1 BEFORE its own B1(kt).
-    //   WAR  tile kt+2 overwrites the slot of kt-1 in phase 1 of kt, i.e. after this group's B2(kt-1)
-    //        >= other group's B1(kt-1); every wave finished reading kt-1 before its own B1(kt-1).
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    //   WAR  tile kt+DIST overwrites the slot of kt-1 in phase 1 of kt, i.e. after this group's
+    //        B2(kt-1) >= other group's B1(kt-1); every wave finished reading kt-1 before its own
+    //        B1(kt-1).
+#pragma unroll
+    for (int d = 0; d < C::DIST; ++d)
+        if (d < nk) stage(d, d);
+    dma_wait_leave<C::DPW>(min(nk, C::DIST) - 1);
     __builtin_amdgcn_s_barrier();                 // every share of tile 0 landed
     if (wid >= 4) __builtin_amdgcn_s_barrier();   // the stagger
     int slot = 0;  // ring slot of tile kt
     const unsigned base = lds_addr(smem);
     for (int kt = 0; kt < nk; ++kt) {
         // ---------------- phase 1 ----------------
-        const unsigned sb = base + slot * LM_STAGE;
-        u32x4_t f0[8], f1[8];  // [0..3] weight fragments of n-tiles, [4..7] activation fragments
+        const unsigned sb = base + slot * C::STAGE;
+        u32x4_t f[C::NF];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            lds_read_b128(f0[t], sb + wrel[0][t]);
-            lds_read_b128(f0[4 + t], sb + xrel[0][t]);
-        }
-        if (kt + 2 < nk) stage(slot == 0 ? 2 : slot - 1, kt + 2);  // into the slot tile kt-1 used
+        for (int i = 0; i < C::NF / 2; ++i) lds_read_b128(f[i], sb + rel[i]);
+        if (kt + C::DIST < nk) stage(slot == 0 ? C::NSTAGE - 1 : slot - 1, kt + C::DIST);  // slot of tile kt-1
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            lds_read_b128(f1[t], sb + wrel[1][t]);
-            lds_read_b128(f1[4 + t], sb + xrel[1][t]);
-        }
-        // this wave's share of tile kt+1 (everything older than the 6 instructions just issued)
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        LM_WAIT8(f0);
-        LM_WAIT8(f1);
+        for (int i = C::NF / 2; i < C::NF; ++i) lds_read_b128(f[i], sb + rel[i]);
+        // this wave's share of tile kt+1: leave only the tiles newer than kt+1 in flight
+        dma_wait_leave<C::DPW>(min(kt + C::DIST, nk - 1) - (kt + 1));
+        lds_wait(f);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();  // B1
         // ---------------- phase 2 ----------------
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8_t, f0[nt]), __builtin_bit_cast(bf16x8_t, f0[4 + mt]), acc[nt][mt], 0, 0, 0);
+            for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8_t, f1[nt]), __builtin_bit_cast(bf16x8_t, f1[4 + mt]), acc[nt][mt], 0, 0, 0);
+                for (int mt = 0; mt < C::MT; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8_t, f[ks * (4 + C::MT) + nt]),
+                        __builtin_bit_cast(bf16x8_t, f[ks * (4 + C::MT) + 4 + mt]), acc[nt][mt], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();  // B2
-        slot = slot == 2 ? 0 : slot + 1;
+        slot = slot == C::NSTAGE - 1 ? 0 : slot + 1;
     }
     if (wid < 4) __builtin_amdgcn_s_barrier();  // match the other group's extra barrier
 
     // ---- epilogue ----
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int row = wm * 64 + 16 * mt + c;
+    for (int mt = 0; mt < C::MT; ++mt) {
+        const int row = wm * (C::BM / 2) + 16 * mt + c;
         if (row >= mcnt) continue;
         bf16_t* yrow = p.y + (int64_t)(m0 + row) * p.ldy;
         if (MODE == GEMM_GATEUP) {
@@ -255,27 +284,46 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
     }
 }
 
-template <int MODE>
-int launch_largem(const GemmParams& p, hipStream_t st) {
+template <int MODE, class C>
+int launch_largem_cfg(const GemmParams& p, hipStream_t st) {
     const int cols_per_wg = MODE == GEMM_GATEUP ? 128 : LM_BN;
     const int n_tiles = (p.N + cols_per_wg - 1) / cols_per_wg;
-    const int64_t combos = p.offs ? (p.R / LM_BM + p.G) : (p.R + LM_BM - 1) / LM_BM;
+    const int64_t combos = p.offs ? (p.R / C::BM + p.G) : (p.R + C::BM - 1) / C::BM;
     const int64_t total = (combos + LM_BAND - 1) / LM_BAND * LM_BAND * n_tiles;
     if (total <= 0) return GLM_OK;
     GLM_CHECK_ARG(total < (1ll << 31), GLM_ERR_UNSUPPORTED, "gemm_largem: grid too large");
-    auto kern = gemm_largem_kernel<MODE>;
+    auto kern = gemm_largem_kernel<MODE, C>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LM_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         if (e != hipSuccess) {
-            glm_set_error("gemm_largem: hipFuncSetAttribute(%d): %s", LM_LDS, hipGetErrorString(e));
+            glm_set_error("gemm_largem: hipFuncSetAttribute(%d): %s", C::LDS, hipGetErrorString(e));
             return GLM_ERR_LAUNCH;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), LM_LDS, st, p, n_tiles, (int)total);
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), C::LDS, st, p, n_tiles, (int)total);
     GLM_CHECK_LAUNCH("gemm_largem");
     return GLM_OK;
+}
+
+// GLM_LARGEM_CFG=A|B overrides the tile configuration (A/B measurements)
+int cfg_choice() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("GLM_LARGEM_CFG");
+        v = (e && (e[0] == 'A' || e[0] == 'a')) ? 1 : (e && (e[0] == 'B' || e[0] == 'b')) ? 2 : 0;
+    }
+    return v;
+}
+
+template <int MODE>
+int launch_largem(const GemmParams& p, hipStream_t st) {
+    // 256-row blocks pay off once a group fills most of one; smaller groups keep the 128-row tile
+    const int ch = cfg_choice();
+    const int64_t avg_rows = p.R / (p.G > 0 ? p.G : 1);
+    const bool use_b = ch == 2 || (ch == 0 && avg_rows >= 192);
+    return use_b ? launch_largem_cfg<MODE, LmCfgB>(p, st) : launch_largem_cfg<MODE, LmCfgA>(p, st);
 }
 
 }  // namespace

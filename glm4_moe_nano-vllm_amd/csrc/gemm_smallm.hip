@@ -43,6 +43,9 @@ __device__ __forceinline__ u32x4_t gload16(const void* p) {
 #ifndef GLM_ABLATE
 #define GLM_ABLATE 0
 #endif
+#ifndef GLM_PIN_BFR
+#define GLM_PIN_BFR 0
+#endif
 
 #ifndef GLM_SM_KS
 #define GLM_SM_KS 4
@@ -219,6 +222,9 @@ __device__ __forceinline__ void smallm_body(const GemmParams& p, char* smem, int
                                                                       (((4 * ks + g4) ^ c) << 4));
                 }
             }
+#if GLM_PIN_BFR
+        __builtin_amdgcn_sched_barrier(0);  // experiment: keep the fragment reads as one burst
+#endif
 #pragma unroll
         for (int ks = 0; ks < SM_KS; ++ks) {
 #pragma unroll

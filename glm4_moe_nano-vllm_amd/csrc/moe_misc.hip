@@ -197,6 +197,9 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const bf16_t* __restri
                                                           const int32_t* __restrict__ pair_pos,
                                                           bf16_t* __restrict__ out, int k, int H,
                                                           int64_t shared_base, int vec_ok) {
+    // grid = (token, column slab): a token's row is split over gridDim.y workgroups so that a
+    // decode batch (32 tokens) still spreads over the chip; every workgroup re-derives the sorted
+    // row list (k <= 64 integers) on its own.
     __shared__ int pos[COMBINE_MAX_K];
     __shared__ int npos;
     const int64_t t = blockIdx.x;
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const bf16_t* __restri
     const int n = npos;
     if (vec_ok) {
         const int nvec = H >> 3;
-        for (int c = threadIdx.x; c < nvec; c += 256) {
+        for (int c = blockIdx.y * 256 + threadIdx.x; c < nvec; c += gridDim.y * 256) {
             float acc[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = 0.f;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const bf16_t* __restri
             reinterpret_cast<u32x4_t*>(out + t * H)[c] = o;
         }
     } else {
-        for (int c = threadIdx.x; c < H; c += 256) {
+        for (int c = blockIdx.y * 256 + threadIdx.x; c < H; c += gridDim.y * 256) {
             float acc = 0.f;
             for (int j = 0; j < n; ++j) acc = rbf(acc + bf2f(y[(int64_t)pos[j] * ldy + c]));
             if (shared_base >= 0) acc = acc + bf2f(y[(shared_base + t) * ldy + c]);
@@ -299,7 +302,11 @@ extern "C" int glm_moe_combine(const void* y, int64_t ldy, const int32_t* pair_p
     GLM_CHECK_ARG(k <= COMBINE_MAX_K, GLM_ERR_UNSUPPORTED, "glm_moe_combine: k > %d", COMBINE_MAX_K);
     if (T == 0) return GLM_OK;
     const int vec_ok = H % 8 == 0 && ldy % 8 == 0 && glm_aligned16(y) && glm_aligned16(out);
-    hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned)T), dim3(256), 0, glm_s(stream),
+    const int work = vec_ok ? H / 8 : H;                       // items per token row
+    int slabs = (work + 255) / 256;                            // at most one item per thread
+    while (slabs > 1 && (int64_t)T * slabs > 2048) slabs = (slabs + 1) / 2;  // enough WGs already
+    GLM_CHECK_ARG(T <= 0x7fffffff, GLM_ERR_UNSUPPORTED, "glm_moe_combine: T too large");
+    hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned)T, (unsigned)slabs), dim3(256), 0, glm_s(stream),
                        (const bf16_t*)y, ldy, pair_pos, (bf16_t*)out, k, H, shared_base, vec_ok);
     GLM_CHECK_LAUNCH("glm_moe_combine");
     return GLM_OK;

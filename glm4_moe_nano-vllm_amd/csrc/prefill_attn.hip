@@ -2,10 +2,9 @@
 // nanovllm/layers/attention.py:85-100 → flash_attn_varlen_func(causal=True[, block_table])).
 // gfx950 only, head_dim 128.
 //
-// Flash-style: the score matrix is never materialised.  A workgroup owns 64 query rows of one
-// (sequence, query head); its 4 waves take 16 rows each and walk the key tiles (64 keys) that the
-// bottom-right-aligned causal mask leaves visible.  K/V tiles are staged once per workgroup by
-// LDS-DMA with the same source-side swizzles as the decode kernel (K: chunk ^ (key & 15) for
+// Flash-style: the score matrix is never materialised.  A workgroup owns 64*FA_QT query rows of
+// one (sequence, query head); its 4 waves take 16*FA_QT rows each and walk the key tiles (64 keys) that the bottom-right-aligned causal mask leaves visible.  K/V
+// tiles are staged once per workgroup by LDS-DMA with the same source-side swizzles as the decode kernel (K: chunk ^ (key & 15) for
 // ds_read_b128 row reads, V: chunk ^ ((key & 7) << 1) for ds_read_b64_tr_b16 transposed reads),
 // double-buffered.  Math per wave is the decode kernel's: S^T = K·Q^T with keys on the MFMA row
 // axis and the wave's 16 query rows on the lane axis, fp32 online softmax per lane column, then
@@ -18,7 +17,9 @@
 namespace {
 
 constexpr int FA_HD = 128, FA_ROWB = 256;
-constexpr int FA_BQ = 64, FA_BK = 64;
+constexpr int FA_QT = 1;                   // 16-row query tiles per wave (2 measured slower: 217 vs 339 TFLOP/s,
+                                           // the loop is VALU-bound in the softmax/rescale, not LDS-bound)
+constexpr int FA_BQ = 64 * FA_QT, FA_BK = 64;
 constexpr int FA_TILE = FA_BK * FA_ROWB;   // 16 KiB per K or V tile
 constexpr int FA_STAGE = 2 * FA_TILE;
 constexpr int FA_MAX_BT = 4096;
@@ -50,14 +51,14 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(
     int nkv, int block_size, float scale_log2e) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* bt_lds = reinterpret_cast<int*>(smem + 2 * FA_STAGE);
-    const int qt = blockIdx.x, head = blockIdx.y;
+    const int qblk = blockIdx.x, head = blockIdx.y;
     const int64_t b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
     const int q0 = cu_q[b], lq = cu_q[b + 1] - q0;
     const int k0 = cu_k[b], lk = cu_k[b + 1] - k0;
-    const int qbase = qt * FA_BQ;
+    const int qbase = qblk * FA_BQ;
     if (qbase >= lq) return;  // uniform
     const int kvh = head / (nh / nkv);
     const int off = lk - lq;  // causal: query i sees keys j <= i + off
@@ -70,21 +71,25 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(
         for (int i = tid; i < nblk; i += 256) bt_lds[i] = block_tables[b * bt_stride + i];
     }
 
-    // Q^T fragments: lane (c,g) = query row qbase + 16*wid + c, k-step ks → hd [32ks+8g, +8)
-    const int qi = qbase + 16 * wid + c;
-    bf16x8_t qf[4];
-    {
-        const bool ok = qi < lq;
-        const bf16_t* qrow = q + ((int64_t)(q0 + (ok ? qi : 0)) * nh + head) * FA_HD;
+    // Q^T fragments: lane (c,g), tile qt = query row qbase + 32*wid + 16*qt + c, k-step ks → hd [32ks+8g, +8)
+    int qi[FA_QT];
+    bf16x8_t qf[FA_QT][4];
+#pragma unroll
+    for (int qt = 0; qt < FA_QT; ++qt) {
+        qi[qt] = qbase + (16 * FA_QT) * wid + 16 * qt + c;
+        const bool ok = qi[qt] < lq;
+        const bf16_t* qrow = q + ((int64_t)(q0 + (ok ? qi[qt] : 0)) * nh + head) * FA_HD;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             u32x4_t t = {0, 0, 0, 0};
             if (ok) t = *reinterpret_cast<const u32x4_t*>(qrow + 32 * ks + 8 * g);
-            qf[ks] = __builtin_bit_cast(bf16x8_t, t);
+            qf[qt][ks] = __builtin_bit_cast(bf16x8_t, t);
         }
     }
     __syncthreads();
-    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
+#pragma unroll
+    for (int qt = 0; qt < FA_QT; ++qt)
+        asm volatile("" : "+v"(qf[qt][0]), "+v"(qf[qt][1]), "+v"(qf[qt][2]), "+v"(qf[qt][3]));
 
     // staging: wave w issues instructions i=0..3 for K and V; instruction covers tile rows
     // (4w+i)*4 .. +3 (4 keys x 256 B); lane → row +(lane>>4), position lane&15
@@ -121,11 +126,17 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(
             v_rel[dt] = FA_TILE + row * FA_ROWB + (((2 * dt + (pp >> 1)) ^ ((row & 7) << 1)) << 4) + ((pp & 1) << 3);
     }
 
-    f32x4_t acc[8];
+    f32x4_t acc[FA_QT][8];
+    float m_run[FA_QT], l_run[FA_QT];
+    int jmax[FA_QT];  // last visible key of this lane's query row, per tile
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
-    const int jmax = qi + off;  // last visible key of this lane's query row
+    for (int qt = 0; qt < FA_QT; ++qt) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[qt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        m_run[qt] = -INFINITY;
+        l_run[qt] = 0.f;
+        jmax[qt] = qi[qt] + off;
+    }
 
     if (ntiles > 0) stage(0, 0);
     for (int t = 0; t < ntiles; ++t) {
@@ -162,66 +173,74 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(
                          :
                          : "memory");
             __builtin_amdgcn_sched_barrier(0);
-            f32x4_t s[2];
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                s[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[tt][ks]),
-                                                                   qf[ks], s[tt], 0, 0, 0);
-            }
             const int kb = t * FA_BK + hlf * 32 + 4 * g;
-            float mloc = -INFINITY;
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
+            for (int qt = 0; qt < FA_QT; ++qt) {
+                f32x4_t s[2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = kb + 16 * tt + r;
-                    float x = s[tt][r] * scale_log2e;
-                    if (j > jmax || j >= lk) x = -INFINITY;
-                    s[tt][r] = x;
-                    mloc = fmaxf(mloc, x);
+                for (int tt = 0; tt < 2; ++tt) {
+                    s[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+                        s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[tt][ks]),
+                                                                       qf[qt][ks], s[tt], 0, 0, 0);
                 }
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            const float m_new = fmaxf(m_run, mloc);
-            // a fully masked 32-key slab for this row keeps m_new = -inf: use 0 as the reference
-            // point so that exp2(-inf - 0) = 0 and no NaN appears
-            const float m_use = m_new == -INFINITY ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-            float psum = 0.f;
-            bf16x8_t pf;
+                float mloc = -INFINITY;
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
+                for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(s[tt][r] - m_use);
-                    psum += pv;
-                    pf[4 * tt + r] = (__bf16)pv;
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = kb + 16 * tt + r;
+                        float x = s[tt][r] * scale_log2e;
+                        if (j > jmax[qt] || j >= lk) x = -INFINITY;
+                        s[tt][r] = x;
+                        mloc = fmaxf(mloc, x);
+                    }
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                const float m_new = fmaxf(m_run[qt], mloc);
+                // a fully masked 32-key slab for this row keeps m_new = -inf: use 0 as the reference
+                // point so that exp2(-inf - 0) = 0 and no NaN appears
+                const float m_use = m_new == -INFINITY ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_use);
+                float psum = 0.f;
+                bf16x8_t pf;
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(s[tt][r] - m_use);
+                        psum += pv;
+                        pf[4 * tt + r] = (__bf16)pv;
+                    }
+                l_run[qt] = l_run[qt] * alpha + psum;
+                m_run[qt] = m_new;
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) {
+                    acc[qt][dt] *= alpha;
+                    const u32x4_t vv = {vf[dt][0][0], vf[dt][0][1], vf[dt][1][0], vf[dt][1][1]};
+                    acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pf,
+                                                                         acc[qt][dt], 0, 0, 0);
                 }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt) {
-                acc[dt] *= alpha;
-                const u32x4_t vv = {vf[dt][0][0], vf[dt][0][1], vf[dt][1][0], vf[dt][1][1]};
-                acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pf,
-                                                                 acc[dt], 0, 0, 0);
             }
         }
         __builtin_amdgcn_s_barrier();  // everyone is done with buf[cur] before it is refilled
     }
 
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
-    if (qi < lq) {
-        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-        bf16_t* orow = out + ((int64_t)(q0 + qi) * nh + head) * FA_HD;
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-            u32x2_t o = {pack2bf(acc[dt][0] * inv, acc[dt][1] * inv), pack2bf(acc[dt][2] * inv, acc[dt][3] * inv)};
-            *reinterpret_cast<u32x2_t*>(orow + 16 * dt + 4 * g) = o;
+    for (int qt = 0; qt < FA_QT; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (qi[qt] < lq) {
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+            bf16_t* orow = out + ((int64_t)(q0 + qi[qt]) * nh + head) * FA_HD;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                u32x2_t o = {pack2bf(acc[qt][dt][0] * inv, acc[qt][dt][1] * inv),
+                             pack2bf(acc[qt][dt][2] * inv, acc[qt][dt][3] * inv)};
+                *reinterpret_cast<u32x2_t*>(orow + 16 * dt + 4 * g) = o;
+            }
         }
     }
 }
