@@ -32,7 +32,13 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st);
 // LDS-tiled MFMA kernels for many rows per group (prefill)
 int glm_launch_gemm_largem(int mode, const GemmParams& p, hipStream_t st);
 
-__device__ __forceinline__ float glm_silu(float g) { return g / (1.0f + expf(-g)); }
+// SiLU for the GEMM epilogues: g * rcp(1 + 2^(-g*log2 e)) on the hardware exp2/rcp units
+// (each within 1 ulp fp32).  The result is rounded to bf16 right away, so against the precise
+// expf + IEEE-division form it can differ by one bf16 ulp only on a rounding boundary; the
+// precise form costs ~6x the VALU work, which a 1-workgroup-per-CU GEMM epilogue cannot hide.
+__device__ __forceinline__ float glm_silu(float g) {
+    return g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g));
+}
 
 // Locate the (group, row-block) a workgroup owns: combo index `target` enumerates
 // ceil(cnt_g / MB) blocks per group in group order.  Executed by the whole first wave;

@@ -22,7 +22,7 @@
 //   * two phases per K tile (loads | MFMAs) and waves 4-7 staggered one barrier behind waves 0-3,
 //     so the two waves of each SIMD alternate between feeding the matrix pipe and issuing loads
 //     (all 8 waves in lockstep left the pipe idle ~60 % of the cycles: 830 TFLOP/s).
-//   * 1-D grid remapped so that one XCD gets a contiguous run of tiles, ordered in bands of 8 row
+//   * 1-D grid remapped so that one XCD gets a contiguous run of tiles, ordered in bands of 4 row
 //     blocks x all n-tiles (n-tile major): the workgroups co-resident on an XCD form a supertile
 //     whose operand panels are shared through that XCD's L2.
 #include "gemm_internal.h"
@@ -32,7 +32,13 @@
 namespace {
 
 constexpr int LM_BN = 256;    // weight rows per tile (MFMA row axis); 4 waves x 64 rows
-constexpr int LM_BAND = 8;    // row blocks per L2 supertile band
+#ifndef GLM_LM_BAND
+#define GLM_LM_BAND 4
+#endif
+#ifndef GLM_LM_STAGE_POS
+#define GLM_LM_STAGE_POS 0  // 0: DMA issue before the fragment reads (measured best, +0.8 %), 1: between, 2: after
+#endif
+constexpr int LM_BAND = GLM_LM_BAND;  // row blocks per L2 supertile band
 
 // Tile configurations (the kernel is written once over these):
 //   CfgA 256(n) x 128(m) x 64(k), 3-stage ring, wave tile 64x64  (16 LDS reads + 6 DMA per 32 MFMA)
@@ -212,11 +218,14 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         // ---------------- phase 1 ----------------
         const unsigned sb = base + slot * C::STAGE;
         u32x4_t f[C::NF];
+        const int nslot = slot == 0 ? C::NSTAGE - 1 : slot - 1;  // slot of tile kt-1
+        if (GLM_LM_STAGE_POS == 0 && kt + C::DIST < nk) stage(nslot, kt + C::DIST);
 #pragma unroll
         for (int i = 0; i < C::NF / 2; ++i) lds_read_b128(f[i], sb + rel[i]);
-        if (kt + C::DIST < nk) stage(slot == 0 ? C::NSTAGE - 1 : slot - 1, kt + C::DIST);  // slot of tile kt-1
+        if (GLM_LM_STAGE_POS == 1 && kt + C::DIST < nk) stage(nslot, kt + C::DIST);
 #pragma unroll
         for (int i = C::NF / 2; i < C::NF; ++i) lds_read_b128(f[i], sb + rel[i]);
+        if (GLM_LM_STAGE_POS == 2 && kt + C::DIST < nk) stage(nslot, kt + C::DIST);
         // this wave's share of tile kt+1: leave only the tiles newer than kt+1 in flight
         dma_wait_leave<C::DPW>(min(kt + C::DIST, nk - 1) - (kt + 1));
         lds_wait(f);
