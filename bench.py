@@ -190,6 +190,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()  # ranks > 0 wait here while rank 0 finishes its per-kernel measurements
         dist.destroy_process_group()
 
 
