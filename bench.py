@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=20)
+    ap.add_argument("--fp8-experts", action="store_true",
+                    help="stream the experts as OCP fp8 e4m3 (weight-only, N4 / BASELINE config 5 flavour); "
+                         "the default bf16 run is the one comparable with the reference")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -92,6 +95,8 @@ def main():
 
     B, ctx, L, bs = args.batch, args.ctx, args.layers, 256
     cfg = air64e_config(L, max(ctx, 4096))
+    if args.fp8_experts:
+        cfg.expert_weight_dtype = "fp8_e4m3"
     torch.set_default_dtype(torch.bfloat16)
     t0 = time.time()
     with torch.device(dev):
@@ -178,7 +183,8 @@ def main():
             "metric": "decode tokens/sec/GPU GLM-4-MoE bs=32 seq=4096; grouped-GEMM MFMA util %",
             "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16 (experts: fp8 e4m3 weight-only)" if args.fp8_experts else "bf16", "data": "synthetic",
             "config": {"workload": f"GLM-4-MoE Air-64E decode bs={B} ctx={ctx} L={L} (layer0 dense), "
                                    f"random-init bf16, paged KV block 256, greedy",
                        "global_batch": B, "seq_len": ctx, "layers": L,
@@ -261,18 +267,34 @@ def measure_kernels(model, cfg, ops, B, ctx, world, iters, dev):
 
     acts = [None] * nl
 
+    fp8 = getattr(cfg, "expert_weight_dtype", None) == "fp8_e4m3"
+    wb = 1 if fp8 else 2  # bytes per expert weight element
+    if fp8:
+        for l in layers:
+            if l.mlp._fp8 is None:
+                l.mlp.quantize_experts_fp8()
+
     def f_gateup(i):
         p = prep[i % nl]
-        acts[i % nl] = ops.grouped_gemm_gateup_silu(x, p[4], p[0], p[1], R)
+        if fp8:
+            q = layers[i % nl].mlp._fp8
+            acts[i % nl] = ops.grouped_gemm_gateup_silu_fp8w(x, q[0], q[1], p[0], p[1], R)
+        else:
+            acts[i % nl] = ops.grouped_gemm_gateup_silu(x, p[4], p[0], p[1], R)
     m, md = timeit(f_gateup, iters)
-    rec("grouped_gemm_gateup_silu", m, md, touched * 2 * I * H * 2,
-        f"touched groups ({touched:.1f} incl. shared) x 2*I*H*2 B of gate|up weights")
+    rec("grouped_gemm_gateup_silu", m, md, touched * 2 * I * H * wb,
+        f"touched groups ({touched:.1f} incl. shared) x 2*I*H*{wb} B of gate|up weights")
 
     def f_down(i):
         p = prep[i % nl]
-        ops.grouped_gemm_down(acts[i % nl] if acts[i % nl] is not None else acts[0], p[5], p[0], p[2], E)
+        a = acts[i % nl] if acts[i % nl] is not None else acts[0]
+        if fp8:
+            q = layers[i % nl].mlp._fp8
+            ops.grouped_gemm_down_fp8w(a, q[2], q[3], p[0], p[2], E)
+        else:
+            ops.grouped_gemm_down(a, p[5], p[0], p[2], E)
     m, md = timeit(f_down, iters)
-    rec("grouped_gemm_down", m, md, touched * H * I * 2, "touched groups x H*I*2 B of down weights")
+    rec("grouped_gemm_down", m, md, touched * H * I * wb, f"touched groups x H*I*{wb} B of down weights")
 
     attn_layers = [l.self_attn for l in model.model.layers]
     q = torch.randn(B, nh, hd, device=dev).to(torch.bfloat16)
@@ -298,10 +320,11 @@ def measure_kernels(model, cfg, ops, B, ctx, world, iters, dev):
     rec("gemm_o", m, md, H * nh * hd * 2, "H*nh*hd*2 B of W_o")
     # ---- prefill shape of the same config: T = 16384 tokens (max_num_batched_tokens,
     # config.py:9) → 131072 routed pairs + 16384 shared rows; MFMA-bound ----
-    try:
-        res.update(measure_prefill_gemm(layers[0], cfg, ops, world, dev))
-    except torch.OutOfMemoryError:
-        pass
+    if not fp8:  # the prefill-shape MFMA measurement is for the bf16 tiled kernel
+        try:
+            res.update(measure_prefill_gemm(layers[0], cfg, ops, world, dev))
+        except torch.OutOfMemoryError:
+            pass
     return res
 
 

@@ -12,7 +12,7 @@ void glm_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int glm_abi_version(void) { return 2; }
+extern "C" int glm_abi_version(void) { return 3; }
 extern "C" const char* glm_last_error(void) { return g_err; }
 
 namespace {
@@ -84,4 +84,51 @@ extern "C" int glm_grouped_gemm_down(const void* act, const void* w2, int64_t w2
     p.y = (bf16_t*)y; p.ldy = ldy;
     p.R = R; p.N = H; p.K = I; p.G = G;
     return dispatch(GEMM_DOWN, p, glm_s(stream));
+}
+
+extern "C" int glm_grouped_gemm_gateup_silu_fp8w(const void* x, int64_t ldx, const void* w13_q,
+                                                 int64_t w13_group_stride, int64_t w13_row_stride,
+                                                 const float* w13_scale, int64_t w13_scale_group_stride,
+                                                 const int32_t* expert_offsets, const int32_t* sorted_token,
+                                                 void* act, int64_t R, int H, int I, int G,
+                                                 glm_stream_t stream) {
+    GLM_CHECK_ARG(x && w13_q && w13_scale && act, GLM_ERR_INVALID, "glm_grouped_gemm_gateup_silu_fp8w: null pointer");
+    GLM_CHECK_ARG(R >= 0 && H > 0 && I > 0 && G >= 1 && ldx >= H && w13_row_stride >= H &&
+                      (G == 1 || (w13_group_stride >= (int64_t)2 * I * w13_row_stride &&
+                                  w13_scale_group_stride >= (int64_t)2 * I)) &&
+                      (expert_offsets != nullptr || G == 1),
+                  GLM_ERR_INVALID, "glm_grouped_gemm_gateup_silu_fp8w: bad shape");
+    if (R == 0) return GLM_OK;
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)x; p.ldx = ldx;
+    p.w = (const bf16_t*)w13_q; p.w_gstride = w13_group_stride; p.ldw = w13_row_stride;
+    p.wscale = w13_scale; p.wscale_gstride = w13_scale_group_stride;
+    p.offs = expert_offsets; p.src = sorted_token;
+    p.y = (bf16_t*)act; p.ldy = I;
+    p.R = R; p.N = I; p.K = H; p.G = G;
+    return glm_launch_gemm_smallm_fp8w(GEMM_GATEUP, p, glm_s(stream));
+}
+
+extern "C" int glm_grouped_gemm_down_fp8w(const void* act, const void* w2_q, int64_t w2_group_stride,
+                                          int64_t w2_row_stride, const float* w2_scale,
+                                          int64_t w2_scale_group_stride, const int32_t* expert_offsets,
+                                          const void* sorted_scale, int n_scaled_groups, void* y,
+                                          int64_t ldy, int64_t R, int H, int I, int G, glm_stream_t stream) {
+    GLM_CHECK_ARG(act && w2_q && w2_scale && y, GLM_ERR_INVALID, "glm_grouped_gemm_down_fp8w: null pointer");
+    GLM_CHECK_ARG(R >= 0 && H > 0 && I > 0 && G >= 1 && ldy >= H && w2_row_stride >= I &&
+                      (G == 1 || (w2_group_stride >= (int64_t)H * w2_row_stride && w2_scale_group_stride >= H)) &&
+                      (expert_offsets != nullptr || G == 1) && (n_scaled_groups == 0 || sorted_scale != nullptr),
+                  GLM_ERR_INVALID, "glm_grouped_gemm_down_fp8w: bad shape");
+    if (R == 0) return GLM_OK;
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)act; p.ldx = I;
+    p.w = (const bf16_t*)w2_q; p.w_gstride = w2_group_stride; p.ldw = w2_row_stride;
+    p.wscale = w2_scale; p.wscale_gstride = w2_scale_group_stride;
+    p.offs = expert_offsets; p.src = nullptr;
+    p.scale = (const bf16_t*)sorted_scale; p.n_scaled = n_scaled_groups;
+    p.y = (bf16_t*)y; p.ldy = ldy;
+    p.R = R; p.N = H; p.K = I; p.G = G;
+    return glm_launch_gemm_smallm_fp8w(GEMM_DOWN, p, glm_s(stream));
 }

@@ -14,6 +14,8 @@ struct GemmParams {
     const bf16_t* w;      // group g at w + g*w_gstride; row n at + n*ldw, K contiguous
     int64_t w_gstride;
     int64_t ldw;
+    const float* wscale;  // fp8 weights only: per-row dequantisation scale, group g at + g*wscale_gstride
+    int64_t wscale_gstride;
     const int32_t* offs;  // [G+1] row offsets per group, or nullptr (one group of R rows)
     const int32_t* src;   // source row of sorted row r, or nullptr (identity)
     const bf16_t* scale;  // [R] per-row scale (GEMM_DOWN) or nullptr
@@ -29,6 +31,8 @@ struct GemmParams {
 
 // weight-streaming kernels for few rows per group (decode); returns GLM_* code
 int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st);
+// same, weights stored as OCP fp8 e4m3 (1 byte/element, ldw/w_gstride in elements) + per-row scale
+int glm_launch_gemm_smallm_fp8w(int mode, const GemmParams& p, hipStream_t st);
 // LDS-tiled MFMA kernels for many rows per group (prefill)
 int glm_launch_gemm_largem(int mode, const GemmParams& p, hipStream_t st);
 

@@ -105,7 +105,7 @@ __device__ __forceinline__ void smallm_epilogue(const GemmParams& p, f32x4_t (&a
 // MT is a template parameter so that the chunk loop is straight-line code: every load is
 // unconditional (clamped address + select), the last chunk is peeled, and hipcc can place
 // counted vmcnt waits instead of draining at control-flow joins.
-template <int MODE, int NWAVES, int WS, int RT, int MT, int XSTRIDE>
+template <int MODE, int NWAVES, int WS, int RT, int MT, int XSTRIDE, bool W8>
 __device__ __forceinline__ void smallm_body(const GemmParams& p, char* smem, int grp, int m0, int mcnt) {
     constexpr int NT = NWAVES * 64;
     constexpr int WR = NWAVES / WS;
@@ -122,22 +122,24 @@ __device__ __forceinline__ void smallm_body(const GemmParams& p, char* smem, int
     const int cps = (nchunks + WS - 1) / WS;  // chunks per K slice
 
     // ---- weight row pointers of this wave (A operand: lane (c,g4) = row c, k-offset 8*g4) ----
-    const bf16_t* wg = p.w + (int64_t)grp * p.w_gstride;
-    const bf16_t* wrow[RT];
+    // byte pointers: weights are bf16 (2 B/element) or, with W8, OCP fp8 e4m3 (1 B/element)
+    constexpr int WB = W8 ? 1 : 2;
+    const char* wg = reinterpret_cast<const char*>(p.w) + (int64_t)grp * p.w_gstride * WB;
+    const char* wrow[RT];
+    int wrowi[RT];  // weight row index (for the fp8 per-row scale)
     int ncol0;  // first output column of this wave
     if (MODE == GEMM_GATEUP) {
         ncol0 = (blockIdx.x * WR + wr) * 16;
         const int r = min(ncol0 + c, p.N - 1);
-        wrow[0] = wg + (int64_t)r * p.ldw;
-        wrow[RT - 1] = wg + (int64_t)(p.N + r) * p.ldw;
+        wrowi[0] = r;
+        wrowi[RT - 1] = p.N + r;
     } else {
         ncol0 = (blockIdx.x * WR + wr) * (16 * RT);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const int r = min(ncol0 + 16 * rt + c, p.N - 1);
-            wrow[rt] = wg + (int64_t)r * p.ldw;
-        }
+        for (int rt = 0; rt < RT; ++rt) wrowi[rt] = min(ncol0 + 16 * rt + c, p.N - 1);
     }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) wrow[rt] = wg + (int64_t)wrowi[rt] * p.ldw * WB;
 
     // ---- activation staging: vector v = tid + i*NT ↔ (slice, row, 16-B chunk) ----
     const bf16_t* xrow[XV];
@@ -177,11 +179,26 @@ __device__ __forceinline__ void smallm_body(const GemmParams& p, char* smem, int
     // weight registers: each one is refilled for the NEXT chunk right after its last MFMA, so a
     // full chunk (8 x 1 KiB per wave) stays in flight across the barrier.  (A 2-chunk-deep
     // variant was measured slower: it costs ~45 VGPRs, i.e. half the resident waves.)
-    u32x4_t wreg[RT][SM_KS];
-    auto w_load = [&](int ci, int rt, int ks) {
-        const int k = (cbeg + ci) * SM_KC + 32 * ks + 8 * g4;
-        const bf16_t* src = k < K ? wrow[rt] + k : reinterpret_cast<const bf16_t*>(g_zero_page);
-        wreg[rt][ks] = gload16(src);
+    // bf16: one 16-B load per (row tile, k-step).  fp8: one 16-B load covers TWO k-steps of this
+    // lane (16 consecutive k), so k-slot (ks, g4, j) ↔ k = 64*(ks>>1) + 16*g4 + 8*(ks&1) + j and
+    // the B fragments below are read with the matching chunk index.
+    constexpr int WL = W8 ? SM_KS / 2 : SM_KS;  // 16-B weight loads per row tile per chunk
+    u32x4_t wreg[RT][WL];
+    auto w_load = [&](int ci, int rt, int l) {
+        const int k = W8 ? (cbeg + ci) * SM_KC + 64 * l + 16 * g4 : (cbeg + ci) * SM_KC + 32 * l + 8 * g4;
+        const char* src = k < K ? wrow[rt] + (int64_t)k * WB : reinterpret_cast<const char*>(g_zero_page);
+        wreg[rt][l] = gload16(src);
+    };
+    // A fragment of k-step ks from the weight registers (fp8 → bf16 is exact)
+    auto a_frag = [&](int rt, int ks) -> bf16x8_t {
+        if (!W8) return __builtin_bit_cast(bf16x8_t, wreg[rt][ks]);
+        const u32x4_t w = wreg[rt][ks >> 1];
+        const unsigned d0 = w[2 * (ks & 1)], d1 = w[2 * (ks & 1) + 1];
+        typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+        const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(d0, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(d0, true);
+        const f32x2_t c2 = __builtin_amdgcn_cvt_pk_f32_fp8(d1, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(d1, true);
+        const u32x4_t o = {pack2bf(a[0], a[1]), pack2bf(b[0], b[1]), pack2bf(c2[0], c2[1]), pack2bf(d[0], d[1])};
+        return __builtin_bit_cast(bf16x8_t, o);
     };
 
     f32x4_t acc[RT][MT];
@@ -193,9 +210,9 @@ __device__ __forceinline__ void smallm_body(const GemmParams& p, char* smem, int
     // ---- prologue ----
     x_load(0);
 #pragma unroll
-    for (int ks = 0; ks < SM_KS; ++ks)
+    for (int l = 0; l < WL; ++l)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) w_load(0, rt, ks);
+        for (int rt = 0; rt < RT; ++rt) w_load(0, rt, l);
     x_store(0);
     __syncthreads();
 
@@ -218,8 +235,9 @@ __device__ __forceinline__ void smallm_body(const GemmParams& p, char* smem, int
                     const u32x4_t z = {(unsigned)ci, 0, 0, 0};
                     bfr[ks][mt] = __builtin_bit_cast(bf16x8_t, z);
                 } else {
+                    const int xch = W8 ? 8 * (ks >> 1) + 2 * g4 + (ks & 1) : 4 * ks + g4;
                     bfr[ks][mt] = *reinterpret_cast<const bf16x8_t*>(xb + (16 * mt + c) * SM_XROWB +
-                                                                      (((4 * ks + g4) ^ c) << 4));
+                                                                      ((xch ^ c) << 4));
                 }
             }
 #if GLM_PIN_BFR
@@ -233,16 +251,16 @@ __device__ __forceinline__ void smallm_body(const GemmParams& p, char* smem, int
                 for (int mt = 0; mt < MT; ++mt) {
                     if (GLM_ABLATE & 1) {
                         const u32x4_t bb = __builtin_bit_cast(u32x4_t, bfr[ks][mt]);
-                        acc[rt][mt][0] += __uint_as_float((wreg[rt][ks][0] ^ wreg[rt][ks][1] ^ wreg[rt][ks][2] ^
-                                                           wreg[rt][ks][3] ^ bb[0]) & 0x3fffffffu);
+                        const u32x4_t ww = __builtin_bit_cast(u32x4_t, a_frag(rt, ks));
+                        acc[rt][mt][0] += __uint_as_float((ww[0] ^ ww[1] ^ ww[2] ^ ww[3] ^ bb[0]) & 0x3fffffffu);
                     } else {
-                        acc[rt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8_t, wreg[rt][ks]), bfr[ks][mt], acc[rt][mt], 0, 0, 0);
+                        acc[rt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_frag(rt, ks), bfr[ks][mt],
+                                                                             acc[rt][mt], 0, 0, 0);
                     }
                 }
-            if (MORE) {
+            if (MORE && (!W8 || (ks & 1))) {  // a register is free again after its last k-step
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) w_load(ci + 1, rt, ks);
+                for (int rt = 0; rt < RT; ++rt) w_load(ci + 1, rt, W8 ? ks >> 1 : ks);
             }
         }
         if (MORE && !(GLM_ABLATE & 2)) x_store(cur ^ 1);
@@ -274,10 +292,26 @@ __device__ __forceinline__ void smallm_body(const GemmParams& p, char* smem, int
                         red + ((((wr * (WS - 1) + (s - 1)) * RT + rt) * MT + mt) * 64 + lane) * 4);
     }
 
+    if (W8) {
+        // dequantisation: accumulator register r of row tile rt belongs to weight row base+4*g4+r
+        const float* ws = p.wscale + (int64_t)grp * p.wscale_gstride;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int rbase = (MODE == GEMM_GATEUP ? (rt == 0 ? ncol0 : p.N + ncol0) : ncol0 + 16 * rt) + 4 * g4;
+            const int rmax = MODE == GEMM_GATEUP ? 2 * p.N - 1 : p.N - 1;
+            float sc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[r] = ws[min(rbase + r, rmax)];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[rt][mt][r] *= sc[r];
+        }
+    }
     smallm_epilogue<MODE, RT, MT>(p, acc, grp, m0, mcnt, ncol0, c, g4);
 }
 
-template <int MODE, int NWAVES, int WS, int RT, int MTMAX>
+template <int MODE, int NWAVES, int WS, int RT, int MTMAX, bool W8>
 __global__ __launch_bounds__(NWAVES * 64) void gemm_smallm_kernel(const GemmParams p) {
     constexpr int MB = 16 * MTMAX;
     constexpr int XBUF = WS * MB * SM_XROWB;  // bytes per x buffer (sized for MTMAX)
@@ -290,12 +324,12 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_smallm_kernel(const GemmPara
     if (grp < 0) return;
     const int m0 = sh[1], mcnt = sh[2];
     const int nmt = (mcnt + 15) >> 4;
-    if (nmt <= 1) smallm_body<MODE, NWAVES, WS, RT, 1, XBUF>(p, smem, grp, m0, mcnt);
-    else if (nmt <= 2 || MTMAX == 2) smallm_body<MODE, NWAVES, WS, RT, 2, XBUF>(p, smem, grp, m0, mcnt);
-    else smallm_body<MODE, NWAVES, WS, RT, MTMAX, XBUF>(p, smem, grp, m0, mcnt);
+    if (nmt <= 1) smallm_body<MODE, NWAVES, WS, RT, 1, XBUF, W8>(p, smem, grp, m0, mcnt);
+    else if (nmt <= 2 || MTMAX == 2) smallm_body<MODE, NWAVES, WS, RT, 2, XBUF, W8>(p, smem, grp, m0, mcnt);
+    else smallm_body<MODE, NWAVES, WS, RT, MTMAX, XBUF, W8>(p, smem, grp, m0, mcnt);
 }
 
-template <int MODE, int NWAVES, int WS, int RT, int MTMAX>
+template <int MODE, int NWAVES, int WS, int RT, int MTMAX, bool W8 = false>
 int launch_cfg(const GemmParams& p, hipStream_t st) {
     constexpr int WR = NWAVES / WS;
     constexpr int MB = 16 * MTMAX;
@@ -308,7 +342,7 @@ int launch_cfg(const GemmParams& p, hipStream_t st) {
     const int64_t combos = p.offs ? (p.R / MB + p.G) : (p.R + MB - 1) / MB;
     if (combos <= 0 || gx == 0) return GLM_OK;
     GLM_CHECK_ARG(combos <= 65535, GLM_ERR_UNSUPPORTED, "gemm_smallm: too many row blocks (%ld)", (long)combos);
-    auto kern = gemm_smallm_kernel<MODE, NWAVES, WS, RT, MTMAX>;
+    auto kern = gemm_smallm_kernel<MODE, NWAVES, WS, RT, MTMAX, W8>;
     if (LDS > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -346,4 +380,17 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
     if (p.G > 1 || rows > 32 || tiles32 >= 1024) return launch_cfg<GEMM_PLAIN, 4, 1, 2, 4>(p, st);
     if (tiles32 >= 384) return launch_cfg<GEMM_PLAIN, 4, 4, 2, 2>(p, st);
     return launch_cfg<GEMM_PLAIN, 8, 8, 1, 2>(p, st);
+}
+
+int glm_launch_gemm_smallm_fp8w(int mode, const GemmParams& p, hipStream_t st) {
+    GLM_CHECK_ARG(p.K % 16 == 0 && p.N % 4 == 0 && p.ldx % 8 == 0 && p.ldy % 4 == 0 && p.ldw % 16 == 0 &&
+                      p.w_gstride % 16 == 0 && glm_aligned16(p.x) && glm_aligned16(p.w) &&
+                      (((uintptr_t)p.y) & 7) == 0 && p.wscale != nullptr,
+                  GLM_ERR_UNSUPPORTED,
+                  "gemm_smallm(fp8 weights): needs K%%16==0, N%%4==0, ldw%%16==0, 16B-aligned x/W, scales (K=%d N=%d)",
+                  p.K, p.N);
+    if (mode == GEMM_GATEUP) return launch_cfg<GEMM_GATEUP, 4, 1, 2, 2, true>(p, st);
+    if (mode == GEMM_DOWN) return launch_cfg<GEMM_DOWN, 4, 1, 2, 2, true>(p, st);
+    glm_set_error("gemm_smallm(fp8 weights): only the grouped expert projections are quantised");
+    return GLM_ERR_UNSUPPORTED;
 }

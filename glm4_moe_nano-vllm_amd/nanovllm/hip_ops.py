@@ -53,6 +53,12 @@ _SIGNATURES = {
                                              c_void_p]),
     "glm_grouped_gemm_down": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int,
                                       c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "glm_grouped_gemm_gateup_silu_fp8w": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                                                  c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                                  c_int, c_int, c_void_p]),
+    "glm_grouped_gemm_down_fp8w": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p,
+                                           c_void_p, c_int, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
+                                           c_void_p]),
     "glm_moe_combine": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
                                 c_int64, c_void_p]),
     "glm_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
@@ -337,6 +343,49 @@ def grouped_gemm_down(act, w2, expert_offsets, sorted_scale, n_scaled_groups: in
                                                 _p(expert_offsets),
                                                 _p(sorted_scale), n_scaled_groups, _p(y), H, R, H,
                                                 I, G, _stream()), "glm_grouped_gemm_down")
+    return y
+
+
+FP8_MAX = 448.0  # largest finite OCP e4m3fn value
+
+
+def quantize_fp8_rowwise(w: torch.Tensor):
+    """Weight-only quantisation used for the experts: per-row scale s = max|row| / 448,
+    q = e4m3fn(row / s).  Returns (q as uint8 with a padded row pitch, s as fp32)."""
+    rows, cols = w.shape[-2], w.shape[-1]
+    s = (w.abs().amax(dim=-1).to(torch.float32) / FP8_MAX).clamp_min(1e-12)
+    q = (w.to(torch.float32) / s.unsqueeze(-1)).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    pad = 128 if cols % 4096 == 0 else 0  # same channel-aliasing rule as padded_weight (bytes)
+    store = torch.empty((*w.shape[:-1], cols + pad), dtype=torch.uint8, device=w.device)
+    view = store[..., :cols]
+    view.copy_(q.view(torch.uint8))
+    return view, s.contiguous()
+
+
+def grouped_gemm_gateup_silu_fp8w(x, w13_q, w13_s, expert_offsets, sorted_token, R: int) -> torch.Tensor:
+    """x [T,H] bf16; w13_q [G,2I,H] uint8 (fp8 e4m3); w13_s [G,2I] fp32 -> act [R,I]."""
+    _bf16(x, "x")
+    G, I2, H = w13_q.shape
+    I = I2 // 2
+    assert w13_q.dtype == torch.uint8 and w13_q.stride(2) == 1 and w13_s.dtype == torch.float32
+    assert w13_s.stride(1) == 1
+    act = torch.empty((R, I), dtype=x.dtype, device=x.device)
+    _check(load_library().glm_grouped_gemm_gateup_silu_fp8w(
+        _p(x), x.stride(0), _p(w13_q), w13_q.stride(0), w13_q.stride(1), _p(w13_s), w13_s.stride(0),
+        _p(expert_offsets), _p(sorted_token), _p(act), R, H, I, G, _stream()),
+        "glm_grouped_gemm_gateup_silu_fp8w")
+    return act
+
+
+def grouped_gemm_down_fp8w(act, w2_q, w2_s, expert_offsets, sorted_scale, n_scaled_groups: int) -> torch.Tensor:
+    _bf16(act, "act")
+    G, H, I = w2_q.shape
+    R = act.shape[0]
+    assert w2_q.dtype == torch.uint8 and w2_q.stride(2) == 1 and w2_s.dtype == torch.float32 and act.is_contiguous()
+    y = torch.empty((R, H), dtype=act.dtype, device=act.device)
+    _check(load_library().glm_grouped_gemm_down_fp8w(
+        _p(act), _p(w2_q), w2_q.stride(0), w2_q.stride(1), _p(w2_s), w2_s.stride(0), _p(expert_offsets),
+        _p(sorted_scale), n_scaled_groups, _p(y), H, R, H, I, G, _stream()), "glm_grouped_gemm_down_fp8w")
     return y
 
 

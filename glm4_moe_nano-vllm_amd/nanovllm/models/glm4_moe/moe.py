@@ -55,6 +55,10 @@ class Glm4MoeMoE(nn.Module):
         self._w13 = None
         self._w2 = None
         self._stack(copy=False)
+        # N4: `config.expert_weight_dtype = "fp8_e4m3"` streams the experts as OCP fp8 (weight-only,
+        # per-row scale); quantised lazily from the loaded bf16 weights at the first forward
+        self.expert_weight_dtype = getattr(config, "expert_weight_dtype", None)
+        self._fp8 = None
 
     # ---- stacked expert storage ---------------------------------------------------------
     def _mlps(self):
@@ -78,6 +82,13 @@ class Glm4MoeMoE(nn.Module):
         if self._w13 is None or first.data_ptr() != self._w13.data_ptr():
             self._stack(copy=True)  # parameters were moved/replaced (e.g. .to(device)): re-tie
         return self._w13, self._w2
+
+    def quantize_experts_fp8(self) -> None:
+        """(Re)build the fp8 copies of the stacked expert weights from the current bf16 values."""
+        w13, w2 = self._stacked()
+        w13_q, w13_s = hip_ops.quantize_fp8_rowwise(w13)
+        w2_q, w2_s = hip_ops.quantize_fp8_rowwise(w2)
+        self._fp8 = (w13_q, w13_s, w2_q, w2_s)
 
     # ---- weights ------------------------------------------------------------------------
     def load_weights(self, path: str, prefix: str):
@@ -103,8 +114,15 @@ class Glm4MoeMoE(nn.Module):
         topk_idx, topk_w = self.gate(h)
         offs, tok, scale, pos = hip_ops.moe_align(topk_idx, topk_w, E, True)
         R = T * k + T
-        act = hip_ops.grouped_gemm_gateup_silu(h, w13, offs, tok, R)
-        y = hip_ops.grouped_gemm_down(act, w2, offs, scale, E)
+        if self.expert_weight_dtype == "fp8_e4m3":
+            if self._fp8 is None:
+                self.quantize_experts_fp8()
+            w13_q, w13_s, w2_q, w2_s = self._fp8
+            act = hip_ops.grouped_gemm_gateup_silu_fp8w(h, w13_q, w13_s, offs, tok, R)
+            y = hip_ops.grouped_gemm_down_fp8w(act, w2_q, w2_s, offs, scale, E)
+        else:
+            act = hip_ops.grouped_gemm_gateup_silu(h, w13, offs, tok, R)
+            y = hip_ops.grouped_gemm_down(act, w2, offs, scale, E)
         out = hip_ops.moe_combine(y, pos, T, k, T * k)
         if get_tp_group().world_size > 1:
             get_tp_group().all_reduce(out)

@@ -163,6 +163,26 @@ int glm_grouped_gemm_down(const void* act, const void* w2,
                           int n_scaled_groups, void* y, int64_t ldy,
                           int64_t R, int H, int I, int G, glm_stream_t stream);
 
+/* N4 (no reference counterpart; BASELINE config 5): the same two grouped projections with the
+ *     expert weights stored as OCP fp8 e4m3 (1 byte/element) plus one fp32 scale per weight row:
+ *     W'[n,k] = scale[n] * fp8(Wq[n,k]).  Weight-only quantisation: activations stay bf16, the
+ *     fp8 values are converted exactly to bf16 in registers, accumulated in fp32 on the bf16 MFMA,
+ *     and the row scale is applied to the fp32 accumulator before the bf16 roundings of a13.
+ *     w13_q: [G, 2I, H] uint8 with element strides (group, row, 1); w13_scale: f32 [G, 2I]
+ *     (row stride 1, group stride w13_scale_group_stride); likewise w2_q [G, H, I], w2_scale [G, H]. */
+int glm_grouped_gemm_gateup_silu_fp8w(const void* x, int64_t ldx, const void* w13_q,
+                                      int64_t w13_group_stride, int64_t w13_row_stride,
+                                      const float* w13_scale, int64_t w13_scale_group_stride,
+                                      const int32_t* expert_offsets, const int32_t* sorted_token,
+                                      void* act, int64_t R, int H, int I, int G,
+                                      glm_stream_t stream);
+int glm_grouped_gemm_down_fp8w(const void* act, const void* w2_q,
+                               int64_t w2_group_stride, int64_t w2_row_stride,
+                               const float* w2_scale, int64_t w2_scale_group_stride,
+                               const int32_t* expert_offsets, const void* sorted_scale,
+                               int n_scaled_groups, void* y, int64_t ldy,
+                               int64_t R, int H, int I, int G, glm_stream_t stream);
+
 /* a12 models/glm4_moe/moe.py:133,151,171: out[t] = bf16-accumulate of the token's k routed
  *     rows in ascending expert order (one bf16 rounding per add, starting from 0), then
  *     + shared row (bf16 add) when shared_base >= 0 (row index shared_base + t of y).       */

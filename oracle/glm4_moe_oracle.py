@@ -317,3 +317,41 @@ def model_forward(input_ids, positions, embed_w, layers, final_norm_w, cfg, cos_
 def greedy_sample(logits):
     """layers/sampler.py:13-16 (all temperatures == 0)."""
     return logits.to(torch.float32).argmax(dim=-1)
+
+
+# ---------------------------------------------------------------------------------------------
+# N4  fp8 (OCP e4m3fn) weight-only quantised experts.  No reference counterpart (the reference has
+# int4-AWQ dequant-then-GEMM, layers/linear_awq_new.py:254-255; BASELINE config 5 asks for fp8):
+# the oracle is the reference's expert arithmetic (a12/a13) evaluated on the DEQUANTISED weights.
+FP8_MAX = 448.0
+
+
+def quantize_fp8_rowwise(w: torch.Tensor):
+    """Per-row scale s = max|row|/448, q = e4m3fn(row/s) (round-to-nearest-even, saturating)."""
+    s = (w.abs().amax(dim=-1).to(torch.float32) / FP8_MAX).clamp_min(1e-12)
+    q = (w.to(torch.float32) / s.unsqueeze(-1)).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    return q, s
+
+
+def linear_fp8w(x, q, s):
+    """fp32 accumulation of bf16(x) * fp8(q), row scale on the fp32 sum, ONE rounding to x.dtype."""
+    acc = torch.matmul(x.to(torch.float32), q.to(torch.float32).t())
+    return (acc * s.unsqueeze(0)).to(x.dtype)
+
+
+def mlp_fp8w(x, q13, s13, q2, s2):
+    return linear_fp8w(silu_and_mul(linear_fp8w(x, q13, s13)), q2, s2)
+
+
+def moe_fp8w(x, top_k, idx, w, q13, s13, q2, s2, sq13, ss13, sq2, ss2):
+    """moe() with quantised experts; routing (idx, w) is given (the router stays bf16)."""
+    h = x.reshape(-1, x.shape[-1])
+    acc = torch.zeros_like(h)
+    for e in range(q13.shape[0]):
+        hit = idx == e
+        if not bool(hit.any()):
+            continue
+        rows, slot = torch.where(hit)
+        y = mlp_fp8w(h[rows], q13[e], s13[e], q2[e], s2[e])
+        acc.index_add_(0, rows, y * w[rows, slot].unsqueeze(-1))
+    return acc + mlp_fp8w(h, sq13, ss13, sq2, ss2)

@@ -119,3 +119,38 @@ def test_decoder_layer_prefill(tag, prefix):
     s = t["slot_mapping"].long()
     _mixed(kc.cpu().view(-1, 256)[s], t["k_rows"], f"{tag} k cache rows")
     _mixed(vc.cpu().view(-1, 256)[s], t["v_rows"], f"{tag} v cache rows")
+
+
+def test_moe_module_fp8_experts():
+    """nanovllm.models.glm4_moe.moe.Glm4MoeMoE with config.expert_weight_dtype = "fp8_e4m3":
+    router stays bf16 (reference R1-R7), experts stream as OCP fp8 with per-row scales; oracle =
+    the reference's expert arithmetic on the dequantised weights (same bytes, same routing)."""
+    import types
+    from nanovllm.models.glm4_moe.moe import Glm4MoeMoE
+    t, cfg = load_golden("moe")
+    cfg = dict(cfg, expert_weight_dtype="fp8_e4m3")
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device("cuda"):
+            moe = Glm4MoeMoE(types.SimpleNamespace(**cfg))
+    finally:
+        torch.set_default_dtype(old)
+    sd = {k: v for k, v in t.items() if k not in ("x", "y", "idx", "w")}
+    missing, unexpected = moe.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    captured = {}
+    moe.gate.register_forward_hook(lambda m, i, o: captured.update(idx=o[0], w=o[1]))
+    with torch.inference_mode():
+        out = moe(t["x"].cuda())
+    torch.cuda.synchronize()
+    E = cfg["n_routed_experts"]
+    q13, s13, q2, s2 = [a.cpu() for a in moe._fp8]
+    q13 = q13.contiguous().view(torch.float8_e4m3fn)
+    q2 = q2.contiguous().view(torch.float8_e4m3fn)
+    ref = O.moe_fp8w(t["x"], cfg["num_experts_per_tok"], captured["idx"].cpu(), captured["w"].cpu(),
+                     q13[:E], s13[:E], q2[:E], s2[:E], q13[E], s13[E], q2[E], s2[E])
+    _mixed(out, ref, "fp8-expert MoE module")
+    # and close to the bf16 golden within fp8 quantisation error
+    rel = float((out.cpu().float() - t["y"].float()).norm() / t["y"].float().norm())
+    assert rel < 0.08, rel
