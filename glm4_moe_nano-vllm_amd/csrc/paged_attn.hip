@@ -77,7 +77,7 @@ __device__ __forceinline__ void issue_group(const bf16_t* __restrict__ kc, const
 }
 
 template <int DUMMY>
-__global__ __launch_bounds__(256) void paged_attn_decode_kernel(
+__global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
     const int32_t* __restrict__ context_lens, const int32_t* __restrict__ block_tables,
     int64_t bt_stride, bf16_t* __restrict__ out, float* __restrict__ part_o,

@@ -17,8 +17,8 @@
 namespace {
 
 constexpr int FA_HD = 128, FA_ROWB = 256;
-constexpr int FA_QT = 1;                   // 16-row query tiles per wave (2 measured slower: 217 vs 339 TFLOP/s,
-                                           // the loop is VALU-bound in the softmax/rescale, not LDS-bound)
+constexpr int FA_QT = 1;                   // 16-row query tiles per wave (2 pushes the kernel past 256 registers:
+                                           // one wave per SIMD, 232 vs 366 TFLOP/s)
 constexpr int FA_BQ = 64 * FA_QT, FA_BK = 64;
 constexpr int FA_TILE = FA_BK * FA_ROWB;   // 16 KiB per K or V tile
 constexpr int FA_STAGE = 2 * FA_TILE;
@@ -39,12 +39,20 @@ template <int OFF>
 __device__ __forceinline__ void lds_read_tr16_b64(u32x2_t& dst, unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
 }
+// v_max3_f32 without the quieting v_max x,x that fmaxf() gets for each MFMA output
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(uintptr_t)(const lds_void_t*)p;
 }
 
 template <bool PAGED>
-__global__ __launch_bounds__(256) void prefill_attn_kernel(
+// launch bound of 2 waves per SIMD caps the kernel at 256 registers, which makes hipcc pick the VGPR form of the
+// MFMAs: with the default (512) the accumulators live in AGPRs and every slab pays ~40 v_accvgpr copies
+__global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
     const int32_t* __restrict__ block_tables, int64_t bt_stride, bf16_t* __restrict__ out, int nh,
@@ -126,119 +134,171 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(
             v_rel[dt] = FA_TILE + row * FA_ROWB + (((2 * dt + (pp >> 1)) ^ ((row & 7) << 1)) << 4) + ((pp & 1) << 3);
     }
 
-    f32x4_t acc[FA_QT][8];
-    float m_run[FA_QT], l_run[FA_QT];
-    int jmax[FA_QT];  // last visible key of this lane's query row, per tile
+    f32x4_t acc[8];
 #pragma unroll
-    for (int qt = 0; qt < FA_QT; ++qt) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[qt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        m_run[qt] = -INFINITY;
-        l_run[qt] = 0.f;
-        jmax[qt] = qi[qt] + off;
-    }
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const int jmax = qi[0] + off;                     // last visible key of this lane's query row
+    const int row_first = qbase + 16 * wid;           // first query row of the wave
 
-    if (ntiles > 0) stage(0, 0);
-    for (int t = 0; t < ntiles; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < ntiles) {
-            stage(cur ^ 1, t + 1);
+    // The loop is software-pipelined inside the wave over 32-key slabs: the S MFMAs of slab i+1 are
+    // issued before the softmax VALU work of slab i, so the matrix pipe runs under the exp/max/convert
+    // instructions of the same wave; V fragments of slab i are fetched from LDS while that softmax
+    // runs.  One workgroup barrier per 64-key tile.
+    u32x4_t kf[2][4];
+    u32x2_t vf[8][2];
+    auto read_k = [&](unsigned hb) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            lds_read_b128<0>(kf[0][ks], hb + k_rel[ks]);
+            lds_read_b128<4096>(kf[1][ks], hb + k_rel[ks]);
+        }
+    };
+    auto read_v = [&](unsigned hb, int dlo, int dhi) {
+#pragma unroll
+        for (int dt = dlo; dt < dhi; ++dt) {
+            lds_read_tr16_b64<0>(vf[dt][0], hb + v_rel[dt]);
+            lds_read_tr16_b64<4096>(vf[dt][1], hb + v_rel[dt]);
+        }
+    };
+#define FA_K_REGS                                                                                          \
+    "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]), "+v"(kf[1][0]), "+v"(kf[1][1]),       \
+        "+v"(kf[1][2]), "+v"(kf[1][3])
+#define FA_V_REGS                                                                                          \
+    "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]), "+v"(vf[2][0]), "+v"(vf[2][1]),       \
+        "+v"(vf[3][0]), "+v"(vf[3][1]), "+v"(vf[4][0]), "+v"(vf[4][1]), "+v"(vf[5][0]), "+v"(vf[5][1]),   \
+        "+v"(vf[6][0]), "+v"(vf[6][1]), "+v"(vf[7][0]), "+v"(vf[7][1])
+    auto s_mfma = [&](f32x4_t (&s)[2]) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            s[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[tt][ks]),
+                                                               qf[0][ks], s[tt], 0, 0, 0);
+        }
+    };
+    // online softmax of one slab (keys [kbase, kbase+32)); returns the bf16 P^T fragment and leaves acc
+    // rescaled.  The running maximum lives in the scaled (log2) domain: p = exp2(s*c - m).
+    auto softmax = [&](f32x4_t (&s)[2], int kbase) -> bf16x8_t {
+        // masking is only needed on slabs that touch the causal diagonal or the sequence end for this
+        // wave's rows: the test is wave-uniform and false for almost every slab
+        const bool need_mask = kbase + 31 > row_first + off || kbase + 31 >= lk;
+        if (need_mask) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = kbase + 4 * g + 16 * tt + r;
+                    if (j > jmax || j >= lk) s[tt][r] = -INFINITY;
+                }
+        }
+        float mloc = vmax3(vmax3(vmax3(s[0][0], s[0][1], s[0][2]), s[0][3], s[1][0]), s[1][1], s[1][2]);
+        mloc = vmax3(mloc, s[1][3], s[1][3]);
+        {   // max over the four 16-lane groups that share a query column: VALU lane swaps, no LDS trip
+            const unsigned u = __float_as_uint(mloc);
+            const u32x2_t a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+            mloc = vmax3(__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(a[1]));
+            const unsigned w = __float_as_uint(mloc);
+            const u32x2_t b2 = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+            mloc = vmax3(__uint_as_float(b2[0]), __uint_as_float(b2[1]), __uint_as_float(b2[1]));
+        }
+        const float ms = mloc * scale_log2e;
+        const float m_new = vmax3(m_run, ms, ms);
+        // a row with nothing visible yet keeps m_new = -inf: use 0 as the reference point so that
+        // exp2(-inf - 0) = 0 and no NaN appears
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        float psum = 0.f;
+        bf16x8_t pf;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[tt][r], scale_log2e, -m_use));
+                psum += pv;
+                pf[4 * tt + r] = (__bf16)pv;
+            }
+        // rescale only when some row's maximum actually grew (wave-uniform; after the first few
+        // tiles it rarely does)
+        float alpha = 1.0f;
+        if (__any(m_new > m_run)) {
+            alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) acc[dt] *= alpha;
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        return pf;
+    };
+    auto pv_mfma = [&](bf16x8_t pf) {
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            const u32x4_t vv = {vf[dt][0][0], vf[dt][0][1], vf[dt][1][0], vf[dt][1][1]};
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pf, acc[dt], 0, 0, 0);
+        }
+    };
+
+    if (ntiles > 0) {
+        f32x4_t s_cur[2], s_nxt[2];
+        stage(0, 0);
+        if (ntiles > 1) {
+            stage(1, 1);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        const unsigned sb = lds_addr(smem + cur * FA_STAGE);
-#pragma unroll
-        for (int hlf = 0; hlf < 2; ++hlf) {  // 32 keys at a time
-            u32x4_t kf[2][4];
-            u32x2_t vf[8][2];
-            const unsigned hb = sb + hlf * 32 * FA_ROWB;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                lds_read_b128<0>(kf[0][ks], hb + k_rel[ks]);
-                lds_read_b128<4096>(kf[1][ks], hb + k_rel[ks]);
-            }
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt) {
-                lds_read_tr16_b64<0>(vf[dt][0], hb + v_rel[dt]);
-                lds_read_tr16_b64<4096>(vf[dt][1], hb + v_rel[dt]);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]), "+v"(kf[1][0]),
-                           "+v"(kf[1][1]), "+v"(kf[1][2]), "+v"(kf[1][3]), "+v"(vf[0][0]), "+v"(vf[0][1]),
-                           "+v"(vf[1][0]), "+v"(vf[1][1]), "+v"(vf[2][0]), "+v"(vf[2][1]), "+v"(vf[3][0]),
-                           "+v"(vf[3][1]), "+v"(vf[4][0]), "+v"(vf[4][1]), "+v"(vf[5][0]), "+v"(vf[5][1]),
-                           "+v"(vf[6][0]), "+v"(vf[6][1]), "+v"(vf[7][0]), "+v"(vf[7][1])
-                         :
-                         : "memory");
+        read_k(lds_addr(smem));
+        asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
+        s_mfma(s_cur);
+        for (int t = 0; t < ntiles; ++t) {
+            const unsigned sb = lds_addr(smem + (t & 1) * FA_STAGE);
+            // ---- slab 0 of tile t: S of slab 1 goes to the matrix pipe first
+            read_k(sb + 32 * FA_ROWB);
+            read_v(sb, 0, 4);  // the LDS counter holds 15: K (8 reads) + half of V (8 reads) in flight
+            asm volatile("s_waitcnt lgkmcnt(8)" : FA_K_REGS : : "memory");
             __builtin_amdgcn_sched_barrier(0);
-            const int kb = t * FA_BK + hlf * 32 + 4 * g;
-#pragma unroll
-            for (int qt = 0; qt < FA_QT; ++qt) {
-                f32x4_t s[2];
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    s[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-                        s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[tt][ks]),
-                                                                       qf[qt][ks], s[tt], 0, 0, 0);
-                }
-                float mloc = -INFINITY;
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int j = kb + 16 * tt + r;
-                        float x = s[tt][r] * scale_log2e;
-                        if (j > jmax[qt] || j >= lk) x = -INFINITY;
-                        s[tt][r] = x;
-                        mloc = fmaxf(mloc, x);
-                    }
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-                const float m_new = fmaxf(m_run[qt], mloc);
-                // a fully masked 32-key slab for this row keeps m_new = -inf: use 0 as the reference
-                // point so that exp2(-inf - 0) = 0 and no NaN appears
-                const float m_use = m_new == -INFINITY ? 0.f : m_new;
-                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_use);
-                float psum = 0.f;
-                bf16x8_t pf;
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pv = __builtin_amdgcn_exp2f(s[tt][r] - m_use);
-                        psum += pv;
-                        pf[4 * tt + r] = (__bf16)pv;
-                    }
-                l_run[qt] = l_run[qt] * alpha + psum;
-                m_run[qt] = m_new;
-#pragma unroll
-                for (int dt = 0; dt < 8; ++dt) {
-                    acc[qt][dt] *= alpha;
-                    const u32x4_t vv = {vf[dt][0][0], vf[dt][0][1], vf[dt][1][0], vf[dt][1][1]};
-                    acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pf,
-                                                                         acc[qt][dt], 0, 0, 0);
-                }
+            s_mfma(s_nxt);
+            read_v(sb, 4, 8);
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8_t pf = softmax(s_cur, t * FA_BK);
+            asm volatile("s_waitcnt lgkmcnt(0)" : FA_V_REGS : : "memory");
+            pv_mfma(pf);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- slab 1: its V fragments are the last LDS reads of this buffer
+            read_v(sb + 32 * FA_ROWB, 0, 8);
+            asm volatile("s_waitcnt lgkmcnt(0)" : FA_V_REGS : : "memory");
+            if (t + 1 < ntiles) {
+                // tile t+1 was issued a whole tile ago; after the barrier every wave is done with
+                // buffer t&1, which tile t+2 may then overwrite
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (t + 2 < ntiles) stage(t & 1, t + 2);
+                read_k(lds_addr(smem + ((t + 1) & 1) * FA_STAGE));
+                asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                s_mfma(s_cur);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            pf = softmax(s_nxt, t * FA_BK + 32);
+            pv_mfma(pf);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_s_barrier();  // everyone is done with buf[cur] before it is refilled
     }
+#undef FA_K_REGS
+#undef FA_V_REGS
 
-#pragma unroll
-    for (int qt = 0; qt < FA_QT; ++qt) {
-        float l = l_run[qt];
+    {
+        float l = l_run;
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
-        if (qi[qt] < lq) {
+        if (qi[0] < lq) {
             const float inv = l > 0.f ? 1.0f / l : 0.f;
-            bf16_t* orow = out + ((int64_t)(q0 + qi[qt]) * nh + head) * FA_HD;
+            bf16_t* orow = out + ((int64_t)(q0 + qi[0]) * nh + head) * FA_HD;
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
-                u32x2_t o = {pack2bf(acc[qt][dt][0] * inv, acc[qt][dt][1] * inv),
-                             pack2bf(acc[qt][dt][2] * inv, acc[qt][dt][3] * inv)};
+                u32x2_t o = {pack2bf(acc[dt][0] * inv, acc[dt][1] * inv),
+                             pack2bf(acc[dt][2] * inv, acc[dt][3] * inv)};
                 *reinterpret_cast<u32x2_t*>(orow + 16 * dt + 4 * g) = o;
             }
         }
@@ -275,13 +335,15 @@ extern "C" int glm_varlen_attn_prefill(const void* q, const void* k, const void*
         attr_set[paged] = true;
     }
     const dim3 grid((unsigned)((max_seqlen_q + FA_BQ - 1) / FA_BQ), (unsigned)nh, (unsigned)B);
+    // K/V ring + the block-table slice (paged only): two workgroups per CU need <= 80 KiB each
+    const size_t lds = 2 * FA_STAGE + (paged ? (size_t)bt_stride * 4 : 0);
     const float sl2 = scale * 1.4426950408889634f;
     if (paged)
-        hipLaunchKernelGGL((prefill_attn_kernel<true>), grid, dim3(256), FA_LDS, glm_s(stream), (const bf16_t*)q,
+        hipLaunchKernelGGL((prefill_attn_kernel<true>), grid, dim3(256), lds, glm_s(stream), (const bf16_t*)q,
                            (const bf16_t*)k, (const bf16_t*)v, cu_seqlens_q, cu_seqlens_k, block_tables,
                            bt_stride, (bf16_t*)out, nh, nkv, block_size, sl2);
     else
-        hipLaunchKernelGGL((prefill_attn_kernel<false>), grid, dim3(256), FA_LDS, glm_s(stream), (const bf16_t*)q,
+        hipLaunchKernelGGL((prefill_attn_kernel<false>), grid, dim3(256), lds, glm_s(stream), (const bf16_t*)q,
                            (const bf16_t*)k, (const bf16_t*)v, cu_seqlens_q, cu_seqlens_k, block_tables,
                            bt_stride, (bf16_t*)out, nh, nkv, block_size, sl2);
     GLM_CHECK_LAUNCH("glm_varlen_attn_prefill");

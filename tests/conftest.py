@@ -12,6 +12,16 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "timeout: per-test timeout (pytest-timeout)")
+    # the HIP library is built in-tree (git-ignored); build it when a fresh checkout lacks it —
+    # hipcc cross-compiles gfx950 without a GPU.  There is still no CPU fallback for the ops.
+    lib = os.path.join(PKG, "lib", "libglm4moe_hip.so")
+    if not os.path.exists(lib):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("glm4moe_build", os.path.join(PKG, "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build_lib(force=False, verbose=False)
 
 
 def pytest_collection_modifyitems(config, items):
