@@ -2,28 +2,40 @@
 // nanovllm/layers/attention.py:85-100 → flash_attn_varlen_func(causal=True[, block_table])).
 // gfx950 only, head_dim 128.
 //
-// Flash-style: the score matrix is never materialised.  A workgroup owns 64*FA_QT query rows of
-// one (sequence, query head); its 4 waves take 16*FA_QT rows each and walk the key tiles (64 keys) that the bottom-right-aligned causal mask leaves visible.  K/V
-// tiles are staged once per workgroup by LDS-DMA with the same source-side swizzles as the decode kernel (K: chunk ^ (key & 15) for
+// Flash-style: the score matrix is never materialised.  A workgroup owns 128 query rows of one
+// (sequence, query head); each of its 4 waves takes two 16-row query tiles and walks the 64-key tiles
+// that the bottom-right-aligned causal mask leaves visible.  K/V tiles are staged once per workgroup
+// by LDS-DMA with the same source-side swizzles as the decode kernel (K: chunk ^ (key & 15) for
 // ds_read_b128 row reads, V: chunk ^ ((key & 7) << 1) for ds_read_b64_tr_b16 transposed reads),
-// double-buffered.  Math per wave is the decode kernel's: S^T = K·Q^T with keys on the MFMA row
-// axis and the wave's 16 query rows on the lane axis, fp32 online softmax per lane column, then
+// double-buffered, one barrier per tile.  Math per wave is the decode kernel's: S^T = K·Q^T with keys
+// on the MFMA row axis and 16 query rows on the lane axis, fp32 online softmax per lane column, then
 // O^T += V^T·P^T straight from registers.
+//
+// What the loop is built around (ablation on MI355X, tools/ablate_prefill_attn.sh): the MFMAs and the
+// exp2 are hidden; LDS fragment reads, the staging traffic and plain VALU instruction count are what
+// cost time.  Hence: every K/V fragment read from LDS feeds two query tiles; LDS addresses are one
+// register per fragment plus immediates; the non-paged staging path is a scalar base plus constant
+// per-lane offsets; and the work is software-pipelined in (32-key slab, query tile) units — the S
+// MFMAs of unit u+1 are issued before the softmax of unit u.
 //
 // K/V come either from contiguous [Tk, nkv, hd] tensors or from the paged cache through
 // block_tables (prefix-cache hit, attention.py:86-87).
 #include "common.h"
 
+// timing-only ablations (results are wrong): 1 no exp, 2 no barrier, 4 no S MFMA, 8 no PV MFMA, 16 no LDS reads,
+// 32 no K/V staging after the first two tiles
+#ifndef GLM_FA_ABLATE
+#define GLM_FA_ABLATE 0
+#endif
+
 namespace {
 
 constexpr int FA_HD = 128, FA_ROWB = 256;
-constexpr int FA_QT = 1;                   // 16-row query tiles per wave (2 pushes the kernel past 256 registers:
-                                           // one wave per SIMD, 232 vs 366 TFLOP/s)
+constexpr int FA_QT = 2;                   // 16-row query tiles per wave
 constexpr int FA_BQ = 64 * FA_QT, FA_BK = 64;
 constexpr int FA_TILE = FA_BK * FA_ROWB;   // 16 KiB per K or V tile
 constexpr int FA_STAGE = 2 * FA_TILE;
 constexpr int FA_MAX_BT = 4096;
-constexpr int FA_LDS = 2 * FA_STAGE + FA_MAX_BT * 4;
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
@@ -49,18 +61,42 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(uintptr_t)(const lds_void_t*)p;
 }
 
-template <bool PAGED>
 // launch bound of 2 waves per SIMD caps the kernel at 256 registers, which makes hipcc pick the VGPR form of the
 // MFMAs: with the default (512) the accumulators live in AGPRs and every slab pays ~40 v_accvgpr copies
+template <bool PAGED>
 __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
     const int32_t* __restrict__ block_tables, int64_t bt_stride, bf16_t* __restrict__ out, int nh,
-    int nkv, int block_size, float scale_log2e) {
+    int nkv, int block_size, float scale_log2e, int nqblk, int nseq, int xcd_groups) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* bt_lds = reinterpret_cast<int*>(smem + 2 * FA_STAGE);
-    const int qblk = blockIdx.x, head = blockIdx.y;
-    const int64_t b = blockIdx.z;
+    // Work order.  Workgroups are handed to the 8 XCDs round-robin in linear-id order and, inside an XCD, to its
+    // shader engines the same way, so a causal grid with the query block as the fast index gives some engines only
+    // long workgroups and others only short ones (measured: CUs idle a third of the time).  Instead the linear id
+    // is decoded so that (a) all workgroups in flight have the same query block, longest first, (b) an XCD always
+    // serves the same (sequence, kv head) groups, whose K/V tiles then stay in its own L2.
+    int qblk, head;
+    int64_t b;
+    {
+        const int L = blockIdx.x;
+        const int hpg = nh / nkv;
+        if (xcd_groups > 0) {
+            const int xcd = L & 7, j = L >> 3;
+            const int per_q = xcd_groups * hpg;  // workgroups per query block on one XCD
+            const int sidx = j / per_q, r = j - sidx * per_q;
+            const int group = (r / hpg) * 8 + xcd;  // (sequence, kv head) pair
+            qblk = nqblk - 1 - sidx;
+            b = group / nkv;
+            head = (group % nkv) * hpg + r % hpg;
+        } else {
+            const int per_q = nh * nseq;
+            const int sidx = L / per_q, r = L - sidx * per_q;
+            qblk = nqblk - 1 - sidx;
+            b = r / nh;
+            head = r % nh;
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
@@ -99,68 +135,101 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
     for (int qt = 0; qt < FA_QT; ++qt)
         asm volatile("" : "+v"(qf[qt][0]), "+v"(qf[qt][1]), "+v"(qf[qt][2]), "+v"(qf[qt][3]));
 
-    // staging: wave w issues instructions i=0..3 for K and V; instruction covers tile rows
-    // (4w+i)*4 .. +3 (4 keys x 256 B); lane → row +(lane>>4), position lane&15
-    auto stage = [&](int buf, int t) {
-        char* kd = smem + buf * FA_STAGE + wid * 4 * 1024;
-        char* vd = kd + FA_TILE;
+    // staging: wave w issues instructions i=0..3 for K and V; instruction i covers tile rows
+    // (4w+i)*4 .. +3 (4 keys x 256 B); lane → row +(lane>>4), 16-byte position lane&15.
+    // Contiguous K/V: the source is a wave-uniform tile base plus a per-lane byte offset that is the same for
+    // every full tile (only the last, partial tile clamps rows), so a tile costs no vector address math.
+    const int64_t row_bytes = (int64_t)nkv * FA_ROWB;
+    unsigned soff_k[4], soff_v[4];
+    auto stage_offsets = [&](int t) {
         const int r4 = lane >> 4, pch = lane & 15;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = (wid * 4 + i) * 4 + r4;
-            int key = t * FA_BK + row;
-            key = key < lk ? key : lk - 1;  // masked keys re-read a valid row
-            int64_t tok;
-            if (PAGED) {
-                const int pb = bt_lds[key / block_size];
-                tok = (int64_t)pb * block_size + key % block_size;
-            } else {
-                tok = (int64_t)k0 + key;
+            const int rc = min(t * FA_BK + row, lk - 1) - t * FA_BK;  // masked keys re-read a valid row
+            soff_k[i] = (unsigned)(rc * (int)row_bytes) + ((pch ^ (row & 15)) << 4);
+            soff_v[i] = (unsigned)(rc * (int)row_bytes) + ((pch ^ ((row & 7) << 1)) << 4);
+        }
+    };
+    if (!PAGED) stage_offsets(0);
+    auto stage = [&](int buf, int t) {
+        char* kd = smem + buf * FA_STAGE + wid * 4 * 1024;
+        char* vd = kd + FA_TILE;
+        if (!PAGED) {
+            if ((t + 1) * FA_BK > lk) stage_offsets(t);  // uniform; last tile only
+            const int64_t tb = ((int64_t)(k0 + t * FA_BK) * nkv + kvh) * FA_ROWB;
+            const char* kt = reinterpret_cast<const char*>(k) + tb;
+            const char* vt = reinterpret_cast<const char*>(v) + tb;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                glds16(kt + soff_k[i], kd + i * 1024);
+                glds16(vt + soff_v[i], vd + i * 1024);
             }
-            const int64_t ro = (tok * nkv + kvh) * FA_HD;
-            glds16(k + ro + ((pch ^ (row & 15)) << 3), kd + i * 1024);
-            glds16(v + ro + ((pch ^ ((row & 7) << 1)) << 3), vd + i * 1024);
+        } else {
+            const int r4 = lane >> 4, pch = lane & 15;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (wid * 4 + i) * 4 + r4;
+                int key = t * FA_BK + row;
+                key = key < lk ? key : lk - 1;
+                const int pb = bt_lds[key / block_size];
+                const int64_t tok = (int64_t)pb * block_size + key % block_size;
+                const int64_t ro = (tok * nkv + kvh) * FA_HD;
+                glds16(k + ro + ((pch ^ (row & 15)) << 3), kd + i * 1024);
+                glds16(v + ro + ((pch ^ ((row & 7) << 1)) << 3), vd + i * 1024);
+            }
         }
     };
 
-    unsigned k_rel[4], v_rel[8];
+    // LDS fragment addresses of the CURRENT buffer: one register per fragment, slab / half-slab as immediates.
+    // They flip between the two buffers once per tile.
+    unsigned k_abs[4], v_abs[8];
     {
+        const unsigned base = lds_addr(smem);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) k_rel[ks] = c * FA_ROWB + (((4 * ks + g) ^ c) << 4);
+        for (int ks = 0; ks < 4; ++ks) k_abs[ks] = base + c * FA_ROWB + (((4 * ks + g) ^ c) << 4);
         const int qq = (lane >> 2) & 3, pp = lane & 3;
         const int row = 4 * g + qq;
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt)
-            v_rel[dt] = FA_TILE + row * FA_ROWB + (((2 * dt + (pp >> 1)) ^ ((row & 7) << 1)) << 4) + ((pp & 1) << 3);
+            v_abs[dt] = base + FA_TILE + row * FA_ROWB + (((2 * dt + (pp >> 1)) ^ ((row & 7) << 1)) << 4) +
+                        ((pp & 1) << 3);
     }
 
-    f32x4_t acc[8];
+    f32x4_t acc[FA_QT][8];
+    float m_run[FA_QT], l_run[FA_QT];
+    int jmax[FA_QT];  // last visible key of this lane's query row, per tile
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
-    const int jmax = qi[0] + off;                     // last visible key of this lane's query row
-    const int row_first = qbase + 16 * wid;           // first query row of the wave
+    for (int qt = 0; qt < FA_QT; ++qt) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[qt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        m_run[qt] = -INFINITY;
+        l_run[qt] = 0.f;
+        jmax[qt] = qi[qt] + off;
+    }
 
-    // The loop is software-pipelined inside the wave over 32-key slabs: the S MFMAs of slab i+1 are
-    // issued before the softmax VALU work of slab i, so the matrix pipe runs under the exp/max/convert
-    // instructions of the same wave; V fragments of slab i are fetched from LDS while that softmax
-    // runs.  One workgroup barrier per 64-key tile.
+#if GLM_FA_ABLATE & 16
+    u32x4_t kf[2][4] = {};
+    u32x2_t vf[8][2] = {};
+#else
     u32x4_t kf[2][4];
     u32x2_t vf[8][2];
-    auto read_k = [&](unsigned hb) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            lds_read_b128<0>(kf[0][ks], hb + k_rel[ks]);
-            lds_read_b128<4096>(kf[1][ks], hb + k_rel[ks]);
-        }
-    };
-    auto read_v = [&](unsigned hb, int dlo, int dhi) {
-#pragma unroll
-        for (int dt = dlo; dt < dhi; ++dt) {
-            lds_read_tr16_b64<0>(vf[dt][0], hb + v_rel[dt]);
-            lds_read_tr16_b64<4096>(vf[dt][1], hb + v_rel[dt]);
-        }
-    };
+#endif
+    // SLAB = 0/1: 32-key half of the tile (8 KiB apart); the second 16 keys of a slab are 4 KiB further
+#define FA_READ_K(SLAB)                                                     \
+    if (!(GLM_FA_ABLATE & 16)) {                                            \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                  \
+            lds_read_b128<(SLAB) * 8192>(kf[0][ks], k_abs[ks]);             \
+            lds_read_b128<(SLAB) * 8192 + 4096>(kf[1][ks], k_abs[ks]);      \
+        }                                                                   \
+    }
+#define FA_READ_V(SLAB)                                                     \
+    if (!(GLM_FA_ABLATE & 16)) {                                            \
+        _Pragma("unroll") for (int dt = 0; dt < 8; ++dt) {                  \
+            lds_read_tr16_b64<(SLAB) * 8192>(vf[dt][0], v_abs[dt]);         \
+            lds_read_tr16_b64<(SLAB) * 8192 + 4096>(vf[dt][1], v_abs[dt]);  \
+        }                                                                   \
+    }
 #define FA_K_REGS                                                                                          \
     "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]), "+v"(kf[1][0]), "+v"(kf[1][1]),       \
         "+v"(kf[1][2]), "+v"(kf[1][3])
@@ -168,21 +237,27 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
     "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]), "+v"(vf[2][0]), "+v"(vf[2][1]),       \
         "+v"(vf[3][0]), "+v"(vf[3][1]), "+v"(vf[4][0]), "+v"(vf[4][1]), "+v"(vf[5][0]), "+v"(vf[5][1]),   \
         "+v"(vf[6][0]), "+v"(vf[6][1]), "+v"(vf[7][0]), "+v"(vf[7][1])
-    auto s_mfma = [&](f32x4_t (&s)[2]) {
+    auto s_mfma = [&](f32x4_t (&s)[2], int qt) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             s[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (GLM_FA_ABLATE & 4) {
+                s[tt] = __builtin_bit_cast(f32x4_t, kf[tt][0]) + __builtin_bit_cast(f32x4_t, kf[tt][1]) +
+                        __builtin_bit_cast(f32x4_t, kf[tt][2]) + __builtin_bit_cast(f32x4_t, kf[tt][3]);
+                continue;
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
                 s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[tt][ks]),
-                                                               qf[0][ks], s[tt], 0, 0, 0);
+                                                               qf[qt][ks], s[tt], 0, 0, 0);
         }
     };
-    // online softmax of one slab (keys [kbase, kbase+32)); returns the bf16 P^T fragment and leaves acc
-    // rescaled.  The running maximum lives in the scaled (log2) domain: p = exp2(s*c - m).
-    auto softmax = [&](f32x4_t (&s)[2], int kbase) -> bf16x8_t {
+    // online softmax of one unit (keys [kbase, kbase+32) x query tile qt); returns the bf16 P^T fragment and
+    // leaves acc[qt] rescaled.  The running maximum lives in the scaled (log2) domain: p = exp2(s*c - m).
+    auto softmax = [&](f32x4_t (&s)[2], int kbase, int qt) -> bf16x8_t {
         // masking is only needed on slabs that touch the causal diagonal or the sequence end for this
-        // wave's rows: the test is wave-uniform and false for almost every slab
+        // query tile: the test is wave-uniform and false for almost every slab
+        const int row_first = qbase + (16 * FA_QT) * wid + 16 * qt;
         const bool need_mask = kbase + 31 > row_first + off || kbase + 31 >= lk;
         if (need_mask) {
 #pragma unroll
@@ -190,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = kbase + 4 * g + 16 * tt + r;
-                    if (j > jmax || j >= lk) s[tt][r] = -INFINITY;
+                    if (j > jmax[qt] || j >= lk) s[tt][r] = -INFINITY;
                 }
         }
         float mloc = vmax3(vmax3(vmax3(s[0][0], s[0][1], s[0][2]), s[0][3], s[1][0]), s[1][1], s[1][2]);
@@ -204,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
             mloc = vmax3(__uint_as_float(b2[0]), __uint_as_float(b2[1]), __uint_as_float(b2[1]));
         }
         const float ms = mloc * scale_log2e;
-        const float m_new = vmax3(m_run, ms, ms);
+        const float m_new = vmax3(m_run[qt], ms, ms);
         // a row with nothing visible yet keeps m_new = -inf: use 0 as the reference point so that
         // exp2(-inf - 0) = 0 and no NaN appears
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
@@ -214,32 +289,39 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(s[tt][r], scale_log2e, -m_use));
+                const float arg = fmaf(s[tt][r], scale_log2e, -m_use);
+                const float pv = (GLM_FA_ABLATE & 1) ? arg : __builtin_amdgcn_exp2f(arg);
                 psum += pv;
                 pf[4 * tt + r] = (__bf16)pv;
             }
         // rescale only when some row's maximum actually grew (wave-uniform; after the first few
         // tiles it rarely does)
         float alpha = 1.0f;
-        if (__any(m_new > m_run)) {
-            alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        if (__any(m_new > m_run[qt])) {
+            alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_use);
 #pragma unroll
-            for (int dt = 0; dt < 8; ++dt) acc[dt] *= alpha;
+            for (int dt = 0; dt < 8; ++dt) acc[qt][dt] *= alpha;
         }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
+        l_run[qt] = l_run[qt] * alpha + psum;
+        m_run[qt] = m_new;
         return pf;
     };
-    auto pv_mfma = [&](bf16x8_t pf) {
+    auto pv_mfma = [&](bf16x8_t pf, int qt) {
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) {
             const u32x4_t vv = {vf[dt][0][0], vf[dt][0][1], vf[dt][1][0], vf[dt][1][1]};
-            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pf, acc[dt], 0, 0, 0);
+            if (GLM_FA_ABLATE & 8) {
+                acc[qt][dt] += __builtin_bit_cast(f32x4_t, vv) * __builtin_bit_cast(f32x4_t, pf);
+                continue;
+            }
+            acc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pf,
+                                                                 acc[qt][dt], 0, 0, 0);
         }
     };
 
     if (ntiles > 0) {
-        f32x4_t s_cur[2], s_nxt[2];
+        static_assert(FA_QT == 2, "the unit schedule below is written for two query tiles per wave");
+        f32x4_t sa[2], sb[2];  // S of the unit being softmaxed / of the next unit
         stage(0, 0);
         if (ntiles > 1) {
             stage(1, 1);
@@ -248,57 +330,79 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        read_k(lds_addr(smem));
+        FA_READ_K(0);
         asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
-        s_mfma(s_cur);
+        s_mfma(sa, 0);
         for (int t = 0; t < ntiles; ++t) {
-            const unsigned sb = lds_addr(smem + (t & 1) * FA_STAGE);
-            // ---- slab 0 of tile t: S of slab 1 goes to the matrix pipe first
-            read_k(sb + 32 * FA_ROWB);
-            read_v(sb, 0, 4);  // the LDS counter holds 15: K (8 reads) + half of V (8 reads) in flight
-            asm volatile("s_waitcnt lgkmcnt(8)" : FA_K_REGS : : "memory");
+            const int kb0 = t * FA_BK;
+            bf16x8_t pf;
+            // ---- unit (slab 0, q0): S(slab 0, q1) goes to the matrix pipe first, then K of slab 1 and V of
+            // slab 0 are fetched while the softmax runs
+            s_mfma(sb, 1);
             __builtin_amdgcn_sched_barrier(0);
-            s_mfma(s_nxt);
-            read_v(sb, 4, 8);
+            FA_READ_V(0);
+            FA_READ_K(1);
+            pf = softmax(sa, kb0, 0);
+            asm volatile("s_waitcnt lgkmcnt(8)" : FA_V_REGS : : "memory");  // V landed, K may be in flight
+            pv_mfma(pf, 0);
             __builtin_amdgcn_sched_barrier(0);
-            bf16x8_t pf = softmax(s_cur, t * FA_BK);
+            // ---- unit (slab 0, q1)
+            asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
+            s_mfma(sa, 0);  // S(slab 1, q0)
+            __builtin_amdgcn_sched_barrier(0);
+            pf = softmax(sb, kb0, 1);
+            pv_mfma(pf, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- unit (slab 1, q0): V of slab 1 is the last LDS read of this buffer
+            s_mfma(sb, 1);  // S(slab 1, q1)
+            __builtin_amdgcn_sched_barrier(0);
+            FA_READ_V(1);
             asm volatile("s_waitcnt lgkmcnt(0)" : FA_V_REGS : : "memory");
-            pv_mfma(pf);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- slab 1: its V fragments are the last LDS reads of this buffer
-            read_v(sb + 32 * FA_ROWB, 0, 8);
-            asm volatile("s_waitcnt lgkmcnt(0)" : FA_V_REGS : : "memory");
-            if (t + 1 < ntiles) {
-                // tile t+1 was issued a whole tile ago; after the barrier every wave is done with
-                // buffer t&1, which tile t+2 may then overwrite
+            const bool more = t + 1 < ntiles;
+            if (more) {
+                // tile t+1 was issued a whole tile ago; after the barrier every wave is done with this
+                // buffer, which tile t+2 may then overwrite
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (t + 2 < ntiles) stage(t & 1, t + 2);
-                read_k(lds_addr(smem + ((t + 1) & 1) * FA_STAGE));
+                if (!(GLM_FA_ABLATE & 2)) __builtin_amdgcn_s_barrier();
+                if (t + 2 < ntiles && !(GLM_FA_ABLATE & 32)) stage(t & 1, t + 2);
+                const int flip = (t & 1) ? -FA_STAGE : FA_STAGE;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) k_abs[ks] += flip;
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) v_abs[dt] += flip;
+                FA_READ_K(0);
+            }
+            pf = softmax(sa, kb0 + 32, 0);
+            pv_mfma(pf, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- unit (slab 1, q1)
+            if (more) {
                 asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                s_mfma(s_cur);
+                s_mfma(sa, 0);  // S(tile t+1 slab 0, q0)
                 __builtin_amdgcn_sched_barrier(0);
             }
-            pf = softmax(s_nxt, t * FA_BK + 32);
-            pv_mfma(pf);
+            pf = softmax(sb, kb0 + 32, 1);
+            pv_mfma(pf, 1);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+#undef FA_READ_K
+#undef FA_READ_V
 #undef FA_K_REGS
 #undef FA_V_REGS
 
-    {
-        float l = l_run;
+#pragma unroll
+    for (int qt = 0; qt < FA_QT; ++qt) {
+        float l = l_run[qt];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
-        if (qi[0] < lq) {
+        if (qi[qt] < lq) {
             const float inv = l > 0.f ? 1.0f / l : 0.f;
-            bf16_t* orow = out + ((int64_t)(q0 + qi[0]) * nh + head) * FA_HD;
+            bf16_t* orow = out + ((int64_t)(q0 + qi[qt]) * nh + head) * FA_HD;
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
-                u32x2_t o = {pack2bf(acc[dt][0] * inv, acc[dt][1] * inv),
-                             pack2bf(acc[dt][2] * inv, acc[dt][3] * inv)};
+                u32x2_t o = {pack2bf(acc[qt][dt][0] * inv, acc[qt][dt][1] * inv),
+                             pack2bf(acc[qt][dt][2] * inv, acc[qt][dt][3] * inv)};
                 *reinterpret_cast<u32x2_t*>(orow + 16 * dt + 4 * g) = o;
             }
         }
@@ -327,25 +431,41 @@ extern "C" int glm_varlen_attn_prefill(const void* q, const void* k, const void*
     const int paged = block_tables != nullptr;
     if (!attr_set[paged]) {
         const void* fn = paged ? (const void*)prefill_attn_kernel<true> : (const void*)prefill_attn_kernel<false>;
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FA_STAGE + FA_MAX_BT * 4);
         if (e != hipSuccess) {
             glm_set_error("glm_varlen_attn_prefill: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return GLM_ERR_LAUNCH;
         }
         attr_set[paged] = true;
     }
-    const dim3 grid((unsigned)((max_seqlen_q + FA_BQ - 1) / FA_BQ), (unsigned)nh, (unsigned)B);
+    const int nqblk = (max_seqlen_q + FA_BQ - 1) / FA_BQ;
+    const int64_t total = (int64_t)nqblk * nh * B;
+    GLM_CHECK_ARG(total < (int64_t)1 << 31, GLM_ERR_UNSUPPORTED, "glm_varlen_attn_prefill: grid too large");
+    // (sequence, kv head) groups per XCD when they divide evenly over the 8 XCDs, else 0 (plain longest-first order)
+    const int xcd_groups = (B * nkv) % 8 == 0 ? (int)(B * nkv / 8) : 0;
+    const dim3 grid((unsigned)total);
     // K/V ring + the block-table slice (paged only): two workgroups per CU need <= 80 KiB each
     const size_t lds = 2 * FA_STAGE + (paged ? (size_t)bt_stride * 4 : 0);
     const float sl2 = scale * 1.4426950408889634f;
     if (paged)
         hipLaunchKernelGGL((prefill_attn_kernel<true>), grid, dim3(256), lds, glm_s(stream), (const bf16_t*)q,
                            (const bf16_t*)k, (const bf16_t*)v, cu_seqlens_q, cu_seqlens_k, block_tables,
-                           bt_stride, (bf16_t*)out, nh, nkv, block_size, sl2);
+                           bt_stride, (bf16_t*)out, nh, nkv, block_size, sl2, nqblk, (int)B, xcd_groups);
     else
         hipLaunchKernelGGL((prefill_attn_kernel<false>), grid, dim3(256), lds, glm_s(stream), (const bf16_t*)q,
                            (const bf16_t*)k, (const bf16_t*)v, cu_seqlens_q, cu_seqlens_k, block_tables,
-                           bt_stride, (bf16_t*)out, nh, nkv, block_size, sl2);
+                           bt_stride, (bf16_t*)out, nh, nkv, block_size, sl2, nqblk, (int)B, xcd_groups);
     GLM_CHECK_LAUNCH("glm_varlen_attn_prefill");
     return GLM_OK;
+}
+
+// debug aid (not part of the C-ABI in include/glm4moe_hip.h): resident workgroups per CU the runtime
+// predicts for the contiguous-K/V kernel with `lds_bytes` of dynamic LDS
+extern "C" int glm_debug_prefill_attn_occupancy(int lds_bytes) {
+    int nb = -1;
+    (void)hipFuncSetAttribute((const void*)prefill_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              2 * FA_STAGE + FA_MAX_BT * 4);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, prefill_attn_kernel<false>, 256,
+                                                                (size_t)lds_bytes);
+    return e == hipSuccess ? nb : -(int)e;
 }
