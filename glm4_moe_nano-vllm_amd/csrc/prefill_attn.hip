@@ -27,12 +27,21 @@
 #ifndef GLM_FA_ABLATE
 #define GLM_FA_ABLATE 0
 #endif
+#ifndef GLM_FA_PRIO
+#define GLM_FA_PRIO 0
+#endif
+#ifndef GLM_FA_NW
+#define GLM_FA_NW 4
+#endif
 
 namespace {
 
 constexpr int FA_HD = 128, FA_ROWB = 256;
 constexpr int FA_QT = 2;                   // 16-row query tiles per wave
-constexpr int FA_BQ = 64 * FA_QT, FA_BK = 64;
+constexpr int FA_NW = GLM_FA_NW;           // waves per workgroup
+constexpr int FA_NT = 64 * FA_NW;
+constexpr int FA_BQ = 16 * FA_QT * FA_NW, FA_BK = 64;
+constexpr int FA_PPW = 16 / FA_NW;         // 1 KiB staging pieces per wave, for K and for V
 constexpr int FA_TILE = FA_BK * FA_ROWB;   // 16 KiB per K or V tile
 constexpr int FA_STAGE = 2 * FA_TILE;
 constexpr int FA_MAX_BT = 4096;
@@ -51,12 +60,6 @@ template <int OFF>
 __device__ __forceinline__ void lds_read_tr16_b64(u32x2_t& dst, unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
 }
-// v_max3_f32 without the quieting v_max x,x that fmaxf() gets for each MFMA output
-__device__ __forceinline__ float vmax3(float a, float b, float c) {
-    float d;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(uintptr_t)(const lds_void_t*)p;
 }
@@ -64,7 +67,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 // launch bound of 2 waves per SIMD caps the kernel at 256 registers, which makes hipcc pick the VGPR form of the
 // MFMAs: with the default (512) the accumulators live in AGPRs and every slab pays ~40 v_accvgpr copies
 template <bool PAGED>
-__global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
+__global__ __launch_bounds__(FA_NT, 2) void prefill_attn_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
     const int32_t* __restrict__ block_tables, int64_t bt_stride, bf16_t* __restrict__ out, int nh,
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
 
     if (PAGED) {
         const int nblk = (kend + block_size - 1) / block_size;
-        for (int i = tid; i < nblk; i += 256) bt_lds[i] = block_tables[b * bt_stride + i];
+        for (int i = tid; i < nblk; i += FA_NT) bt_lds[i] = block_tables[b * bt_stride + i];
     }
 
     // Q^T fragments: lane (c,g), tile qt = query row qbase + 32*wid + 16*qt + c, k-step ks → hd [32ks+8g, +8)
@@ -135,50 +138,58 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
     for (int qt = 0; qt < FA_QT; ++qt)
         asm volatile("" : "+v"(qf[qt][0]), "+v"(qf[qt][1]), "+v"(qf[qt][2]), "+v"(qf[qt][3]));
 
-    // staging: wave w issues instructions i=0..3 for K and V; instruction i covers tile rows
-    // (4w+i)*4 .. +3 (4 keys x 256 B); lane → row +(lane>>4), 16-byte position lane&15.
+    // staging: wave w issues FA_PPW instructions for K and for V; instruction i covers tile rows
+    // (FA_PPW*w+i)*4 .. +3 (4 keys x 256 B); lane → row +(lane>>4), 16-byte position lane&15.
     // Contiguous K/V: the source is a wave-uniform tile base plus a per-lane byte offset that is the same for
     // every full tile (only the last, partial tile clamps rows), so a tile costs no vector address math.
     const int64_t row_bytes = (int64_t)nkv * FA_ROWB;
-    unsigned soff_k[4], soff_v[4];
+    unsigned soff_k[FA_PPW], soff_v[FA_PPW];
     auto stage_offsets = [&](int t) {
         const int r4 = lane >> 4, pch = lane & 15;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (wid * 4 + i) * 4 + r4;
+        for (int i = 0; i < FA_PPW; ++i) {
+            const int row = (wid * FA_PPW + i) * 4 + r4;
             const int rc = min(t * FA_BK + row, lk - 1) - t * FA_BK;  // masked keys re-read a valid row
             soff_k[i] = (unsigned)(rc * (int)row_bytes) + ((pch ^ (row & 15)) << 4);
             soff_v[i] = (unsigned)(rc * (int)row_bytes) + ((pch ^ ((row & 7) << 1)) << 4);
         }
     };
     if (!PAGED) stage_offsets(0);
-    auto stage = [&](int buf, int t) {
-        char* kd = smem + buf * FA_STAGE + wid * 4 * 1024;
+    // one K piece and one V piece (1 KiB each) of tile t; pieces are spread over the loop's softmax phases, where
+    // an LDS-DMA issue is cheapest (back to back after the barrier they cost ~115 cycles apiece)
+    auto stage_piece = [&](int buf, int t, int i) {
+        char* kd = smem + buf * FA_STAGE + (wid * FA_PPW + i) * 1024;
         char* vd = kd + FA_TILE;
+        if (GLM_FA_ABLATE & 32) return;
         if (!PAGED) {
-            if ((t + 1) * FA_BK > lk) stage_offsets(t);  // uniform; last tile only
+            if (i == 0 && (t + 1) * FA_BK > lk) stage_offsets(t);  // uniform; last tile only
             const int64_t tb = ((int64_t)(k0 + t * FA_BK) * nkv + kvh) * FA_ROWB;
-            const char* kt = reinterpret_cast<const char*>(k) + tb;
-            const char* vt = reinterpret_cast<const char*>(v) + tb;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                glds16(kt + soff_k[i], kd + i * 1024);
-                glds16(vt + soff_v[i], vd + i * 1024);
-            }
+            glds16(reinterpret_cast<const char*>(k) + tb + soff_k[i], kd);
+            glds16(reinterpret_cast<const char*>(v) + tb + soff_v[i], vd);
         } else {
             const int r4 = lane >> 4, pch = lane & 15;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = (wid * 4 + i) * 4 + r4;
-                int key = t * FA_BK + row;
-                key = key < lk ? key : lk - 1;
-                const int pb = bt_lds[key / block_size];
-                const int64_t tok = (int64_t)pb * block_size + key % block_size;
-                const int64_t ro = (tok * nkv + kvh) * FA_HD;
-                glds16(k + ro + ((pch ^ (row & 15)) << 3), kd + i * 1024);
-                glds16(v + ro + ((pch ^ ((row & 7) << 1)) << 3), vd + i * 1024);
-            }
+            const int row = (wid * FA_PPW + i) * 4 + r4;
+            int key = t * FA_BK + row;
+            key = key < lk ? key : lk - 1;
+            const int pb = bt_lds[key / block_size];
+            const int64_t tok = (int64_t)pb * block_size + key % block_size;
+            const int64_t ro = (tok * nkv + kvh) * FA_HD;
+            glds16(k + ro + ((pch ^ (row & 15)) << 3), kd);
+            glds16(v + ro + ((pch ^ ((row & 7) << 1)) << 3), vd);
         }
+    };
+    auto stage = [&](int buf, int t) {
+#pragma unroll
+        for (int i = 0; i < FA_PPW; ++i) stage_piece(buf, t, i);
+    };
+    // piece i of a tile is issued in slot i: slots 0,1 = units 3,4 of the tile two before it (right after the
+    // barrier that frees its buffer), slots 2,3 = units 1,2 of the tile before it
+    constexpr int FA_SLOTS = FA_PPW < 4 ? FA_PPW : 4;
+    constexpr int FA_PPS = FA_PPW / FA_SLOTS;  // pieces per slot
+    auto stage_slot = [&](int buf, int t, int slot) {
+        if (slot >= FA_SLOTS) return;
+#pragma unroll
+        for (int i = 0; i < FA_PPS; ++i) stage_piece(buf, t, slot * FA_PPS + i);
     };
 
     // LDS fragment addresses of the CURRENT buffer: one register per fragment, slab / half-slab as immediates.
@@ -238,6 +249,9 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
         "+v"(vf[3][0]), "+v"(vf[3][1]), "+v"(vf[4][0]), "+v"(vf[4][1]), "+v"(vf[5][0]), "+v"(vf[5][1]),   \
         "+v"(vf[6][0]), "+v"(vf[6][1]), "+v"(vf[7][0]), "+v"(vf[7][1])
     auto s_mfma = [&](f32x4_t (&s)[2], int qt) {
+#if GLM_FA_PRIO
+        __builtin_amdgcn_s_setprio(GLM_FA_PRIO);
+#endif
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             s[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -251,6 +265,9 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
                 s[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[tt][ks]),
                                                                qf[qt][ks], s[tt], 0, 0, 0);
         }
+#if GLM_FA_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
     // online softmax of one unit (keys [kbase, kbase+32) x query tile qt); returns the bf16 P^T fragment and
     // leaves acc[qt] rescaled.  The running maximum lives in the scaled (log2) domain: p = exp2(s*c - m).
@@ -268,21 +285,30 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
                     if (j > jmax[qt] || j >= lk) s[tt][r] = -INFINITY;
                 }
         }
-        float mloc = vmax3(vmax3(vmax3(s[0][0], s[0][1], s[0][2]), s[0][3], s[1][0]), s[1][1], s[1][2]);
-        mloc = vmax3(mloc, s[1][3], s[1][3]);
-        {   // max over the four 16-lane groups that share a query column: VALU lane swaps, no LDS trip
-            const unsigned u = __float_as_uint(mloc);
-            const u32x2_t a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-            mloc = vmax3(__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(a[1]));
-            const unsigned w = __float_as_uint(mloc);
-            const u32x2_t b2 = __builtin_amdgcn_permlane32_swap(w, w, false, false);
-            mloc = vmax3(__uint_as_float(b2[0]), __uint_as_float(b2[1]), __uint_as_float(b2[1]));
-        }
+        // row maximum over this lane's 8 keys, then over the four 16-lane groups that share a query column
+        // (VALU lane swaps, no LDS trip).  One asm block: hipcc pads every separate asm VALU op with an s_nop.
+        float mloc, mtmp;
+        asm("v_max3_f32 %0, %2, %3, %4\n\t"
+            "v_max3_f32 %0, %0, %5, %6\n\t"
+            "v_max3_f32 %0, %0, %7, %8\n\t"
+            "v_max_f32 %0, %0, %9\n\t"
+            "v_mov_b32 %1, %0\n\t"
+            "s_nop 1\n\t"
+            "v_permlane16_swap_b32 %0, %1\n\t"
+            "v_max_f32 %0, %0, %1\n\t"
+            "v_mov_b32 %1, %0\n\t"
+            "s_nop 1\n\t"
+            "v_permlane32_swap_b32 %0, %1\n\t"
+            "v_max_f32 %0, %0, %1"
+            : "=&v"(mloc), "=&v"(mtmp)
+            : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][3]), "v"(s[1][0]), "v"(s[1][1]), "v"(s[1][2]),
+              "v"(s[1][3]));
         const float ms = mloc * scale_log2e;
-        const float m_new = vmax3(m_run[qt], ms, ms);
-        // a row with nothing visible yet keeps m_new = -inf: use 0 as the reference point so that
-        // exp2(-inf - 0) = 0 and no NaN appears
-        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        const float m_new = ms > m_run[qt] ? ms : m_run[qt];  // neither side is NaN-quieted: v_cmp + v_cndmask
+        // a row with nothing visible yet keeps m_new = -inf (only possible on a masked slab): use 0 as the
+        // reference point there so that exp2(-inf - 0) = 0 and no NaN appears
+        float m_use = m_new;
+        if (need_mask) m_use = m_new == -INFINITY ? 0.f : m_new;
         float psum = 0.f;
         bf16x8_t pf;
 #pragma unroll
@@ -319,13 +345,17 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
         }
     };
 
+    // consume the kernel-argument scalars here: otherwise the wait for their s_load lands at the first use inside
+    // the loop as an lgkmcnt(0), which also drains every LDS read that was meant to overlap the softmax
+    asm volatile("" ::"s"(scale_log2e), "s"(lk), "s"(off));
     if (ntiles > 0) {
         static_assert(FA_QT == 2, "the unit schedule below is written for two query tiles per wave");
         f32x4_t sa[2], sb[2];  // S of the unit being softmaxed / of the next unit
         stage(0, 0);
         if (ntiles > 1) {
             stage(1, 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (FA_PPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -333,28 +363,37 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
         FA_READ_K(0);
         asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
         s_mfma(sa, 0);
+        // a unit whose 32 keys are all past the causal diagonal of its 16 query rows (or past the sequence end)
+        // is skipped; wave-uniform.  Only the last tiles of a workgroup have such units.
+        auto live = [&](int kbase, int qt) -> bool {
+            return kbase <= qbase + (16 * FA_QT) * wid + 16 * qt + 15 + off && kbase < lk;
+        };
         for (int t = 0; t < ntiles; ++t) {
             const int kb0 = t * FA_BK;
             bf16x8_t pf;
             // ---- unit (slab 0, q0): S(slab 0, q1) goes to the matrix pipe first, then K of slab 1 and V of
             // slab 0 are fetched while the softmax runs
-            s_mfma(sb, 1);
+            if (live(kb0, 1)) s_mfma(sb, 1);
             __builtin_amdgcn_sched_barrier(0);
             FA_READ_V(0);
             FA_READ_K(1);
-            pf = softmax(sa, kb0, 0);
+            if (t >= 1 && t + 1 < ntiles) stage_slot((t + 1) & 1, t + 1, 2);
+            if (live(kb0, 0)) pf = softmax(sa, kb0, 0);
             asm volatile("s_waitcnt lgkmcnt(8)" : FA_V_REGS : : "memory");  // V landed, K may be in flight
-            pv_mfma(pf, 0);
+            if (live(kb0, 0)) pv_mfma(pf, 0);
             __builtin_amdgcn_sched_barrier(0);
             // ---- unit (slab 0, q1)
             asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
-            s_mfma(sa, 0);  // S(slab 1, q0)
+            if (live(kb0 + 32, 0)) s_mfma(sa, 0);  // S(slab 1, q0)
             __builtin_amdgcn_sched_barrier(0);
-            pf = softmax(sb, kb0, 1);
-            pv_mfma(pf, 1);
+            if (t >= 1 && t + 1 < ntiles) stage_slot((t + 1) & 1, t + 1, 3);
+            if (live(kb0, 1)) {
+                pf = softmax(sb, kb0, 1);
+                pv_mfma(pf, 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
             // ---- unit (slab 1, q0): V of slab 1 is the last LDS read of this buffer
-            s_mfma(sb, 1);  // S(slab 1, q1)
+            if (live(kb0 + 32, 1)) s_mfma(sb, 1);  // S(slab 1, q1)
             __builtin_amdgcn_sched_barrier(0);
             FA_READ_V(1);
             asm volatile("s_waitcnt lgkmcnt(0)" : FA_V_REGS : : "memory");
@@ -364,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
                 // buffer, which tile t+2 may then overwrite
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (!(GLM_FA_ABLATE & 2)) __builtin_amdgcn_s_barrier();
-                if (t + 2 < ntiles && !(GLM_FA_ABLATE & 32)) stage(t & 1, t + 2);
+                if (t + 2 < ntiles) stage_slot(t & 1, t + 2, 0);
                 const int flip = (t & 1) ? -FA_STAGE : FA_STAGE;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) k_abs[ks] += flip;
@@ -372,17 +411,22 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
                 for (int dt = 0; dt < 8; ++dt) v_abs[dt] += flip;
                 FA_READ_K(0);
             }
-            pf = softmax(sa, kb0 + 32, 0);
-            pv_mfma(pf, 0);
+            if (live(kb0 + 32, 0)) {
+                pf = softmax(sa, kb0 + 32, 0);
+                pv_mfma(pf, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             // ---- unit (slab 1, q1)
             if (more) {
                 asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
-                s_mfma(sa, 0);  // S(tile t+1 slab 0, q0)
+                if (live(kb0 + FA_BK, 0)) s_mfma(sa, 0);  // S(tile t+1 slab 0, q0)
                 __builtin_amdgcn_sched_barrier(0);
+                if (t + 2 < ntiles) stage_slot(t & 1, t + 2, 1);
             }
-            pf = softmax(sb, kb0 + 32, 1);
-            pv_mfma(pf, 1);
+            if (live(kb0 + 32, 1)) {
+                pf = softmax(sb, kb0 + 32, 1);
+                pv_mfma(pf, 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -448,11 +492,11 @@ extern "C" int glm_varlen_attn_prefill(const void* q, const void* k, const void*
     const size_t lds = 2 * FA_STAGE + (paged ? (size_t)bt_stride * 4 : 0);
     const float sl2 = scale * 1.4426950408889634f;
     if (paged)
-        hipLaunchKernelGGL((prefill_attn_kernel<true>), grid, dim3(256), lds, glm_s(stream), (const bf16_t*)q,
+        hipLaunchKernelGGL((prefill_attn_kernel<true>), grid, dim3(FA_NT), lds, glm_s(stream), (const bf16_t*)q,
                            (const bf16_t*)k, (const bf16_t*)v, cu_seqlens_q, cu_seqlens_k, block_tables,
                            bt_stride, (bf16_t*)out, nh, nkv, block_size, sl2, nqblk, (int)B, xcd_groups);
     else
-        hipLaunchKernelGGL((prefill_attn_kernel<false>), grid, dim3(256), lds, glm_s(stream), (const bf16_t*)q,
+        hipLaunchKernelGGL((prefill_attn_kernel<false>), grid, dim3(FA_NT), lds, glm_s(stream), (const bf16_t*)q,
                            (const bf16_t*)k, (const bf16_t*)v, cu_seqlens_q, cu_seqlens_k, block_tables,
                            bt_stride, (bf16_t*)out, nh, nkv, block_size, sl2, nqblk, (int)B, xcd_groups);
     GLM_CHECK_LAUNCH("glm_varlen_attn_prefill");
@@ -465,7 +509,7 @@ extern "C" int glm_debug_prefill_attn_occupancy(int lds_bytes) {
     int nb = -1;
     (void)hipFuncSetAttribute((const void*)prefill_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               2 * FA_STAGE + FA_MAX_BT * 4);
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, prefill_attn_kernel<false>, 256,
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, prefill_attn_kernel<false>, FA_NT,
                                                                 (size_t)lds_bytes);
     return e == hipSuccess ? nb : -(int)e;
 }

@@ -412,7 +412,10 @@ def test_moe_block_large_t(ops, T, E, k, H, I):
 
 @pytest.mark.parametrize("lens_q,lens_k,nh,nkv,paged", [
     ([21, 16], [21, 16], 4, 2, False), ([64], [64], 2, 1, False), ([65, 1, 200], [65, 1, 200], 12, 2, False),
-    ([300], [300], 24, 2, False), ([5, 40], [300, 296], 4, 2, True), ([130], [513], 8, 8, True)])
+    ([300], [300], 24, 2, False), ([5, 40], [300, 296], 4, 2, True), ([130], [513], 8, 8, True),
+    # (sequences x kv heads) divisible by 8: the XCD-grouped workgroup order; several query blocks per sequence
+    ([300, 17, 513, 64], [300, 17, 513, 64], 16, 4, False), ([700, 260], [700, 260], 8, 4, False),
+    ([100, 50], [612, 306], 16, 4, True), ([1025], [1025], 12, 1, False)])
 def test_varlen_attn_prefill(ops, lens_q, lens_k, nh, nkv, paged):
     g = torch.Generator().manual_seed(sum(lens_k) + nh)
     hd, bs = 128, 256
