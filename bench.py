@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=20)
+    ap.add_argument("--graph-body-only", action="store_true",
+                    help="debug: at 1 GPU, capture only the layer stack and run the lm_head eagerly (the TP>1 arrangement)")
     ap.add_argument("--fp8-experts", action="store_true",
                     help="stream the experts as OCP fp8 e4m3 (weight-only, N4 / BASELINE config 5 flavour); "
                          "the default bf16 run is the one comparable with the reference")
@@ -127,23 +129,54 @@ def main():
     set_context(False, slot_mapping=slot_mapping, context_lens=context_lens, block_tables=block_tables)
     out_tokens = torch.zeros(B, dtype=torch.int64, device=dev)
 
+    hidden = {}
+
     @torch.inference_mode()
-    def step():
-        h = model(input_ids, positions)
-        logits = model.compute_logits(h)
+    def body():
+        hidden["h"] = model(input_ids, positions)
+
+    @torch.inference_mode()
+    def head():
+        logits = model.compute_logits(hidden["h"])
         if logits is not None:
             out_tokens.copy_(torch.argmax(logits, dim=-1))
 
-    # ---- warm-up (also sets kernel attributes, sizes workspaces), optional HIP-graph capture ----
+    def step():
+        body()
+        head()
+
+    # ---- warm-up (also sets kernel attributes, sizes workspaces, brings up the RCCL communicator), then
+    # HIP-graph capture.  TP=1: the whole step is one graph.  TP>1: the layer stack with its RCCL all-reduces is
+    # captured (rehearsed on one GPU by tools/tp_graph_rehearsal.py; an eager TP step needs ~0.19 ms of host time
+    # per layer, more than its GPU time at TP>=4); the lm_head gather stays eager.  Ranks agree on the outcome,
+    # and any failure falls back to eager on every rank.
     step()
     torch.cuda.synchronize()
-    use_graph = (not args.no_graph) and world == 1
-    graph = None
+    use_graph = not args.no_graph
+    whole = world == 1 and not args.graph_body_only
+    graph_note = None
     if use_graph:
+        ok = 1
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step()
+        try:
+            with torch.cuda.graph(graph):
+                if whole:
+                    step()
+                else:
+                    body()
+        except Exception as e:  # noqa: BLE001 - report and fall back
+            ok, graph_note = 0, repr(e)[:200]
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        use_graph = bool(ok)
+    if use_graph and whole:
         run = graph.replay
+    elif use_graph:
+        def run():
+            graph.replay()
+            head()
     else:
         run = step
     for _ in range(args.warmup):
@@ -188,7 +221,7 @@ def main():
             "config": {"workload": f"GLM-4-MoE Air-64E decode bs={B} ctx={ctx} L={L} (layer0 dense), "
                                    f"random-init bf16, paged KV block 256, greedy",
                        "global_batch": B, "seq_len": ctx, "layers": L,
-                       "parallelism": f"tp{world}", "hip_graph": bool(use_graph),
+                       "parallelism": f"tp{world}", "hip_graph": bool(use_graph), "hip_graph_note": graph_note,
                        "ms_per_layer": round(ms_per_step / L, 4), "model_build_s": round(t_build, 1)},
             "roofline": dom,
             "kernels": kernels,
