@@ -103,62 +103,87 @@ __device__ __forceinline__ void dma_wait_leave(int tiles) {
     else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * DPW) : "memory");
 }
 
+// Persistent: one workgroup per CU walks its XCD's contiguous run of tiles with a stride of (workgroups per XCD).
+// Between two tiles the next tile's first ring stages are put in flight BEFORE the finished tile's epilogue, so the
+// ring-fill latency and the workgroup relaunch (~6 % of a 256x256x1408 tile) hide behind the epilogue's stores.
 template <int MODE, class C>
-__global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, int n_tiles, int total_wg) {
+__global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, int n_tiles, int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sh = reinterpret_cast<int*>(smem + C::NSTAGE * C::STAGE);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wid & 3, wm = wid >> 2;
     const int c = lane & 15, g4 = lane >> 4;
-
-    // XCD-aware remap (bijective for any grid size): blocks with equal id%8 share an XCD
-    int bid = blockIdx.x;
-    {
-        const int q = total_wg >> 3, r = total_wg & 7, x = bid & 7, i = bid >> 3;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-    }
-    const int band = bid / (LM_BAND * n_tiles);
-    const int rem = bid % (LM_BAND * n_tiles);
-    const int ntile = rem / LM_BAND;
-    const int combo = band * LM_BAND + rem % LM_BAND;
-    glm_locate_block(p.offs, p.G, p.R, C::BM, combo, sh);
-    __syncthreads();
-    const int grp = sh[0];
-    if (grp < 0) return;
-    const int m0 = sh[1], mcnt = sh[2];
     const int K = p.K;
     const int nk = (K + C::BK - 1) / C::BK;
+
+    // XCD-aware tile list (bijective for any tile count): workgroups with equal id%8 share an XCD and get one
+    // contiguous run of the band-ordered tile list
+    int chunk_base, chunk_len;
+    {
+        const int q = total_tiles >> 3, r = total_tiles & 7, x = blockIdx.x & 7;
+        chunk_base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        chunk_len = q + (x < r ? 1 : 0);
+    }
+    const int pstep = gridDim.x >> 3;  // host launches a multiple of 8 workgroups
+    int pos = blockIdx.x >> 3;
+
+    // tile state: *_c = tile being computed / stored, plain = tile whose operands are being staged
+    int grp = -1, m0 = 0, mcnt = 0, ntile = 0;
+    // next valid tile at or after `pos` (uniform); leaves pos on it
+    auto find_tile = [&]() -> bool {
+        while (pos < chunk_len) {
+            const int bid = chunk_base + pos;
+            const int band = bid / (LM_BAND * n_tiles);
+            const int rem = bid % (LM_BAND * n_tiles);
+            const int combo = band * LM_BAND + rem % LM_BAND;
+            glm_locate_block(p.offs, p.G, p.R, C::BM, combo, sh);
+            __syncthreads();
+            const int g_ = sh[0], a_ = sh[1], b_ = sh[2];
+            __syncthreads();  // sh is rewritten by the next search step
+            if (g_ >= 0) {
+                grp = g_;
+                m0 = a_;
+                mcnt = b_;
+                ntile = rem / LM_BAND;
+                return true;
+            }
+            pos += pstep;
+        }
+        return false;
+    };
 
     // ---- DMA sources.  One instruction = RPI tile rows x CPR chunks (1 KiB); lane → row
     // +(lane / CPR), LDS position lane % CPR holds global chunk (lane % CPR) ^ swz(row). ----
     const bf16_t* wsrc[C::W_DMA];
     const bf16_t* xsrc[C::X_DMA];
     int wch[C::W_DMA], xch[C::X_DMA];
-    const bf16_t* wg = p.w + (int64_t)grp * p.w_gstride;
+    auto setup_sources = [&]() {
+        const bf16_t* wg = p.w + (int64_t)grp * p.w_gstride;
 #pragma unroll
-    for (int i = 0; i < C::W_DMA; ++i) {
-        const int row = (wid * C::W_DMA + i) * C::RPI + lane / C::CPR;  // 0..255
-        const int ch = (lane % C::CPR) ^ C::swz(row);
-        wch[i] = ch;
-        int wr;
-        if (MODE == GEMM_GATEUP) {
-            const int half = row >> 7;  // 0: gate rows, 1: up rows
-            wr = half * p.N + min(ntile * 128 + (row & 127), p.N - 1);
-        } else {
-            wr = min(ntile * LM_BN + row, p.N - 1);
+        for (int i = 0; i < C::W_DMA; ++i) {
+            const int row = (wid * C::W_DMA + i) * C::RPI + lane / C::CPR;  // 0..255
+            const int ch = (lane % C::CPR) ^ C::swz(row);
+            wch[i] = ch;
+            int wr;
+            if (MODE == GEMM_GATEUP) {
+                const int half = row >> 7;  // 0: gate rows, 1: up rows
+                wr = half * p.N + min(ntile * 128 + (row & 127), p.N - 1);
+            } else {
+                wr = min(ntile * LM_BN + row, p.N - 1);
+            }
+            wsrc[i] = wg + (int64_t)wr * p.ldw + ch * 8;
         }
-        wsrc[i] = wg + (int64_t)wr * p.ldw + ch * 8;
-    }
 #pragma unroll
-    for (int i = 0; i < C::X_DMA; ++i) {
-        const int row = (wid * C::X_DMA + i) * C::RPI + lane / C::CPR;  // 0..BM-1
-        const int ch = (lane % C::CPR) ^ C::swz(row);
-        xch[i] = ch;
-        const int mr = row < mcnt ? row : 0;
-        const int64_t srow = p.src ? (int64_t)p.src[m0 + mr] : (int64_t)(m0 + mr);
-        xsrc[i] = p.x + srow * p.ldx + ch * 8;
-    }
+        for (int i = 0; i < C::X_DMA; ++i) {
+            const int row = (wid * C::X_DMA + i) * C::RPI + lane / C::CPR;  // 0..BM-1
+            const int ch = (lane % C::CPR) ^ C::swz(row);
+            xch[i] = ch;
+            const int mr = row < mcnt ? row : 0;
+            const int64_t srow = p.src ? (int64_t)p.src[m0 + mr] : (int64_t)(m0 + mr);
+            xsrc[i] = p.x + srow * p.ldx + ch * 8;
+        }
+    };
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_lm);
     auto stage = [&](int slot, int kt) {
         char* wdst = smem + slot * C::STAGE + wid * C::W_DMA * 1024;
@@ -168,6 +193,11 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         for (int i = 0; i < C::W_DMA; ++i) glds16(k0 + wch[i] * 8 < K ? wsrc[i] + k0 : zero, wdst + i * 1024);
 #pragma unroll
         for (int i = 0; i < C::X_DMA; ++i) glds16(k0 + xch[i] * 8 < K ? xsrc[i] + k0 : zero, xdst + i * 1024);
+    };
+    auto fill_ring = [&]() {
+#pragma unroll
+        for (int d = 0; d < C::DIST; ++d)
+            if (d < nk) stage(d, d);
     };
 
     // ---- fragment read offsets relative to the stage base: lane (c,g4) reads row +c, chunk 4ks+g4
@@ -187,109 +217,124 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             rel[ks * (4 + C::MT) + 4 + t] = C::WT + xrow * C::RB + (((4 * ks + g4) ^ C::swz(xrow)) << 4);
         }
     }
-
-    f32x4_t acc[4][C::MT];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < C::MT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    // ---- main loop: two phases per K tile, waves 4-7 run ONE BARRIER BEHIND waves 0-3 ----
-    //   phase 1: LDS fragment reads of tile kt + DMA issue of tile kt+DIST + counted wait for
-    //            this wave's share of tile kt+1, then barrier
-    //   phase 2: the tile's MFMAs, then barrier
-    // The two waves that share a SIMD (w, w+4) are therefore always in opposite phases: one feeds
-    // the matrix pipe while the other issues loads (in lockstep the pipe idles ~60 % of the time).
-    // Ordering under the stagger (the other group sits one barrier earlier/later):
-    //   RAW  tile kt+1 is read in phase 1 of kt+1, i.e. after this group's B2(kt) = other group's
-    //        B1(kt) (or later); every wave waited for its share of kt+1 BEFORE its own B1(kt).
-    //   WAR  tile kt+DIST overwrites the slot of kt-1 in phase 1 of kt, i.e. after this group's
-    //        B2(kt-1) >= other group's B1(kt-1); every wave finished reading kt-1 before its own
-    //        B1(kt-1).
-#pragma unroll
-    for (int d = 0; d < C::DIST; ++d)
-        if (d < nk) stage(d, d);
-    dma_wait_leave<C::DPW>(min(nk, C::DIST) - 1);
-    __builtin_amdgcn_s_barrier();                 // every share of tile 0 landed
-    if (wid >= 4) __builtin_amdgcn_s_barrier();   // the stagger
-    int slot = 0;  // ring slot of tile kt
     const unsigned base = lds_addr(smem);
-    for (int kt = 0; kt < nk; ++kt) {
-        // ---------------- phase 1 ----------------
-        const unsigned sb = base + slot * C::STAGE;
-        u32x4_t f[C::NF];
-        const int nslot = slot == 0 ? C::NSTAGE - 1 : slot - 1;  // slot of tile kt-1
-        if (GLM_LM_STAGE_POS == 0 && kt + C::DIST < nk) stage(nslot, kt + C::DIST);
-#pragma unroll
-        for (int i = 0; i < C::NF / 2; ++i) lds_read_b128(f[i], sb + rel[i]);
-        if (GLM_LM_STAGE_POS == 1 && kt + C::DIST < nk) stage(nslot, kt + C::DIST);
-#pragma unroll
-        for (int i = C::NF / 2; i < C::NF; ++i) lds_read_b128(f[i], sb + rel[i]);
-        if (GLM_LM_STAGE_POS == 2 && kt + C::DIST < nk) stage(nslot, kt + C::DIST);
-        // this wave's share of tile kt+1: leave only the tiles newer than kt+1 in flight
-        dma_wait_leave<C::DPW>(min(kt + C::DIST, nk - 1) - (kt + 1));
-        lds_wait(f);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();  // B1
-        // ---------------- phase 2 ----------------
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < C::MT; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8_t, f[ks * (4 + C::MT) + nt]),
-                        __builtin_bit_cast(bf16x8_t, f[ks * (4 + C::MT) + 4 + mt]), acc[nt][mt], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();  // B2
-        slot = slot == C::NSTAGE - 1 ? 0 : slot + 1;
-    }
-    if (wid < 4) __builtin_amdgcn_s_barrier();  // match the other group's extra barrier
 
-    // ---- epilogue ----
+    if (!find_tile()) return;
+    setup_sources();
+    fill_ring();
+    for (;;) {
+        // the tile whose ring is filling is now the tile being computed
+        const int grp_c = grp, m0_c = m0, mcnt_c = mcnt, ntile_c = ntile;
+        f32x4_t acc[4][C::MT];
 #pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt) {
-        const int row = wm * (C::BM / 2) + 16 * mt + c;
-        if (row >= mcnt) continue;
-        bf16_t* yrow = p.y + (int64_t)(m0 + row) * p.ldy;
-        if (MODE == GEMM_GATEUP) {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int n = ntile * 128 + wn * 32 + 16 * t + 4 * g4;
-                if (n >= p.N) continue;
-                float o[4];
+            for (int j = 0; j < C::MT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+        // ---- main loop: two phases per K tile, waves 4-7 run ONE BARRIER BEHIND waves 0-3 ----
+        //   phase 1: LDS fragment reads of tile kt + DMA issue of tile kt+DIST + counted wait for
+        //            this wave's share of tile kt+1, then barrier
+        //   phase 2: the tile's MFMAs, then barrier
+        // The two waves that share a SIMD (w, w+4) are therefore always in opposite phases: one feeds
+        // the matrix pipe while the other issues loads (in lockstep the pipe idles ~60 % of the time).
+        // Ordering under the stagger (the other group sits one barrier earlier/later):
+        //   RAW  tile kt+1 is read in phase 1 of kt+1, i.e. after this group's B2(kt) = other group's
+        //        B1(kt) (or later); every wave waited for its share of kt+1 BEFORE its own B1(kt).
+        //   WAR  tile kt+DIST overwrites the slot of kt-1 in phase 1 of kt, i.e. after this group's
+        //        B2(kt-1) >= other group's B1(kt-1); every wave finished reading kt-1 before its own
+        //        B1(kt-1).
+        // The ring fill was issued before the previous tile's epilogue stores, and stores retire out of order with
+        // loads, so the first wait of a tile is a full drain (the stores are long acknowledged by then).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // every share of the first DIST tiles landed
+        if (wid >= 4) __builtin_amdgcn_s_barrier();   // the stagger
+        int slot = 0;  // ring slot of tile kt
+        for (int kt = 0; kt < nk; ++kt) {
+            // ---------------- phase 1 ----------------
+            const unsigned sb = base + slot * C::STAGE;
+            u32x4_t f[C::NF];
+            const int nslot = slot == 0 ? C::NSTAGE - 1 : slot - 1;  // slot of tile kt-1
+            if (GLM_LM_STAGE_POS == 0 && kt + C::DIST < nk) stage(nslot, kt + C::DIST);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    o[r] = rbf(glm_silu(rbf(acc[t][mt][r]))) * rbf(acc[t + 2][mt][r]);
-                u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-                *reinterpret_cast<u32x2_t*>(yrow + n) = v;
-            }
-        } else {
-            float sc = 1.0f;
-            bool scaled = false;
-            if (MODE == GEMM_DOWN && grp < p.n_scaled) {
-                sc = bf2f(p.scale[m0 + row]);
-                scaled = true;
-            }
+            for (int i = 0; i < C::NF / 2; ++i) lds_read_b128(f[i], sb + rel[i]);
+            if (GLM_LM_STAGE_POS == 1 && kt + C::DIST < nk) stage(nslot, kt + C::DIST);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int n = ntile * LM_BN + wn * 64 + 16 * nt + 4 * g4;
-                if (n >= p.N) continue;
-                float o[4];
+            for (int i = C::NF / 2; i < C::NF; ++i) lds_read_b128(f[i], sb + rel[i]);
+            if (GLM_LM_STAGE_POS == 2 && kt + C::DIST < nk) stage(nslot, kt + C::DIST);
+            // this wave's share of tile kt+1: leave only the tiles newer than kt+1 in flight
+            dma_wait_leave<C::DPW>(min(kt + C::DIST, nk - 1) - (kt + 1));
+            lds_wait(f);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();  // B1
+            // ---------------- phase 2 ----------------
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float a = acc[nt][mt][r];
-                    if (MODE == GEMM_PLAIN && p.bias) a += bf2f(p.bias[n + r]);
-                    if (scaled) a = rbf(a) * sc;
-                    o[r] = a;
+            for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < C::MT; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_t, f[ks * (4 + C::MT) + nt]),
+                            __builtin_bit_cast(bf16x8_t, f[ks * (4 + C::MT) + 4 + mt]), acc[nt][mt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();  // B2
+            slot = slot == C::NSTAGE - 1 ? 0 : slot + 1;
+        }
+        if (wid < 4) __builtin_amdgcn_s_barrier();  // match the other group's extra barrier
+
+        // ---- next tile: every wave is past its last LDS read, so the ring can be refilled right away ----
+        pos += pstep;
+        const bool more = find_tile();
+        if (more) {
+            setup_sources();
+            fill_ring();
+        }
+
+        // ---- epilogue of the finished tile ----
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+            const int row = wm * (C::BM / 2) + 16 * mt + c;
+            if (row >= mcnt_c) continue;
+            bf16_t* yrow = p.y + (int64_t)(m0_c + row) * p.ldy;
+            if (MODE == GEMM_GATEUP) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int n = ntile_c * 128 + wn * 32 + 16 * t + 4 * g4;
+                    if (n >= p.N) continue;
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        o[r] = rbf(glm_silu(rbf(acc[t][mt][r]))) * rbf(acc[t + 2][mt][r]);
+                    u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                    *reinterpret_cast<u32x2_t*>(yrow + n) = v;
                 }
-                u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-                *reinterpret_cast<u32x2_t*>(yrow + n) = v;
+            } else {
+                float sc = 1.0f;
+                bool scaled = false;
+                if (MODE == GEMM_DOWN && grp_c < p.n_scaled) {
+                    sc = bf2f(p.scale[m0_c + row]);
+                    scaled = true;
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int n = ntile_c * LM_BN + wn * 64 + 16 * nt + 4 * g4;
+                    if (n >= p.N) continue;
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float a = acc[nt][mt][r];
+                        if (MODE == GEMM_PLAIN && p.bias) a += bf2f(p.bias[n + r]);
+                        if (scaled) a = rbf(a) * sc;
+                        o[r] = a;
+                    }
+                    u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                    *reinterpret_cast<u32x2_t*>(yrow + n) = v;
+                }
             }
         }
+        if (!more) break;
     }
 }
 
@@ -311,7 +356,22 @@ int launch_largem_cfg(const GemmParams& p, hipStream_t st) {
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(512), C::LDS, st, p, n_tiles, (int)total);
+    // one workgroup per CU (the ring takes most of the LDS), a multiple of 8 so that every XCD gets the same count
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            glm_set_error("gemm_largem: hipGetDeviceProperties failed");
+            return GLM_ERR_LAUNCH;
+        }
+        n_cu = prop.multiProcessorCount;
+    }
+    int64_t nwg = (n_cu / 8) * 8;
+    if (nwg < 8) nwg = 8;
+    const int64_t need = (total + 7) / 8 * 8;
+    if (nwg > need) nwg = need;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), C::LDS, st, p, n_tiles, (int)total);
     GLM_CHECK_LAUNCH("gemm_largem");
     return GLM_OK;
 }
