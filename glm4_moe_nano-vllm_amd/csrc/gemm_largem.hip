@@ -38,6 +38,9 @@ constexpr int LM_BN = 256;    // weight rows per tile (MFMA row axis); 4 waves x
 #ifndef GLM_LM_STAGE_POS
 #define GLM_LM_STAGE_POS 0  // 0: DMA issue before the fragment reads (measured best, +0.8 %), 1: between, 2: after
 #endif
+#ifndef GLM_LM_SCHED
+#define GLM_LM_SCHED 0  // 0: two barriers per K tile with waves 4-7 one barrier behind; 1: one barrier per K tile
+#endif
 constexpr int LM_BAND = GLM_LM_BAND;  // row blocks per L2 supertile band
 
 // Tile configurations (the kernel is written once over these):
@@ -70,6 +73,17 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
 __device__ const u32x4_t g_zero_page_lm[4] = {};
+
+// GLM_LM_STAMP=1 (timing study only): waves 0 and 4 of workgroup 0 accumulate s_memtime deltas per phase segment
+#ifndef GLM_LM_STAMP
+#define GLM_LM_STAMP 0
+#endif
+#if GLM_LM_STAMP
+__device__ unsigned long long g_lm_stamps[2][8];
+#define LM_T(i) do { if (GLM_LM_STAMP) { unsigned long long t_ = __builtin_readcyclecounter(); if (i) tacc[i - 1] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define LM_T(i) do {} while (0)
+#endif
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_void_t*)gsrc, (lds_void_t*)lds_wave_base, 16, 0, 0);
@@ -247,25 +261,35 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         // loads, so the first wait of a tile is a full drain (the stores are long acknowledged by then).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                 // every share of the first DIST tiles landed
+#if GLM_LM_SCHED == 0
         if (wid >= 4) __builtin_amdgcn_s_barrier();   // the stagger
         int slot = 0;  // ring slot of tile kt
+#if GLM_LM_STAMP
+        unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#endif
         for (int kt = 0; kt < nk; ++kt) {
             // ---------------- phase 1 ----------------
             const unsigned sb = base + slot * C::STAGE;
             u32x4_t f[C::NF];
             const int nslot = slot == 0 ? C::NSTAGE - 1 : slot - 1;  // slot of tile kt-1
+            LM_T(0);
             if (GLM_LM_STAGE_POS == 0 && kt + C::DIST < nk) stage(nslot, kt + C::DIST);
+            LM_T(1);  // 0: DMA issue
 #pragma unroll
             for (int i = 0; i < C::NF / 2; ++i) lds_read_b128(f[i], sb + rel[i]);
             if (GLM_LM_STAGE_POS == 1 && kt + C::DIST < nk) stage(nslot, kt + C::DIST);
 #pragma unroll
             for (int i = C::NF / 2; i < C::NF; ++i) lds_read_b128(f[i], sb + rel[i]);
             if (GLM_LM_STAGE_POS == 2 && kt + C::DIST < nk) stage(nslot, kt + C::DIST);
+            LM_T(2);  // 1: LDS read issue
             // this wave's share of tile kt+1: leave only the tiles newer than kt+1 in flight
             dma_wait_leave<C::DPW>(min(kt + C::DIST, nk - 1) - (kt + 1));
+            LM_T(3);  // 2: counted DMA wait
             lds_wait(f);
+            LM_T(4);  // 3: LDS wait
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();  // B1
+            LM_T(5);  // 4: barrier 1
             // ---------------- phase 2 ----------------
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -279,10 +303,59 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                             __builtin_bit_cast(bf16x8_t, f[ks * (4 + C::MT) + 4 + mt]), acc[nt][mt], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
+            LM_T(6);  // 5: MFMA issue
             __builtin_amdgcn_s_barrier();  // B2
+            LM_T(7);  // 6: barrier 2
             slot = slot == C::NSTAGE - 1 ? 0 : slot + 1;
         }
+#if GLM_LM_STAMP
+        if (blockIdx.x == 8 && lane == 0 && (wid == 0 || wid == 4)) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) g_lm_stamps[wid >> 2][i] = tacc[i];
+            g_lm_stamps[wid >> 2][7] = (unsigned long long)nk;
+        }
+#endif
         if (wid < 4) __builtin_amdgcn_s_barrier();  // match the other group's extra barrier
+
+#else
+        // ---- one barrier per K tile.  Every wave runs the same stream — fragment reads of tile kt (+ DMA issue of tile
+        // kt+DIST, counted wait for its share of tile kt+1), then the tile's MFMAs — but waves 0-3 take the barrier
+        // BETWEEN the two phases and waves 4-7 AFTER the MFMAs.  Between two barriers waves 0-3 therefore run
+        // MFMA(kt-1) then the reads of kt while waves 4-7 run the reads of kt then MFMA(kt): the two waves of a
+        // SIMD (w, w+4) start every interval in opposite roles and swap half way without a barrier to wait at.
+        //   RAW  tile kt+1 is read in the interval after barrier kt; every wave waited for its share before taking it.
+        //   WAR  tile kt+DIST overwrites the slot of tile kt-1, read by all waves before barrier kt-1; it is issued
+        //        after that barrier.
+        const bool lead = wid < 4;
+        int slot = 0;  // ring slot of tile kt
+        for (int kt = 0; kt < nk; ++kt) {
+            const unsigned sb = base + slot * C::STAGE;
+            u32x4_t f[C::NF];
+            const int nslot = slot == 0 ? C::NSTAGE - 1 : slot - 1;  // slot of tile kt-1
+            if (kt + C::DIST < nk) stage(nslot, kt + C::DIST);
+#pragma unroll
+            for (int i = 0; i < C::NF; ++i) lds_read_b128(f[i], sb + rel[i]);
+            dma_wait_leave<C::DPW>(min(kt + C::DIST, nk - 1) - (kt + 1));
+            lds_wait(f);
+            __builtin_amdgcn_sched_barrier(0);
+            if (lead) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < C::MT; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_t, f[ks * (4 + C::MT) + nt]),
+                            __builtin_bit_cast(bf16x8_t, f[ks * (4 + C::MT) + 4 + mt]), acc[nt][mt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!lead) __builtin_amdgcn_s_barrier();
+            slot = slot == C::NSTAGE - 1 ? 0 : slot + 1;
+        }
+        // waves 4-7 are past every LDS read of this tile here, waves 0-3 finished theirs before the last barrier
+#endif
 
         // ---- next tile: every wave is past its last LDS read, so the ring can be refilled right away ----
         pos += pstep;
@@ -407,3 +480,10 @@ int glm_launch_gemm_largem(int mode, const GemmParams& p, hipStream_t st) {
     if (mode == GEMM_DOWN) return launch_largem<GEMM_DOWN>(p, st);
     return launch_largem<GEMM_PLAIN>(p, st);
 }
+
+#if GLM_LM_STAMP
+// timing study only: per-segment cycle sums of the last tile workgroup 8 ran (waves 0 and 4), [2][8]; [7] = K tiles
+extern "C" int glm_debug_largem_stamps(unsigned long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lm_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -1,0 +1,35 @@
+"""Phase-segment cycle breakdown of the prefill grouped GEMM (needs the GLM_LM_STAMP=1 variant library:
+python glm4_moe_nano-vllm_amd/build.py --variant _stamp GLM_LM_STAMP=1; GLM4MOE_HIP_LIB=.../libglm4moe_hip_stamp.so)."""
+import ctypes, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "glm4_moe_nano-vllm_amd"))
+import bench
+from nanovllm import hip_ops as ops
+from nanovllm.models.glm4_moe.model import Glm4MoeForCausalLM
+torch.set_default_dtype(torch.bfloat16)
+cfg = bench.air64e_config(2, 4096)
+with torch.device("cuda"):
+    model = Glm4MoeForCausalLM(cfg)
+bench.init_weights(model, 1)
+layer = model.model.layers[1]
+T, H, E, k = 16384, cfg.hidden_size, cfg.n_routed_experts, cfg.num_experts_per_tok
+x = torch.randn(T, H, device="cuda").to(torch.bfloat16)
+idx, w = layer.mlp.gate(x)
+offs, tok, scale, pos = ops.moe_align(idx, w, E, True)
+w13, w2 = layer.mlp._stacked()
+R = T * k + T
+lib = ops.load_library()
+f = lib.glm_debug_largem_stamps
+f.restype = ctypes.c_int; f.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+names = ["dma issue", "lds read issue", "dma wait", "lds wait", "barrier 1", "mfma issue", "barrier 2"]
+def show(tag):
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 16)()
+    assert f(buf) == 0
+    for g in range(2):
+        nk = buf[g * 8 + 7]
+        tot = sum(buf[g * 8 + i] for i in range(7))
+        print(f"{tag} wave {4*g}: K tiles {nk}, cycles/tile {tot/max(nk,1):.0f}: " +
+              ", ".join(f"{names[i]} {buf[g*8+i]/max(nk,1):.0f}" for i in range(7)))
+act = ops.grouped_gemm_gateup_silu(x, w13, offs, tok, R); show("gate|up")
+ops.grouped_gemm_down(act, w2, offs, scale, E); show("down")
