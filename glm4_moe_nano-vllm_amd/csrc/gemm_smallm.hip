@@ -378,8 +378,15 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
     return launch_cfg<GEMM_PLAIN, 4, 1, 2, 4>(p, st);
 #endif
     if (p.G > 1 || rows > 32 || tiles32 >= 1024) return launch_cfg<GEMM_PLAIN, 4, 1, 2, 4>(p, st);
-    if (tiles32 >= 384) return launch_cfg<GEMM_PLAIN, 4, 4, 2, 2>(p, st);
-    return launch_cfg<GEMM_PLAIN, 8, 8, 1, 2>(p, st);
+    // (waves, K-split waves, row tiles per wave, max 16-row activation tiles); overridable for A/B builds
+#ifndef GLM_SM_CFG_MID
+#define GLM_SM_CFG_MID 8, 2, 1, 2  // QKV at M=32: 26.9 us (4,4,2,2: 33.2; 4,2,2,2: 28.9; 8,4,2,2: 29.5)
+#endif
+#ifndef GLM_SM_CFG_SMALL
+#define GLM_SM_CFG_SMALL 8, 8, 1, 2
+#endif
+    if (tiles32 >= 384) return launch_cfg<GEMM_PLAIN, GLM_SM_CFG_MID>(p, st);
+    return launch_cfg<GEMM_PLAIN, GLM_SM_CFG_SMALL>(p, st);
 }
 
 int glm_launch_gemm_smallm_fp8w(int mode, const GemmParams& p, hipStream_t st) {

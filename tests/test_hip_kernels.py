@@ -348,7 +348,7 @@ def test_moe_combine_order_is_reference_order(ops):
 @pytest.mark.parametrize("M,N,K,bias", [
     (1, 64, 128, False), (5, 72, 4096, True), (32, 4096, 1408, False), (33, 512, 176, True),
     (32, 14336, 512, True), (32, 1024, 12288, False), (64, 256, 704, False), (7, 4096, 4096, True),
-    (16, 151552 // 8, 256, False)])
+    (16, 151552 // 8, 256, False), (32, 14336, 4096, False), (9, 12288, 1152, True)])
 def test_gemm_bf16_small_m(ops, M, N, K, bias):
     x = rnd(M, K, seed=71)
     w = rnd(N, K, seed=72, scale=K ** -0.5)
