@@ -369,8 +369,18 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
                   p.K, p.N);
     // grouped experts: 32-row blocks (at decode batch sizes only the shared expert ever fills one;
     // a group with more rows re-reads its weights once per extra block)
-    if (mode == GEMM_GATEUP) return launch_cfg<GEMM_GATEUP, 4, 1, 2, 2>(p, st);
-    if (mode == GEMM_DOWN) return launch_cfg<GEMM_DOWN, 4, 1, 2, 2>(p, st);
+    // (waves, K-split waves, row tiles per wave, max 16-row activation tiles).  Same-box sweep at the C3 decode shape
+    // (tools/sweep_grouped.sh, two rounds): gate|up 4,1,2,2: 272 us; 8,4,2,2: 256; 4,2,2,2: 251; 4,4,2,2: 245-249.
+    // down 4,1,2,2: 130 us; 8,1,1,2: 122; 2,1,1,2: 120; 4,2,1,2: 118-120.  Splitting K over the waves of a small
+    // workgroup (16 act columns of gate|up, 32 columns of down) beats one long stream per wave.
+#ifndef GLM_SM_CFG_GATEUP
+#define GLM_SM_CFG_GATEUP 4, 4, 2, 2
+#endif
+#ifndef GLM_SM_CFG_DOWN
+#define GLM_SM_CFG_DOWN 4, 2, 1, 2
+#endif
+    if (mode == GEMM_GATEUP) return launch_cfg<GEMM_GATEUP, GLM_SM_CFG_GATEUP>(p, st);
+    if (mode == GEMM_DOWN) return launch_cfg<GEMM_DOWN, GLM_SM_CFG_DOWN>(p, st);
     // dense projection: choose the K-split so that the grid covers the chip
     const int64_t rows = p.offs ? 64 : p.R;
     const int tiles32 = (p.N + 31) / 32;
@@ -396,8 +406,14 @@ int glm_launch_gemm_smallm_fp8w(int mode, const GemmParams& p, hipStream_t st) {
                   GLM_ERR_UNSUPPORTED,
                   "gemm_smallm(fp8 weights): needs K%%16==0, N%%4==0, ldw%%16==0, 16B-aligned x/W, scales (K=%d N=%d)",
                   p.K, p.N);
-    if (mode == GEMM_GATEUP) return launch_cfg<GEMM_GATEUP, 4, 1, 2, 2, true>(p, st);
-    if (mode == GEMM_DOWN) return launch_cfg<GEMM_DOWN, 4, 1, 2, 2, true>(p, st);
+#ifndef GLM_SM_CFG_GATEUP_W8
+#define GLM_SM_CFG_GATEUP_W8 4, 1, 2, 2
+#endif
+#ifndef GLM_SM_CFG_DOWN_W8
+#define GLM_SM_CFG_DOWN_W8 4, 1, 2, 2
+#endif
+    if (mode == GEMM_GATEUP) return launch_cfg<GEMM_GATEUP, GLM_SM_CFG_GATEUP_W8, true>(p, st);
+    if (mode == GEMM_DOWN) return launch_cfg<GEMM_DOWN, GLM_SM_CFG_DOWN_W8, true>(p, st);
     glm_set_error("gemm_smallm(fp8 weights): only the grouped expert projections are quantised");
     return GLM_ERR_UNSUPPORTED;
 }
