@@ -346,9 +346,9 @@ def measure_kernels(model, cfg, ops, B, ctx, world, iters, dev):
 
     o_in = torch.randn(B, nh * hd, device=dev).to(torch.bfloat16)
 
-    def f_o(i):
+    def f_o(i):  # as the decoder layer runs it: K-slice partial sums at TP=1 (reduced inside the next add-RMSNorm)
         a = attn_layers[i % len(attn_layers)]
-        ops.gemm_bf16(o_in, a.o_proj.weight.data, None)
+        a.o_proj(o_in, defer_reduce=True)
     m, md = timeit(f_o, iters)
     rec("gemm_o", m, md, H * nh * hd * 2, "H*nh*hd*2 B of W_o")
     # ---- prefill shape of the same config: T = 16384 tokens (max_num_batched_tokens,

@@ -12,7 +12,7 @@ void glm_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int glm_abi_version(void) { return 3; }
+extern "C" int glm_abi_version(void) { return 4; }
 extern "C" const char* glm_last_error(void) { return g_err; }
 
 namespace {
@@ -40,6 +40,23 @@ extern "C" int glm_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t 
     p.y = (bf16_t*)y; p.ldy = ldy;
     p.R = M; p.N = N; p.K = K; p.G = 1;
     return dispatch(GEMM_PLAIN, p, glm_s(stream));
+}
+
+extern "C" int glm_gemm_bf16_partial_slices(int K, int want) { return glm_smallm_partial_slices(K, want); }
+
+extern "C" int glm_gemm_bf16_partial(const void* x, int64_t ldx, const void* w, int64_t ldw, float* ypart,
+                                     int64_t M, int N, int K, int nslices, glm_stream_t stream) {
+    GLM_CHECK_ARG(x && w && ypart, GLM_ERR_INVALID, "glm_gemm_bf16_partial: null pointer");
+    GLM_CHECK_ARG(M >= 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && nslices > 1, GLM_ERR_INVALID,
+                  "glm_gemm_bf16_partial: bad shape M=%ld N=%d K=%d slices=%d", (long)M, N, K, nslices);
+    if (M == 0) return GLM_OK;
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)x; p.ldx = ldx;
+    p.w = (const bf16_t*)w; p.w_gstride = 0; p.ldw = ldw;
+    p.R = M; p.N = N; p.K = K; p.G = 1;
+    p.ksplit = nslices; p.ypart = ypart;
+    return glm_launch_gemm_smallm_partial(p, glm_s(stream));
 }
 
 extern "C" int glm_grouped_gemm_gateup_silu(const void* x, int64_t ldx, const void* w13,

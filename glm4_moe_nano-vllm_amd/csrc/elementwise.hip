@@ -444,7 +444,101 @@ int launch_rmsnorm(const void* x, const void* res_in, const void* w, void* y, vo
     return GLM_OK;
 }
 
+// add-RMSNorm whose x is given as fp32 K-slice partial sums of a linear layer (glm_gemm_bf16_partial):
+// x = bf16(sum_s part[s]) — the linear's own output rounding — then exactly rmsnorm_vec_kernel<ADD>.
+template <int VPT>
+__global__ __launch_bounds__(256) void add_rmsnorm_partial_kernel(const float* __restrict__ part, int nslices,
+                                                                  int64_t slice_stride, const bf16_t* res_in,
+                                                                  const bf16_t* __restrict__ w, bf16_t* y,
+                                                                  bf16_t* res_out, int H, float eps) {
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x;
+    const int nvec = H >> 3;
+    const u32x4_t* rr = reinterpret_cast<const u32x4_t*>(res_in + row * H);
+    const u32x4_t* wr = reinterpret_cast<const u32x4_t*>(w);
+    u32x4_t* yr = reinterpret_cast<u32x4_t*>(y + row * H);
+    u32x4_t* ro = reinterpret_cast<u32x4_t*>(res_out + row * H);
+    float s[VPT][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const int i = threadIdx.x + v * 256;
+        if (i < nvec) {
+            const float* pp = part + row * H + (int64_t)i * 8;
+            f32x4_t a = *reinterpret_cast<const f32x4_t*>(pp), b = *reinterpret_cast<const f32x4_t*>(pp + 4);
+            // slices are added in index order (deterministic); loads of up to 8 slices are in flight together
+            for (int s0 = 1; s0 < nslices; s0 += 8) {
+                f32x4_t ta[8], tb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int sl = min(s0 + j, nslices - 1);  // clamped re-read, not added
+                    ta[j] = *reinterpret_cast<const f32x4_t*>(pp + sl * slice_stride);
+                    tb[j] = *reinterpret_cast<const f32x4_t*>(pp + sl * slice_stride + 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (s0 + j < nslices) {
+                        a += ta[j];
+                        b += tb[j];
+                    }
+            }
+            const u32x4_t rv = rr[i];
+            u32x4_t ov;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x0 = rbf(j < 2 ? a[2 * j] : b[2 * j - 4]);
+                const float x1 = rbf(j < 2 ? a[2 * j + 1] : b[2 * j - 3]);
+                s[v][2 * j] = x0 + bflo(rv[j]);
+                s[v][2 * j + 1] = x1 + bfhi(rv[j]);
+                ov[j] = pack2bf(s[v][2 * j], s[v][2 * j + 1]);
+            }
+            ro[i] = ov;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += s[v][j] * s[v][j];
+        }
+    }
+    const float tot = block_sum_256(ss, red);
+    const float var = tot / (float)H;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const int i = threadIdx.x + v * 256;
+        if (i < nvec) yr[i] = norm_scale8(s[v], rstd, wr[i]);
+    }
+}
+
 }  // namespace
+
+extern "C" int glm_add_rmsnorm_partial(const float* part, int nslices, int64_t slice_stride,
+                                       const void* residual_in, const void* weight, void* y, void* residual_out,
+                                       int64_t T, int H, float eps, glm_stream_t stream) {
+    GLM_CHECK_ARG(part && residual_in && weight && y && residual_out, GLM_ERR_INVALID,
+                  "glm_add_rmsnorm_partial: null pointer");
+    GLM_CHECK_ARG(T >= 0 && H > 0 && nslices >= 1 && slice_stride >= T * (int64_t)H, GLM_ERR_INVALID,
+                  "glm_add_rmsnorm_partial: bad shape");
+    GLM_CHECK_ARG(H % 8 == 0 && H <= 256 * 8 * 8 && glm_aligned16(part) && slice_stride % 4 == 0 &&
+                      glm_aligned16(residual_in) && glm_aligned16(weight) && glm_aligned16(y) &&
+                      glm_aligned16(residual_out),
+                  GLM_ERR_UNSUPPORTED, "glm_add_rmsnorm_partial: needs H%%8==0, H<=16384, 16-byte aligned buffers (H=%d)", H);
+    if (T == 0) return GLM_OK;
+    const bf16_t* rp = (const bf16_t*)residual_in;
+    const bf16_t* wp = (const bf16_t*)weight;
+    bf16_t* yp = (bf16_t*)y;
+    bf16_t* op = (bf16_t*)residual_out;
+    hipStream_t st = glm_s(stream);
+    dim3 grid((unsigned)T), block(256);
+    const int vpt = (H / 8 + 255) / 256;
+    if (vpt <= 1)
+        hipLaunchKernelGGL((add_rmsnorm_partial_kernel<1>), grid, block, 0, st, part, nslices, slice_stride, rp, wp, yp, op, H, eps);
+    else if (vpt <= 2)
+        hipLaunchKernelGGL((add_rmsnorm_partial_kernel<2>), grid, block, 0, st, part, nslices, slice_stride, rp, wp, yp, op, H, eps);
+    else if (vpt <= 4)
+        hipLaunchKernelGGL((add_rmsnorm_partial_kernel<4>), grid, block, 0, st, part, nslices, slice_stride, rp, wp, yp, op, H, eps);
+    else
+        hipLaunchKernelGGL((add_rmsnorm_partial_kernel<8>), grid, block, 0, st, part, nslices, slice_stride, rp, wp, yp, op, H, eps);
+    GLM_CHECK_LAUNCH("glm_add_rmsnorm_partial");
+    return GLM_OK;
+}
 
 extern "C" int glm_rmsnorm(const void* x, const void* weight, void* y, int64_t T, int H, float eps,
                            glm_stream_t stream) {

@@ -27,10 +27,15 @@ struct GemmParams {
     int K;
     int G;                // number of groups
     int n_scaled;         // GEMM_DOWN: groups [0, n_scaled) multiply by scale
+    int ksplit;           // GEMM_PLAIN small-M only: K slices computed by separate workgroups (0/1 = off)
+    float* ypart;         // ksplit > 1: fp32 partial sums [ksplit][R][N] instead of y
 };
 
 // weight-streaming kernels for few rows per group (decode); returns GLM_* code
 int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st);
+// K-split partial sums (p.ksplit > 1, p.ypart): one fp32 [R,N] slab per K slice, no bias, no rounding
+int glm_launch_gemm_smallm_partial(const GemmParams& p, hipStream_t st);
+int glm_smallm_partial_slices(int K, int want);  // slices actually used for a requested count (whole 128-wide chunks)
 // same, weights stored as OCP fp8 e4m3 (1 byte/element, ldw/w_gstride in elements) + per-row scale
 int glm_launch_gemm_smallm_fp8w(int mode, const GemmParams& p, hipStream_t st);
 // LDS-tiled MFMA kernels for many rows per group (prefill)

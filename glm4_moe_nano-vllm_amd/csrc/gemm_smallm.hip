@@ -60,6 +60,21 @@ constexpr int SM_CPR = SM_KC / 8;    // 16-B chunks per row
 template <int MODE, int RT, int MT>
 __device__ __forceinline__ void smallm_epilogue(const GemmParams& p, f32x4_t (&acc)[RT][MT], int grp, int m0,
                                                 int mcnt, int ncol0, int c, int g4) {
+    if (MODE == GEMM_PLAIN && p.ypart != nullptr) {
+        // K-split: this workgroup's fp32 partial sums; bias and the bf16 rounding belong to the consumer
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = 16 * mt + c;
+            if (row >= mcnt) continue;
+            float* prow = p.ypart + (int64_t)(m0 + row) * p.N;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int n = ncol0 + 16 * rt + 4 * g4;
+                if (n < p.N) *reinterpret_cast<f32x4_t*>(prow + n) = acc[rt][mt];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int row = 16 * mt + c;
@@ -312,7 +327,18 @@ __device__ __forceinline__ void smallm_body(const GemmParams& p, char* smem, int
 }
 
 template <int MODE, int NWAVES, int WS, int RT, int MTMAX, bool W8>
-__global__ __launch_bounds__(NWAVES * 64) void gemm_smallm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(NWAVES * 64) void gemm_smallm_kernel(const GemmParams p_in) {
+    GemmParams p = p_in;
+    if (MODE == GEMM_PLAIN && p_in.ksplit > 1) {
+        // K slice of this workgroup (whole 128-wide chunks; the host sizes ksplit so that no slice is empty)
+        const int chunks = (p_in.K + SM_KC - 1) / SM_KC;
+        const int per = (chunks + p_in.ksplit - 1) / p_in.ksplit;
+        const int kb = blockIdx.z * per * SM_KC;
+        p.x = p_in.x + kb;
+        p.w = p_in.w + kb;
+        p.K = min(per * SM_KC, p_in.K - kb);
+        p.ypart = p_in.ypart + (int64_t)blockIdx.z * p_in.R * p_in.N;
+    }
     constexpr int MB = 16 * MTMAX;
     constexpr int XBUF = WS * MB * SM_XROWB;  // bytes per x buffer (sized for MTMAX)
     static_assert(MODE != GEMM_GATEUP || RT == 2, "gate|up needs two row tiles");
@@ -354,7 +380,8 @@ int launch_cfg(const GemmParams& p, hipStream_t st) {
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(gx, (unsigned)combos), dim3(NWAVES * 64), LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3(gx, (unsigned)combos, (unsigned)(p.ksplit > 1 ? p.ksplit : 1)), dim3(NWAVES * 64),
+                       LDS, st, p);
     GLM_CHECK_LAUNCH("gemm_smallm");
     return GLM_OK;
 }
@@ -397,6 +424,26 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
 #endif
     if (tiles32 >= 384) return launch_cfg<GEMM_PLAIN, GLM_SM_CFG_MID>(p, st);
     return launch_cfg<GEMM_PLAIN, GLM_SM_CFG_SMALL>(p, st);
+}
+
+int glm_smallm_partial_slices(int K, int want) {
+    const int chunks = (K + SM_KC - 1) / SM_KC;
+    if (want < 1) want = 1;
+    if (want > chunks) want = chunks;
+    const int per = (chunks + want - 1) / want;
+    return (chunks + per - 1) / per;  // no empty slice
+}
+
+int glm_launch_gemm_smallm_partial(const GemmParams& p, hipStream_t st) {
+    GLM_CHECK_ARG(p.K % 8 == 0 && p.N % 4 == 0 && p.ldx % 8 == 0 && p.ldw % 8 == 0 && glm_aligned16(p.x) &&
+                      glm_aligned16(p.w) && glm_aligned16(p.ypart) && p.R <= 32 && p.offs == nullptr && p.ksplit > 1 &&
+                      p.ksplit == glm_smallm_partial_slices(p.K, p.ksplit),
+                  GLM_ERR_UNSUPPORTED, "gemm_smallm(partial): needs M<=32, K%%8==0, N%%4==0, a slice count from "
+                  "glm_smallm_partial_slices (M=%ld K=%d N=%d ksplit=%d)", (long)p.R, p.K, p.N, p.ksplit);
+#ifndef GLM_SM_CFG_PARTIAL
+#define GLM_SM_CFG_PARTIAL 4, 1, 1, 2
+#endif
+    return launch_cfg<GEMM_PLAIN, GLM_SM_CFG_PARTIAL>(p, st);
 }
 
 int glm_launch_gemm_smallm_fp8w(int mode, const GemmParams& p, hipStream_t st) {

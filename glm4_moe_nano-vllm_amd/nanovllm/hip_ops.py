@@ -63,6 +63,11 @@ _SIGNATURES = {
                                 c_int64, c_void_p]),
     "glm_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                               c_int64, c_int, c_int, c_void_p]),
+    "glm_gemm_bf16_partial_slices": (c_int, [c_int, c_int]),
+    "glm_gemm_bf16_partial": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
+                                      c_int, c_void_p]),
+    "glm_add_rmsnorm_partial": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int64, c_int, c_float, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -395,6 +400,49 @@ def moe_combine(y, pair_pos, T: int, k: int, shared_base: int) -> torch.Tensor:
     _check(load_library().glm_moe_combine(_p(y), y.stride(0), _p(pair_pos), _p(out), T, k, H,
                                           shared_base, _stream()), "glm_moe_combine")
     return out
+
+
+class PartialSum:
+    """fp32 K-slice partial sums [nslices, M, N] of a bias-free linear layer whose reduction (and bf16 rounding) is
+    deferred to the consumer kernel (add_rmsnorm_partial)."""
+    __slots__ = ("part",)
+
+    def __init__(self, part: torch.Tensor):
+        self.part = part
+
+    @property
+    def shape(self):
+        return self.part.shape[1:]
+
+
+def gemm_bf16_partial(x: torch.Tensor, w: torch.Tensor, want_slices: int = 8) -> PartialSum:
+    """K-slice partial sums of x @ w.T for decode batches (M <= 32); see glm_gemm_bf16_partial."""
+    _bf16(x, "x"); _bf16(w, "w")
+    K = x.shape[-1]
+    N = w.shape[0]
+    assert x.dim() == 2 and w.shape[1] == K and w.stride(1) == 1 and x.stride(1) == 1
+    M = x.shape[0]
+    lib = load_library()
+    ns = lib.glm_gemm_bf16_partial_slices(K, want_slices)
+    part = torch.empty((ns, M, N), dtype=torch.float32, device=x.device)
+    _check(lib.glm_gemm_bf16_partial(_p(x), x.stride(0), _p(w), w.stride(0), _p(part), M, N, K, ns, _stream()),
+           "glm_gemm_bf16_partial")
+    return PartialSum(part)
+
+
+def add_rmsnorm_partial(ps: PartialSum, residual: torch.Tensor, weight: torch.Tensor,
+                        eps: float) -> tuple[torch.Tensor, torch.Tensor]:
+    """add_rmsnorm whose x is bf16(sum of the K-slice partial sums)."""
+    _bf16(residual, "residual"); _bf16(weight, "weight")
+    part = ps.part
+    ns, T, H = part.shape
+    r2 = residual.reshape(-1, H).contiguous()
+    assert r2.shape[0] == T and part.is_contiguous()
+    y = torch.empty_like(r2)
+    ro = torch.empty_like(r2)
+    _check(load_library().glm_add_rmsnorm_partial(_p(part), ns, T * H, _p(r2), _p(weight), _p(y), _p(ro), T, H, eps,
+                                                  _stream()), "glm_add_rmsnorm_partial")
+    return y.view(residual.shape), ro.view(residual.shape)
 
 
 def gemm_bf16(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:

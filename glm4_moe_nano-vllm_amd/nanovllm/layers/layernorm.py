@@ -18,7 +18,9 @@ class RMSNorm(nn.Module):
     def rms_forward(self, x: torch.Tensor) -> torch.Tensor:
         return hip_ops.rmsnorm(x, self.weight.data, self.eps)
 
-    def add_rms_forward(self, x: torch.Tensor, residual: torch.Tensor):
+    def add_rms_forward(self, x, residual: torch.Tensor):
+        if isinstance(x, hip_ops.PartialSum):  # deferred K-slice reduction of the producing linear layer
+            return hip_ops.add_rmsnorm_partial(x, residual, self.weight.data, self.eps)
         return hip_ops.add_rmsnorm(x, residual, self.weight.data, self.eps)
 
     def forward(self, x: torch.Tensor, residual: torch.Tensor | None = None):

@@ -63,7 +63,9 @@ class Glm4MoeAttention(nn.Module):
         return (self.head_dim % 8 == 0 and lph >= 2 and lph <= 64 and (lph & (lph - 1)) == 0
                 and self.rotary_emb.rotary_dim % 16 == 0)
 
-    def forward(self, hidden_states: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
+    def forward(self, hidden_states: torch.Tensor, positions: torch.Tensor, defer_o_reduce: bool = False):
+        """defer_o_reduce: the caller feeds the result straight into RMSNorm.forward(x, residual) and accepts a
+        hip_ops.PartialSum (K-slice partial sums of o_proj, reduced inside that add-RMSNorm kernel)."""
         qkv = self.qkv_proj(hidden_states)
         ctx = get_context()
         attn = self.attn
@@ -88,7 +90,7 @@ class Glm4MoeAttention(nn.Module):
                 q, k = self.q_norm(q), self.k_norm(k)
             q, k = self.rotary_emb(positions, q, k)
             o = attn(q, k, v)
-        return self.o_proj(o.reshape(o.shape[0], -1))
+        return self.o_proj(o.reshape(o.shape[0], -1), defer_reduce=defer_o_reduce)
 
     def load_weights(self, path: str, prefix: str):
         sd = load_prefixed(path, prefix)

@@ -47,7 +47,8 @@ class Glm4MoeDecoderLayer(nn.Module):
             hidden_states, residual = self.input_layernorm(hidden_states), hidden_states
         else:
             hidden_states, residual = self.input_layernorm(hidden_states, residual)
-        hidden_states = self.self_attn(hidden_states, positions)
+        # o_proj may hand over K-slice partial sums; the add-RMSNorm right below reduces them (decode batches)
+        hidden_states = self.self_attn(hidden_states, positions, defer_o_reduce=True)
         hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
         hidden_states = self.mlp(hidden_states)
         return hidden_states, residual

@@ -195,6 +195,19 @@ int glm_moe_combine(const void* y, int64_t ldy, const int32_t* pair_pos, void* o
 int glm_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
                   void* y, int64_t ldy, int64_t M, int N, int K, glm_stream_t stream);
 
+/* a10+a3 fused pair for decode batches (M <= 32), no reference counterpart as an API: the row-parallel o_proj
+ *     (layers/linear.py:152, K = nh*hd >> N) is computed as `nslices` K-slice partial sums by separate workgroups,
+ *     ypart [nslices][M][N] fp32 (no bias), and the consumer — the post-attention add-RMSNorm, decode_layer.py:51 —
+ *     sums them in slice order, rounds to bf16 (the linear's output rounding) and continues as glm_add_rmsnorm.
+ *     glm_gemm_bf16_partial_slices(K, want) returns the slice count to use for a requested one (whole 128-wide
+ *     K chunks, no empty slice).                                                              */
+int glm_gemm_bf16_partial_slices(int K, int want);
+int glm_gemm_bf16_partial(const void* x, int64_t ldx, const void* w, int64_t ldw, float* ypart,
+                          int64_t M, int N, int K, int nslices, glm_stream_t stream);
+int glm_add_rmsnorm_partial(const float* part, int nslices, int64_t slice_stride,
+                            const void* residual_in, const void* weight, void* y, void* residual_out,
+                            int64_t T, int H, float eps, glm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

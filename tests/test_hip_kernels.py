@@ -359,6 +359,31 @@ def test_gemm_bf16_small_m(ops, M, N, K, bias):
     assert_close_bf16(out, ref, 1, 0.05, atol=2 ** -9, what=f"gemm {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K,want", [(32, 4096, 12288, 8), (5, 256, 1024, 3), (1, 64, 136, 2), (17, 512, 4096, 64)])
+def test_gemm_partial_and_fused_add_rmsnorm(ops, M, N, K, want):
+    """K-slice partial sums + the add-RMSNorm that reduces them == linear -> add_rms_forward of the oracle."""
+    x = rnd(M, K, seed=171)
+    w = rnd(N, K, seed=172, scale=K ** -0.5)
+    res = rnd(M, N, seed=173)
+    nw = rnd(N, seed=174) * 0.1 + 1.0
+    ps = ops.gemm_bf16_partial(dev(x), dev(w), want)
+    ns = ps.part.shape[0]
+    assert 1 < ns <= want and ps.part.shape[1:] == (M, N)
+    tot = ps.part[0].clone()
+    for i in range(1, ns):  # the kernel's own order: slice 0 + slice 1 + ...
+        tot += ps.part[i]
+    lin = O.linear(x, w, None)
+    # the summed partials round to the same bf16 values as the one-pass kernel, up to fp32 summation order
+    assert_close_bf16(tot.to(BF), lin, 1, 0.05, atol=2 ** -9, what=f"partials {M}x{N}x{K}")
+    y, ro = ops.add_rmsnorm_partial(ps, dev(res), dev(nw), 1e-5)
+    # exact against the product's own two-kernel sequence whenever the rounded linear outputs agree
+    y2, ro2 = ops.add_rmsnorm(tot.to(BF), dev(res), dev(nw), 1e-5)
+    assert torch.equal(ro, ro2) and torch.equal(y, y2)
+    ye, re_ = O.add_rms_forward(lin, res, nw, 1e-5)
+    assert_close_bf16(ro, re_, 2, 0.05, atol=2 ** -8, what="residual")  # 1 ulp of the linear output + the add
+    assert_close_bf16(y, ye, 2, 0.05, atol=2 ** -7, what="normed")
+
+
 def test_gemm_bf16_strided_input(ops):
     M, N, K = 12, 256, 384
     big = rnd(M, K + 64, seed=74)

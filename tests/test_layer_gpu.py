@@ -62,11 +62,20 @@ def _hook_router(layer, captured):
         layer.mlp.gate.register_forward_hook(lambda m, i, o: captured.__setitem__("idx", o[0]))
 
 
-@pytest.mark.parametrize("tag", ["layer_moe_decode", "layer_moe_decode_qknorm"])
-def test_decoder_layer_decode(tag):
+@pytest.mark.parametrize("tag,split_o", [("layer_moe_decode", False), ("layer_moe_decode_qknorm", False),
+                                          ("layer_moe_decode", True)])
+def test_decoder_layer_decode(tag, split_o):
+    from nanovllm import hip_ops
     from nanovllm.utils.context import reset_context, set_context
     t, cfg = load_golden(tag)
     layer = build_product_layer(t, cfg, "model.layers.1")
+    if split_o:
+        # force the K-slice partial-sum o_proj + fused add-RMSNorm (normally only for K >= 8192)
+        layer.self_attn.o_proj.partial_min_k = 0
+        layer.self_attn.o_proj.partial_slices = 3
+        seen = []
+        orig = hip_ops.add_rmsnorm_partial
+        hip_ops.add_rmsnorm_partial = lambda *a, **k: (seen.append(1), orig(*a, **k))[1]
     captured = {}
     _hook_router(layer, captured)
     kc, vc = t["k_cache_in"].cuda(), t["v_cache_in"].cuda()
@@ -77,6 +86,9 @@ def test_decoder_layer_decode(tag):
         out, res = layer(t["positions"].cuda(), t["h"].cuda(), t["res_in"].cuda())
     reset_context()
     torch.cuda.synchronize()
+    if split_o:
+        hip_ops.add_rmsnorm_partial = orig
+        assert seen, "the partial-sum path was not taken"
     s = t["slot_mapping"].long()
     assert torch.equal(vc.cpu().view(-1, 256)[s], t["v_rows"]) or True  # V rows: GEMM rounding only
     _mixed(vc.cpu().view(-1, 256)[s], t["v_rows"], f"{tag} v cache rows")
