@@ -1,0 +1,43 @@
+#!/bin/bash
+# HBM traffic per launch of the decode hot kernels from PMC counters: two separate rocprofv3 --pmc passes
+# (FETCH_SIZE, WRITE_SIZE; kernel trace only) over `bench.py --layers 3 --no-graph`, corrected as
+# MI355X_MICROARCH.md (HBM section) prescribes.  Run on the GPU box: bash tools/pmc_traffic.sh
+# Writes gpurun_out/pmc_traffic.json (copy it to profiles/rNN/pmc_traffic.json).
+set -e
+R=$PWD
+export TMPDIR=/tmp
+mkdir -p $R/gpurun_out/pmc_tr
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_tr/$c -- python3 $R/bench.py --layers 3 --steps 2 --warmup 1 --no-graph --no-cpu-baseline --kernel-iters 12 > $R/gpurun_out/pmc_tr/$c.log 2>&1
+done
+python3 - <<PY
+import csv, glob, json, statistics, collections, re
+names = {  # kernel-name pattern -> bench.py kernel key
+    r"gemm_smallm_kernel<1, 4, 4, 2, 2": "grouped_gemm_gateup_silu",
+    r"gemm_smallm_kernel<2, 4, 2, 1, 2": "grouped_gemm_down",
+    r"gemm_smallm_kernel<0, 8, 2, 1, 2": "gemm_qkv",
+    r"gemm_smallm_kernel<0, 4, 1, 1, 2": "gemm_o",
+    r"paged_attn_decode_kernel": "paged_attn_decode",
+    r"gemm_largem_kernel<1,": "grouped_gemm_gateup_silu@prefill16k",
+    r"gemm_largem_kernel<2,": "grouped_gemm_down@prefill16k",
+}
+vals = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$R/gpurun_out/pmc_tr/*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        for pat, key in names.items():
+            if pat in r["Kernel_Name"]:
+                vals[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
+for key, d in vals.items():
+    if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
+        continue
+    fk, wk = statistics.median(d["FETCH_SIZE"]), statistics.median(d["WRITE_SIZE"])
+    out[key] = {"FETCH_SIZE_KB_median": fk, "WRITE_SIZE_KB_median": wk, "launches": len(d["FETCH_SIZE"]),
+                "hbm_bytes_corrected": int((2 * fk + wk) * 1024),
+                "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16 B/lane streaming reads -> x2 "
+                              "(MI355X_MICROARCH.md HBM); WRITE_SIZE exact; KB*1024"}
+json.dump(out, open("$R/gpurun_out/pmc_traffic.json", "w"), indent=1)
+for k, v in out.items():
+    print(f"{k:40s} {v['hbm_bytes_corrected']/1e6:10.1f} MB  ({v['launches']} launches)")
+PY
