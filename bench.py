@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=20)
+    ap.add_argument("--emulate-tp", type=int, default=1,
+                    help="kernel-shape study on ONE GPU: run the per-rank shapes of TP=N (heads, kv heads, expert/MLP "
+                         "intermediate size and vocabulary divided by N) without any collective; not a benchmark result")
     ap.add_argument("--graph-body-only", action="store_true",
                     help="debug: at 1 GPU, capture only the layer stack and run the lm_head eagerly (the TP>1 arrangement)")
     ap.add_argument("--fp8-experts", action="store_true",
@@ -97,6 +100,13 @@ def main():
 
     B, ctx, L, bs = args.batch, args.ctx, args.layers, 256
     cfg = air64e_config(L, max(ctx, 4096))
+    if args.emulate_tp > 1:
+        n = args.emulate_tp
+        cfg.num_attention_heads //= n
+        cfg.num_key_value_heads = max(1, cfg.num_key_value_heads // n)
+        cfg.moe_intermediate_size //= n
+        cfg.intermediate_size //= n
+        cfg.vocab_size //= n
     if args.fp8_experts:
         cfg.expert_weight_dtype = "fp8_e4m3"
     torch.set_default_dtype(torch.bfloat16)
@@ -213,7 +223,8 @@ def main():
         attach_pmc_traffic(kernels)
         dom = kernels.get("grouped_gemm_gateup_silu")
         line = {
-            "metric": "decode tokens/sec/GPU GLM-4-MoE bs=32 seq=4096; grouped-GEMM MFMA util %",
+            "metric": ("decode tokens/sec/GPU GLM-4-MoE bs=32 seq=4096; grouped-GEMM MFMA util %" if args.emulate_tp == 1 else
+                       f"SHAPE STUDY ONLY: one rank's kernels at TP={args.emulate_tp} shapes, no collectives"),
             "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,

@@ -406,6 +406,9 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
 #ifndef GLM_SM_CFG_DOWN
 #define GLM_SM_CFG_DOWN 4, 2, 1, 2
 #endif
+    // a single sequence (k + 1 rows, as many active experts): the long unsplit streams win (42 vs 49 us); from two
+    // sequences on the split config is ahead (74 vs 87 us at bs=2 ... 224 vs 231 us at bs=16; tools/sweep_batch.sh)
+    if (mode == GEMM_GATEUP && p.R <= 16) return launch_cfg<GEMM_GATEUP, 4, 1, 2, 2>(p, st);
     if (mode == GEMM_GATEUP) return launch_cfg<GEMM_GATEUP, GLM_SM_CFG_GATEUP>(p, st);
     if (mode == GEMM_DOWN) return launch_cfg<GEMM_DOWN, GLM_SM_CFG_DOWN>(p, st);
     // dense projection: choose the K-split so that the grid covers the chip
