@@ -34,6 +34,20 @@
 #define GLM_FA_NW 4
 #endif
 
+// GLM_FA_STAMP=1 (timing study only): wave 0 of workgroup 0 accumulates s_memtime deltas per loop segment
+#ifndef GLM_FA_LAZYMAX
+#define GLM_FA_LAZYMAX 1
+#endif
+#ifndef GLM_FA_STAMP
+#define GLM_FA_STAMP 0
+#endif
+#if GLM_FA_STAMP
+__device__ unsigned long long g_fa_stamps[16];
+#define FA_T(i) do { unsigned long long t_ = __builtin_readcyclecounter(); if (i) tacc[(i) - 1] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define FA_T(i) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int FA_HD = 128, FA_ROWB = 256;
@@ -207,15 +221,16 @@ __global__ __launch_bounds__(FA_NT, 2) void prefill_attn_kernel(
                         ((pp & 1) << 3);
     }
 
-    f32x4_t acc[FA_QT][8];
-    float m_run[FA_QT], l_run[FA_QT];
+    f32x4_t acc[FA_QT][8], acc_l[FA_QT];
+    float m_run[FA_QT], m_thr[FA_QT];  // softmax reference point (log2 domain) and m_run + 8
     int jmax[FA_QT];  // last visible key of this lane's query row, per tile
 #pragma unroll
     for (int qt = 0; qt < FA_QT; ++qt) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[qt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        acc_l[qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         m_run[qt] = -INFINITY;
-        l_run[qt] = 0.f;
+        m_thr[qt] = -INFINITY;
         jmax[qt] = qi[qt] + off;
     }
 
@@ -285,31 +300,46 @@ __global__ __launch_bounds__(FA_NT, 2) void prefill_attn_kernel(
                     if (j > jmax[qt] || j >= lk) s[tt][r] = -INFINITY;
                 }
         }
-        // row maximum over this lane's 8 keys, then over the four 16-lane groups that share a query column
-        // (VALU lane swaps, no LDS trip).  One asm block: hipcc pads every separate asm VALU op with an s_nop.
-        float mloc, mtmp;
-        asm("v_max3_f32 %0, %2, %3, %4\n\t"
-            "v_max3_f32 %0, %0, %5, %6\n\t"
-            "v_max3_f32 %0, %0, %7, %8\n\t"
-            "v_max_f32 %0, %0, %9\n\t"
-            "v_mov_b32 %1, %0\n\t"
-            "s_nop 1\n\t"
-            "v_permlane16_swap_b32 %0, %1\n\t"
-            "v_max_f32 %0, %0, %1\n\t"
-            "v_mov_b32 %1, %0\n\t"
-            "s_nop 1\n\t"
-            "v_permlane32_swap_b32 %0, %1\n\t"
-            "v_max_f32 %0, %0, %1"
-            : "=&v"(mloc), "=&v"(mtmp)
+        // Lazy maximum: the reference point m_run only has to keep exp2 in range, not to be the exact running maximum.
+        // Fast path (almost every unit after the first): every score of the slab is within 8 (log2 units) of m_run, so
+        // p = exp2(s*c - m_run) <= 256 and nothing is rescaled — the lane-local maximum and one wave vote decide it.
+        // Slow path: exact row maximum over the four 16-lane groups that share a query column (VALU lane swaps, one
+        // asm block: hipcc pads every separate asm VALU op with an s_nop), new reference point, rescale.
+        float mloc;
+        asm("v_max3_f32 %0, %1, %2, %3\n\t"
+            "v_max3_f32 %0, %0, %4, %5\n\t"
+            "v_max3_f32 %0, %0, %6, %7\n\t"
+            "v_max_f32 %0, %0, %8"
+            : "=&v"(mloc)
             : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][3]), "v"(s[1][0]), "v"(s[1][1]), "v"(s[1][2]),
               "v"(s[1][3]));
-        const float ms = mloc * scale_log2e;
-        const float m_new = ms > m_run[qt] ? ms : m_run[qt];  // neither side is NaN-quieted: v_cmp + v_cndmask
-        // a row with nothing visible yet keeps m_new = -inf (only possible on a masked slab): use 0 as the
-        // reference point there so that exp2(-inf - 0) = 0 and no NaN appears
-        float m_use = m_new;
-        if (need_mask) m_use = m_new == -INFINITY ? 0.f : m_new;
-        float psum = 0.f;
+        float ms = mloc * scale_log2e;
+        float m_use = m_run[qt];
+        if (need_mask || !GLM_FA_LAZYMAX || !__all(ms <= m_thr[qt])) {
+            float mtmp;
+            asm("v_mov_b32 %1, %0\n\t"
+                "s_nop 1\n\t"
+                "v_permlane16_swap_b32 %0, %1\n\t"
+                "v_max_f32 %0, %0, %1\n\t"
+                "v_mov_b32 %1, %0\n\t"
+                "s_nop 1\n\t"
+                "v_permlane32_swap_b32 %0, %1\n\t"
+                "v_max_f32 %0, %0, %1"
+                : "+v"(ms), "=&v"(mtmp));
+            const float m_new = ms > m_run[qt] ? ms : m_run[qt];  // neither side is NaN-quieted: v_cmp + v_cndmask
+            // a row with nothing visible yet keeps m_new = -inf (only possible on a masked slab): use 0 as the
+            // reference point there so that exp2(-inf - 0) = 0 and no NaN appears
+            m_use = m_new;
+            if (need_mask) m_use = m_new == -INFINITY ? 0.f : m_new;
+            if (__any(m_new > m_run[qt])) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_use);
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) acc[qt][dt] *= alpha;
+                acc_l[qt] *= alpha;
+            }
+            m_run[qt] = m_new;
+            m_thr[qt] = m_new + 8.0f;
+        }
         bf16x8_t pf;
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
@@ -317,22 +347,16 @@ __global__ __launch_bounds__(FA_NT, 2) void prefill_attn_kernel(
             for (int r = 0; r < 4; ++r) {
                 const float arg = fmaf(s[tt][r], scale_log2e, -m_use);
                 const float pv = (GLM_FA_ABLATE & 1) ? arg : __builtin_amdgcn_exp2f(arg);
-                psum += pv;
                 pf[4 * tt + r] = (__bf16)pv;
             }
-        // rescale only when some row's maximum actually grew (wave-uniform; after the first few
-        // tiles it rarely does)
-        float alpha = 1.0f;
-        if (__any(m_new > m_run[qt])) {
-            alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_use);
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt) acc[qt][dt] *= alpha;
-        }
-        l_run[qt] = l_run[qt] * alpha + psum;
-        m_run[qt] = m_new;
         return pf;
     };
+    // the softmax denominator rides on the matrix pipe: a ones fragment as the A operand gives, in every row of the
+    // 16x16 result, the column sums of P^T over all 32 keys of the slab (bf16-rounded p, as used in the numerator)
+    const u32x4_t ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_u);
     auto pv_mfma = [&](bf16x8_t pf, int qt) {
+        acc_l[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, acc_l[qt], 0, 0, 0);
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) {
             const u32x4_t vv = {vf[dt][0][0], vf[dt][0][1], vf[dt][1][0], vf[dt][1][1]};
@@ -368,41 +392,57 @@ __global__ __launch_bounds__(FA_NT, 2) void prefill_attn_kernel(
         auto live = [&](int kbase, int qt) -> bool {
             return kbase <= qbase + (16 * FA_QT) * wid + 16 * qt + 15 + off && kbase < lk;
         };
+#if GLM_FA_STAMP
+        unsigned long long tacc[16] = {}, tprev = 0;
+#endif
         for (int t = 0; t < ntiles; ++t) {
             const int kb0 = t * FA_BK;
             bf16x8_t pf;
+            FA_T(0);
             // ---- unit (slab 0, q0): S(slab 0, q1) goes to the matrix pipe first, then K of slab 1 and V of
             // slab 0 are fetched while the softmax runs
             if (live(kb0, 1)) s_mfma(sb, 1);
             __builtin_amdgcn_sched_barrier(0);
+            FA_T(1);  // 0: S issue
             FA_READ_V(0);
             FA_READ_K(1);
             if (t >= 1 && t + 1 < ntiles) stage_slot((t + 1) & 1, t + 1, 2);
+            FA_T(2);  // 1: LDS read + DMA issue
             if (live(kb0, 0)) pf = softmax(sa, kb0, 0);
+            FA_T(3);  // 2: softmax
             asm volatile("s_waitcnt lgkmcnt(8)" : FA_V_REGS : : "memory");  // V landed, K may be in flight
+            FA_T(4);  // 3: V wait
             if (live(kb0, 0)) pv_mfma(pf, 0);
             __builtin_amdgcn_sched_barrier(0);
+            FA_T(5);  // 4: PV issue
             // ---- unit (slab 0, q1)
             asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
+            FA_T(6);  // 5: K wait
             if (live(kb0 + 32, 0)) s_mfma(sa, 0);  // S(slab 1, q0)
             __builtin_amdgcn_sched_barrier(0);
             if (t >= 1 && t + 1 < ntiles) stage_slot((t + 1) & 1, t + 1, 3);
+            FA_T(7);  // 6: S issue + DMA
             if (live(kb0, 1)) {
                 pf = softmax(sb, kb0, 1);
                 pv_mfma(pf, 1);
             }
             __builtin_amdgcn_sched_barrier(0);
+            FA_T(8);  // 7: softmax + PV
             // ---- unit (slab 1, q0): V of slab 1 is the last LDS read of this buffer
             if (live(kb0 + 32, 1)) s_mfma(sb, 1);  // S(slab 1, q1)
             __builtin_amdgcn_sched_barrier(0);
             FA_READ_V(1);
+            FA_T(9);  // 8: S issue + V read issue
             asm volatile("s_waitcnt lgkmcnt(0)" : FA_V_REGS : : "memory");
+            FA_T(10);  // 9: V wait
             const bool more = t + 1 < ntiles;
             if (more) {
                 // tile t+1 was issued a whole tile ago; after the barrier every wave is done with this
                 // buffer, which tile t+2 may then overwrite
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                FA_T(11);  // 10: DMA wait
                 if (!(GLM_FA_ABLATE & 2)) __builtin_amdgcn_s_barrier();
+                FA_T(12);  // 11: barrier
                 if (t + 2 < ntiles) stage_slot(t & 1, t + 2, 0);
                 const int flip = (t & 1) ? -FA_STAGE : FA_STAGE;
 #pragma unroll
@@ -410,12 +450,14 @@ __global__ __launch_bounds__(FA_NT, 2) void prefill_attn_kernel(
 #pragma unroll
                 for (int dt = 0; dt < 8; ++dt) v_abs[dt] += flip;
                 FA_READ_K(0);
+                FA_T(13);  // 12: DMA issue + K read issue
             }
             if (live(kb0 + 32, 0)) {
                 pf = softmax(sa, kb0 + 32, 0);
                 pv_mfma(pf, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            FA_T(14);  // 13: softmax + PV
             // ---- unit (slab 1, q1)
             if (more) {
                 asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
@@ -423,12 +465,20 @@ __global__ __launch_bounds__(FA_NT, 2) void prefill_attn_kernel(
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 2 < ntiles) stage_slot(t & 1, t + 2, 1);
             }
+            FA_T(15);  // 14: K wait + S issue + DMA
             if (live(kb0 + 32, 1)) {
                 pf = softmax(sb, kb0 + 32, 1);
                 pv_mfma(pf, 1);
             }
             __builtin_amdgcn_sched_barrier(0);
+            FA_T(16);  // 15: softmax + PV
         }
+#if GLM_FA_STAMP
+        if (blockIdx.x == 0 && tid == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) g_fa_stamps[i] = tacc[i];
+        }
+#endif
     }
 #undef FA_READ_K
 #undef FA_READ_V
@@ -437,9 +487,7 @@ __global__ __launch_bounds__(FA_NT, 2) void prefill_attn_kernel(
 
 #pragma unroll
     for (int qt = 0; qt < FA_QT; ++qt) {
-        float l = l_run[qt];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        const float l = acc_l[qt][0];  // already summed over the four lane groups by the MFMA
         if (qi[qt] < lq) {
             const float inv = l > 0.f ? 1.0f / l : 0.f;
             bf16_t* orow = out + ((int64_t)(q0 + qi[qt]) * nh + head) * FA_HD;
@@ -513,3 +561,10 @@ extern "C" int glm_debug_prefill_attn_occupancy(int lds_bytes) {
                                                                 (size_t)lds_bytes);
     return e == hipSuccess ? nb : -(int)e;
 }
+
+#if GLM_FA_STAMP
+// timing study only: per-segment cycle sums of wave 0 of workgroup 0 (the longest one), [16]
+extern "C" int glm_debug_prefill_attn_stamps(unsigned long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fa_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
