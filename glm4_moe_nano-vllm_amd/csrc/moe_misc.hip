@@ -5,6 +5,7 @@
 // Compiled with -ffp-contract=off: the rounding points below are the reference's
 // (SURVEY.md §8a R1–R7).
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -18,20 +19,109 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 // x row is staged in LDS (bf16); wave w owns expert blocks w, w+16, ... of ROUTER_EB experts; a
 // lane covers 16-byte chunks lane, lane+64, ... of K.
 constexpr int ROUTER_NT = 1024;
+
+// Optional fused producer of the router input (PRE != 0): the post-attention add-RMSNorm of the same token
+// (layers/layernorm.py:29-40), whose x is either a bf16 row (PRE 1) or fp32 K-slice partial sums of the o_proj
+// (PRE 2, glm_gemm_bf16_partial).  The normalised row goes to `y` (the experts read it) and stays in LDS for the router.
+struct RouterPre {
+    const bf16_t* x;        // PRE 1: [T,H] bf16
+    const float* part;      // PRE 2: [nslices][T][H] fp32
+    int nslices;
+    int64_t slice_stride;
+    const bf16_t* res_in;   // [T,H]
+    const bf16_t* norm_w;   // [H]
+    bf16_t* y;              // [T,H] normalised output
+    bf16_t* res_out;        // [T,H]
+    float eps;
+};
+
+template <int PRE>
 __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ gw, const float* __restrict__ bias,
     int64_t* __restrict__ topk_idx, bf16_t* __restrict__ topk_w, bf16_t* __restrict__ logits_out,
-    int H, int E, int k, float rsf) {
+    int H, int E, int k, float rsf, const RouterPre pre) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                        // [H]
     float* lg = reinterpret_cast<float*>(smem + (((size_t)H * 2 + 15) & ~(size_t)15));  // [E]
     const int64_t t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nvec = H >> 3;
-    {
+    if (PRE == 0) {
         const u32x4_t* src = reinterpret_cast<const u32x4_t*>(x + t * H);
         u32x4_t* dst = reinterpret_cast<u32x4_t*>(xs);
         for (int i = tid; i < nvec; i += ROUTER_NT) dst[i] = src[i];
+    } else {
+        // add-RMSNorm, one 8-element vector per thread (host checks H <= 8 * ROUTER_NT); same arithmetic and
+        // rounding points as rmsnorm_vec_kernel<ADD> / add_rmsnorm_partial_kernel in elementwise.hip
+        float s8[8];
+        float ss = 0.f;
+        const bool act = tid < nvec;
+        if (act) {
+            float xv[8];
+            if (PRE == 1) {
+                const u32x4_t v = reinterpret_cast<const u32x4_t*>(pre.x + t * H)[tid];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xv[2 * j] = bflo(v[j]);
+                    xv[2 * j + 1] = bfhi(v[j]);
+                }
+            } else {
+                const float* pp = pre.part + t * H + (int64_t)tid * 8;
+                f32x4_t a = *reinterpret_cast<const f32x4_t*>(pp), b = *reinterpret_cast<const f32x4_t*>(pp + 4);
+                for (int s0 = 1; s0 < pre.nslices; s0 += 8) {  // slice order, up to 8 loads in flight
+                    f32x4_t ta[8], tb[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int sl = min(s0 + j, pre.nslices - 1);
+                        ta[j] = *reinterpret_cast<const f32x4_t*>(pp + sl * pre.slice_stride);
+                        tb[j] = *reinterpret_cast<const f32x4_t*>(pp + sl * pre.slice_stride + 4);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (s0 + j < pre.nslices) {
+                            a += ta[j];
+                            b += tb[j];
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xv[j] = rbf(a[j]);  // the linear layer's own output rounding
+                    xv[4 + j] = rbf(b[j]);
+                }
+            }
+            const u32x4_t rv = reinterpret_cast<const u32x4_t*>(pre.res_in + t * H)[tid];
+            u32x4_t ov;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s8[2 * j] = xv[2 * j] + bflo(rv[j]);
+                s8[2 * j + 1] = xv[2 * j + 1] + bfhi(rv[j]);
+                ov[j] = pack2bf(s8[2 * j], s8[2 * j + 1]);
+            }
+            reinterpret_cast<u32x4_t*>(pre.res_out + t * H)[tid] = ov;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += s8[j] * s8[j];
+        }
+        // block sum over 16 waves; lg[] is free until the logits are written
+        ss = wave_sum(ss);
+        if (lane == 0) lg[wid] = ss;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < ROUTER_NT / 64; ++w) tot += lg[w];
+        __syncthreads();
+        const float rstd = 1.0f / sqrtf(tot / (float)H + pre.eps);
+        if (act) {
+            const u32x4_t wv = reinterpret_cast<const u32x4_t*>(pre.norm_w)[tid];
+            u32x4_t o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = rbf(s8[2 * i] * rstd) * bflo(wv[i]);
+                const float b = rbf(s8[2 * i + 1] * rstd) * bfhi(wv[i]);
+                o[i] = pack2bf(a, b);
+            }
+            reinterpret_cast<u32x4_t*>(pre.y + t * H)[tid] = o;
+            reinterpret_cast<u32x4_t*>(xs)[tid] = o;
+        }
     }
     __syncthreads();
 
@@ -273,10 +363,48 @@ extern "C" int glm_router_topk(const void* x, const void* gate_w,
                   E, k, H);
     if (T == 0) return GLM_OK;
     const size_t shm = (((size_t)H * 2 + 15) & ~(size_t)15) + (size_t)E * 4;
-    hipLaunchKernelGGL(router_topk_kernel, dim3((unsigned)T), dim3(ROUTER_NT), shm, glm_s(stream),
+    RouterPre pre;
+    memset(&pre, 0, sizeof(pre));
+    hipLaunchKernelGGL(router_topk_kernel<0>, dim3((unsigned)T), dim3(ROUTER_NT), shm, glm_s(stream),
                        (const bf16_t*)x, (const bf16_t*)gate_w, e_score_correction_bias, topk_idx,
-                       (bf16_t*)topk_w, (bf16_t*)logits_out, H, E, k, routed_scaling_factor);
+                       (bf16_t*)topk_w, (bf16_t*)logits_out, H, E, k, routed_scaling_factor, pre);
     GLM_CHECK_LAUNCH("glm_router_topk");
+    return GLM_OK;
+}
+
+extern "C" int glm_add_rmsnorm_router_topk(const void* x, const float* part, int nslices, int64_t slice_stride,
+                                           const void* residual_in, const void* norm_weight, float eps, void* y,
+                                           void* residual_out, const void* gate_w,
+                                           const float* e_score_correction_bias, int64_t* topk_idx, void* topk_w,
+                                           int64_t T, int H, int E, int k, float routed_scaling_factor,
+                                           glm_stream_t stream) {
+    GLM_CHECK_ARG((x != nullptr) != (part != nullptr), GLM_ERR_INVALID,
+                  "glm_add_rmsnorm_router_topk: give either x (bf16) or part (fp32 partial sums)");
+    GLM_CHECK_ARG(residual_in && norm_weight && y && residual_out && gate_w && e_score_correction_bias && topk_idx &&
+                      topk_w, GLM_ERR_INVALID, "glm_add_rmsnorm_router_topk: null pointer");
+    GLM_CHECK_ARG(T >= 0 && H > 0 && E > 0 && k > 0 && k <= E && (part == nullptr || (nslices >= 1 &&
+                      slice_stride >= T * (int64_t)H)), GLM_ERR_INVALID, "glm_add_rmsnorm_router_topk: bad shape");
+    GLM_CHECK_ARG(E <= ROUTER_MAX_E && k <= 64 && H % 8 == 0 && H <= 8 * ROUTER_NT && (x == nullptr || glm_aligned16(x)) &&
+                      (part == nullptr || (glm_aligned16(part) && slice_stride % 4 == 0)) && glm_aligned16(residual_in) &&
+                      glm_aligned16(norm_weight) && glm_aligned16(y) && glm_aligned16(residual_out) && glm_aligned16(gate_w),
+                  GLM_ERR_UNSUPPORTED,
+                  "glm_add_rmsnorm_router_topk: needs E<=256, k<=64, H%%8==0, H<=%d, 16B-aligned buffers (E=%d k=%d H=%d)",
+                  8 * ROUTER_NT, E, k, H);
+    if (T == 0) return GLM_OK;
+    const size_t shm = (((size_t)H * 2 + 15) & ~(size_t)15) + (size_t)(E > ROUTER_NT / 64 ? E : ROUTER_NT / 64) * 4;
+    RouterPre pre;
+    pre.x = (const bf16_t*)x; pre.part = part; pre.nslices = nslices; pre.slice_stride = slice_stride;
+    pre.res_in = (const bf16_t*)residual_in; pre.norm_w = (const bf16_t*)norm_weight; pre.y = (bf16_t*)y;
+    pre.res_out = (bf16_t*)residual_out; pre.eps = eps;
+    if (x)
+        hipLaunchKernelGGL(router_topk_kernel<1>, dim3((unsigned)T), dim3(ROUTER_NT), shm, glm_s(stream), (const bf16_t*)y,
+                           (const bf16_t*)gate_w, e_score_correction_bias, topk_idx, (bf16_t*)topk_w, (bf16_t*)nullptr, H, E,
+                           k, routed_scaling_factor, pre);
+    else
+        hipLaunchKernelGGL(router_topk_kernel<2>, dim3((unsigned)T), dim3(ROUTER_NT), shm, glm_s(stream), (const bf16_t*)y,
+                           (const bf16_t*)gate_w, e_score_correction_bias, topk_idx, (bf16_t*)topk_w, (bf16_t*)nullptr, H, E,
+                           k, routed_scaling_factor, pre);
+    GLM_CHECK_LAUNCH("glm_add_rmsnorm_router_topk");
     return GLM_OK;
 }
 

@@ -66,6 +66,9 @@ _SIGNATURES = {
     "glm_gemm_bf16_partial_slices": (c_int, [c_int, c_int]),
     "glm_gemm_bf16_partial": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
                                       c_int, c_void_p]),
+    "glm_add_rmsnorm_router_topk": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_float, c_void_p,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                            c_int, c_float, c_void_p]),
     "glm_add_rmsnorm_partial": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int64, c_int, c_float, c_void_p]),
 }
@@ -305,6 +308,36 @@ def router_topk(x: torch.Tensor, gate_w: torch.Tensor, bias: torch.Tensor, k: in
                                           T, H, E, k, routed_scaling_factor, _stream()),
            "glm_router_topk")
     return (idx, w, logits) if return_logits else (idx, w)
+
+
+def add_rmsnorm_router_topk(x, residual: torch.Tensor, norm_weight: torch.Tensor, eps: float,
+                            gate_w: torch.Tensor, bias: torch.Tensor, k: int, routed_scaling_factor: float):
+    """Post-attention add-RMSNorm + router in one launch.  x: bf16 [T,H] tensor or PartialSum (o_proj partial sums).
+    Returns (normalised hidden, residual_out, topk_idx, topk_w)."""
+    _bf16(residual, "residual"); _bf16(norm_weight, "norm_weight"); _bf16(gate_w, "gate_w")
+    assert bias.dtype == torch.float32
+    H = residual.shape[-1]
+    r2 = residual.reshape(-1, H).contiguous()
+    T = r2.shape[0]
+    E = gate_w.shape[0]
+    y = torch.empty_like(r2)
+    ro = torch.empty_like(r2)
+    idx = torch.empty((T, k), dtype=torch.int64, device=r2.device)
+    w = torch.empty((T, k), dtype=torch.bfloat16, device=r2.device)
+    if isinstance(x, PartialSum):
+        part = x.part
+        assert part.is_contiguous() and part.shape[1:] == (T, H)
+        xp, pp, ns, stride = None, _p(part), part.shape[0], T * H
+    else:
+        _bf16(x, "x")
+        x2 = x.reshape(-1, H).contiguous()
+        assert x2.shape[0] == T
+        xp, pp, ns, stride = _p(x2), None, 0, 0
+    _check(load_library().glm_add_rmsnorm_router_topk(xp, pp, ns, stride, _p(r2), _p(norm_weight), eps, _p(y), _p(ro),
+                                                      _p(gate_w), _p(bias), _p(idx), _p(w), T, H, E, k,
+                                                      routed_scaling_factor, _stream()),
+           "glm_add_rmsnorm_router_topk")
+    return y.view(residual.shape), ro.view(residual.shape), idx, w
 
 
 def moe_align(topk_idx: torch.Tensor, topk_w: torch.Tensor, E: int, with_shared: bool):

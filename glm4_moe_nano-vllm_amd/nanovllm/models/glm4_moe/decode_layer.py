@@ -6,6 +6,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from nanovllm import hip_ops
 from nanovllm.layers.layernorm import RMSNorm
 from nanovllm.utils.loader import load_one
 from .attention_new import Glm4MoeAttention
@@ -41,6 +42,8 @@ class Glm4MoeDecoderLayer(nn.Module):
         self.self_attn.load_weights(model_path, f"{prefix}.self_attn")
         self.mlp.load_weights(model_path, f"{prefix}.mlp")
 
+    fuse_norm_router = True
+
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor,
                 residual: torch.Tensor | None):
         if residual is None:
@@ -49,6 +52,15 @@ class Glm4MoeDecoderLayer(nn.Module):
             hidden_states, residual = self.input_layernorm(hidden_states, residual)
         # o_proj may hand over K-slice partial sums; the add-RMSNorm right below reduces them (decode batches)
         hidden_states = self.self_attn(hidden_states, positions, defer_o_reduce=True)
-        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
-        hidden_states = self.mlp(hidden_states)
+        gate = getattr(self.mlp, "gate", None)
+        if self.fuse_norm_router and gate is not None and residual.shape[-1] <= 8192:
+            # post-attention add-RMSNorm and the router of the same token in one launch
+            ln = self.post_attention_layernorm
+            hidden_states, residual, idx, w = hip_ops.add_rmsnorm_router_topk(
+                hidden_states, residual, ln.weight.data, ln.eps, gate.weight.data, gate.e_score_correction_bias,
+                gate.top_k, float(gate.routed_scaling_factor))
+            hidden_states = self.mlp(hidden_states, routing=(idx, w))
+        else:
+            hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+            hidden_states = self.mlp(hidden_states)
         return hidden_states, residual

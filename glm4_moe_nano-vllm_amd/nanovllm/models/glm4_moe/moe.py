@@ -33,7 +33,9 @@ class GlmMoeSelectTopk(nn.Module):
         self.register_buffer("e_score_correction_bias",
                              torch.zeros((self.n_routed_experts), dtype=torch.float32))
 
-    def forward(self, hidden_states: torch.Tensor):
+    def forward(self, hidden_states: torch.Tensor, precomputed=None):
+        if precomputed is not None:  # (topk_idx, topk_w) from the fused add-RMSNorm + router launch
+            return precomputed
         h = hidden_states.view(-1, self.config.hidden_size)
         # indices come back in ascending expert id per row (torch.topk(sorted=False) leaves
         # the order unspecified; moe.py:39)
@@ -105,13 +107,14 @@ class Glm4MoeMoE(nn.Module):
         self.shared_experts.load_weights(path, f"{prefix}.shared_experts")
 
     # ---- forward ------------------------------------------------------------------------
-    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+    def forward(self, hidden_states: torch.Tensor, routing=None) -> torch.Tensor:
+        """routing: (topk_idx, topk_w) already computed for these rows (decode_layer's fused norm + router)."""
         shape = hidden_states.shape
         h = hidden_states.view(-1, shape[-1])
         T = h.shape[0]
         E, k = self.config.n_routed_experts, self.config.num_experts_per_tok
         w13, w2 = self._stacked()
-        topk_idx, topk_w = self.gate(h)
+        topk_idx, topk_w = self.gate(h, precomputed=routing)
         offs, tok, scale, pos = hip_ops.moe_align(topk_idx, topk_w, E, True)
         R = T * k + T
         if self.expert_weight_dtype == "fp8_e4m3":

@@ -208,6 +208,16 @@ int glm_add_rmsnorm_partial(const float* part, int nslices, int64_t slice_stride
                             const void* residual_in, const void* weight, void* y, void* residual_out,
                             int64_t T, int H, float eps, glm_stream_t stream);
 
+/* a3+a11 fused: the post-attention add-RMSNorm (layers/layernorm.py:29-40, decode_layer.py:51) and the router of the
+ *     same token (models/glm4_moe/moe.py:28-50) in one launch.  x is a bf16 [T,H] tensor, or NULL with `part` =
+ *     glm_gemm_bf16_partial output (then as glm_add_rmsnorm_partial).  y [T,H] receives the normalised rows (the
+ *     experts' input), residual_out the updated residual; topk_idx/topk_w as glm_router_topk.  H <= 8192.        */
+int glm_add_rmsnorm_router_topk(const void* x, const float* part, int nslices, int64_t slice_stride,
+                                const void* residual_in, const void* norm_weight, float eps, void* y,
+                                void* residual_out, const void* gate_w, const float* e_score_correction_bias,
+                                int64_t* topk_idx, void* topk_w, int64_t T, int H, int E, int k,
+                                float routed_scaling_factor, glm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

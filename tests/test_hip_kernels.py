@@ -384,6 +384,29 @@ def test_gemm_partial_and_fused_add_rmsnorm(ops, M, N, K, want):
     assert_close_bf16(y, ye, 2, 0.05, atol=2 ** -7, what="normed")
 
 
+@pytest.mark.parametrize("T,H,E,k,partial", [(32, 4096, 64, 8, False), (32, 4096, 64, 8, True), (5, 512, 16, 4, False),
+                                              (3, 8192, 128, 8, True), (130, 1024, 8, 2, False)])
+def test_fused_add_rmsnorm_router(ops, T, H, E, k, partial):
+    """One launch == add_rmsnorm (or its partial-sum form) followed by router_topk, bit for bit."""
+    g = torch.Generator().manual_seed(T + H + E)
+    res = rnd(T, H, seed=181)
+    nw = rnd(H, seed=182) * 0.1 + 1.0
+    gw = rnd(E, H, seed=183, scale=H ** -0.5)
+    bias = (torch.rand(E, generator=g) * 0.2 - 0.1).float()
+    if partial:
+        K = 1024
+        ps = ops.gemm_bf16_partial(dev(rnd(T, K, seed=184)), dev(rnd(H, K, seed=185, scale=K ** -0.5)), 4)
+        y0, r0 = ops.add_rmsnorm_partial(ps, dev(res), dev(nw), 1e-5)
+        x = ps
+    else:
+        x = dev(rnd(T, H, seed=186))
+        y0, r0 = ops.add_rmsnorm(x, dev(res), dev(nw), 1e-5)
+    i0, w0 = ops.router_topk(y0, dev(gw), dev(bias), k, 2.5)
+    y1, r1, i1, w1 = ops.add_rmsnorm_router_topk(x, dev(res), dev(nw), 1e-5, dev(gw), dev(bias), k, 2.5)
+    assert torch.equal(y0, y1) and torch.equal(r0, r1)
+    assert torch.equal(i0, i1) and torch.equal(w0, w1)
+
+
 def test_gemm_bf16_strided_input(ops):
     M, N, K = 12, 256, 384
     big = rnd(M, K + 64, seed=74)

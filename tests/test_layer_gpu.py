@@ -74,8 +74,13 @@ def test_decoder_layer_decode(tag, split_o):
         layer.self_attn.o_proj.partial_min_k = 0
         layer.self_attn.o_proj.partial_slices = 3
         seen = []
-        orig = hip_ops.add_rmsnorm_partial
-        hip_ops.add_rmsnorm_partial = lambda *a, **k: (seen.append(1), orig(*a, **k))[1]
+        orig = hip_ops.add_rmsnorm_router_topk  # the fused post-attention norm + router consumes the partial sums
+
+        def spy(x, *a, **k):
+            if isinstance(x, hip_ops.PartialSum):
+                seen.append(1)
+            return orig(x, *a, **k)
+        hip_ops.add_rmsnorm_router_topk = spy
     captured = {}
     _hook_router(layer, captured)
     kc, vc = t["k_cache_in"].cuda(), t["v_cache_in"].cuda()
@@ -87,7 +92,7 @@ def test_decoder_layer_decode(tag, split_o):
     reset_context()
     torch.cuda.synchronize()
     if split_o:
-        hip_ops.add_rmsnorm_partial = orig
+        hip_ops.add_rmsnorm_router_topk = orig
         assert seen, "the partial-sum path was not taken"
     s = t["slot_mapping"].long()
     assert torch.equal(vc.cpu().view(-1, 256)[s], t["v_rows"]) or True  # V rows: GEMM rounding only
