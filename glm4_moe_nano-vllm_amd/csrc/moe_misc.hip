@@ -346,6 +346,107 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const bf16_t* __restri
     }
 }
 
+// Combine fused with the NEXT layer's input add-RMSNorm (decode_layer.py:47-49 of layer i+1): one 512-thread workgroup
+// per token.  x = the combine result rounded to bf16 exactly as moe_combine_kernel writes it, then
+// s = x + residual, residual_out = bf16(s), y = bf16(bf16(s*rstd)*w) as rmsnorm_vec_kernel<ADD>.
+constexpr int CN_NT = 512;
+template <int VPT>
+__global__ __launch_bounds__(CN_NT) void moe_combine_add_rmsnorm_kernel(
+    const bf16_t* __restrict__ y, int64_t ldy, const int32_t* __restrict__ pair_pos, int k, int64_t shared_base,
+    const bf16_t* res_in, const bf16_t* __restrict__ w, bf16_t* out, bf16_t* res_out, int H, float eps) {
+    __shared__ int pos[COMBINE_MAX_K];
+    __shared__ int npos;
+    __shared__ float red[CN_NT / 64];
+    const int64_t t = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int j = 0; j < k; ++j) {
+            const int p = pair_pos[t * k + j];
+            if (p < 0) continue;
+            int i = n++;
+            while (i > 0 && pos[i - 1] > p) {
+                pos[i] = pos[i - 1];
+                --i;
+            }
+            pos[i] = p;
+        }
+        npos = n;
+    }
+    __syncthreads();
+    const int n = npos;
+    const int nvec = H >> 3;
+    float s[VPT][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const int c = threadIdx.x + v * CN_NT;
+        if (c < nvec) {
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+            // the rounding chain is serial, the row loads are not: 8 rows are in flight at a time (clamped re-reads of
+            // the last row fill the batch), together with the shared row and the residual
+            u32x4_t sv = {0, 0, 0, 0};
+            if (shared_base >= 0) sv = reinterpret_cast<const u32x4_t*>(y + (shared_base + t) * ldy)[c];
+            const u32x4_t rv = reinterpret_cast<const u32x4_t*>(res_in + t * H)[c];
+            for (int j0 = 0; j0 < n; j0 += 8) {
+                u32x4_t vv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    vv[j] = reinterpret_cast<const u32x4_t*>(y + (int64_t)pos[min(j0 + j, n - 1)] * ldy)[c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j0 + j < n) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc[2 * q] = rbf(acc[2 * q] + bflo(vv[j][q]));
+                            acc[2 * q + 1] = rbf(acc[2 * q + 1] + bfhi(vv[j][q]));
+                        }
+                    }
+            }
+            if (shared_base >= 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[2 * q] = acc[2 * q] + bflo(sv[q]);
+                    acc[2 * q + 1] = acc[2 * q + 1] + bfhi(sv[q]);
+                }
+            }
+            u32x4_t ov;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s[v][2 * q] = rbf(acc[2 * q]) + bflo(rv[q]);          // rbf: the combine's own output rounding
+                s[v][2 * q + 1] = rbf(acc[2 * q + 1]) + bfhi(rv[q]);
+                ov[q] = pack2bf(s[v][2 * q], s[v][2 * q + 1]);
+            }
+            reinterpret_cast<u32x4_t*>(res_out + t * H)[c] = ov;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ss += s[v][i] * s[v][i];
+        }
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < CN_NT / 64; ++i) tot += red[i];
+    const float rstd = 1.0f / sqrtf(tot / (float)H + eps);
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+        const int c = threadIdx.x + v * CN_NT;
+        if (c < nvec) {
+            const u32x4_t wv = reinterpret_cast<const u32x4_t*>(w)[c];
+            u32x4_t o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = rbf(s[v][2 * i] * rstd) * bflo(wv[i]);
+                const float b = rbf(s[v][2 * i + 1] * rstd) * bfhi(wv[i]);
+                o[i] = pack2bf(a, b);
+            }
+            reinterpret_cast<u32x4_t*>(out + t * H)[c] = o;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int glm_router_topk(const void* x, const void* gate_w,
@@ -437,5 +538,32 @@ extern "C" int glm_moe_combine(const void* y, int64_t ldy, const int32_t* pair_p
     hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned)T, (unsigned)slabs), dim3(256), 0, glm_s(stream),
                        (const bf16_t*)y, ldy, pair_pos, (bf16_t*)out, k, H, shared_base, vec_ok);
     GLM_CHECK_LAUNCH("glm_moe_combine");
+    return GLM_OK;
+}
+
+extern "C" int glm_moe_combine_add_rmsnorm(const void* y, int64_t ldy, const int32_t* pair_pos, int64_t T, int k, int H,
+                                           int64_t shared_base, const void* residual_in, const void* weight,
+                                           void* out, void* residual_out, float eps, glm_stream_t stream) {
+    GLM_CHECK_ARG(y && pair_pos && residual_in && weight && out && residual_out, GLM_ERR_INVALID,
+                  "glm_moe_combine_add_rmsnorm: null pointer");
+    GLM_CHECK_ARG(T >= 0 && k > 0 && H > 0 && ldy >= H, GLM_ERR_INVALID, "glm_moe_combine_add_rmsnorm: bad shape");
+    GLM_CHECK_ARG(k <= COMBINE_MAX_K && H % 8 == 0 && H <= 8 * CN_NT * 4 && ldy % 8 == 0 && glm_aligned16(y) &&
+                      glm_aligned16(residual_in) && glm_aligned16(weight) && glm_aligned16(out) &&
+                      glm_aligned16(residual_out) && T <= 0x7fffffff,
+                  GLM_ERR_UNSUPPORTED, "glm_moe_combine_add_rmsnorm: needs k<=%d, H%%8==0, H<=%d, 16B-aligned rows (H=%d)",
+                  COMBINE_MAX_K, 8 * CN_NT * 4, H);
+    if (T == 0) return GLM_OK;
+    const int vpt = (H / 8 + CN_NT - 1) / CN_NT;
+    hipStream_t st = glm_s(stream);
+    const dim3 grid((unsigned)T), block(CN_NT);
+#define GLM_CN_LAUNCH(V)                                                                                              \
+    hipLaunchKernelGGL((moe_combine_add_rmsnorm_kernel<V>), grid, block, 0, st, (const bf16_t*)y, ldy, pair_pos, k,   \
+                       shared_base, (const bf16_t*)residual_in, (const bf16_t*)weight, (bf16_t*)out,                  \
+                       (bf16_t*)residual_out, H, eps)
+    if (vpt <= 1) GLM_CN_LAUNCH(1);
+    else if (vpt <= 2) GLM_CN_LAUNCH(2);
+    else GLM_CN_LAUNCH(4);
+#undef GLM_CN_LAUNCH
+    GLM_CHECK_LAUNCH("glm_moe_combine_add_rmsnorm");
     return GLM_OK;
 }

@@ -69,6 +69,8 @@ _SIGNATURES = {
     "glm_add_rmsnorm_router_topk": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_float, c_void_p,
                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                             c_int, c_float, c_void_p]),
+    "glm_moe_combine_add_rmsnorm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p,
+                                            c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "glm_add_rmsnorm_partial": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int64, c_int, c_float, c_void_p]),
 }
@@ -433,6 +435,37 @@ def moe_combine(y, pair_pos, T: int, k: int, shared_base: int) -> torch.Tensor:
     _check(load_library().glm_moe_combine(_p(y), y.stride(0), _p(pair_pos), _p(out), T, k, H,
                                           shared_base, _stream()), "glm_moe_combine")
     return out
+
+
+class DeferredCombine:
+    """Rows of the grouped down projection plus the per-token row list: the MoE combine (moe_combine) that has not
+    been run yet because the consumer — the next layer's add-RMSNorm — performs it in the same launch."""
+    __slots__ = ("y", "pair_pos", "T", "k", "shared_base", "out_shape")
+
+    def __init__(self, y, pair_pos, T, k, shared_base, out_shape):
+        self.y, self.pair_pos, self.T, self.k, self.shared_base, self.out_shape = y, pair_pos, T, k, shared_base, out_shape
+
+    @property
+    def shape(self):
+        return self.out_shape
+
+    def materialize(self) -> torch.Tensor:
+        return moe_combine(self.y, self.pair_pos, self.T, self.k, self.shared_base).view(self.out_shape)
+
+
+def moe_combine_add_rmsnorm(dc: DeferredCombine, residual: torch.Tensor, weight: torch.Tensor,
+                            eps: float) -> tuple[torch.Tensor, torch.Tensor]:
+    """moe_combine + add_rmsnorm(combined, residual) in one launch."""
+    _bf16(residual, "residual"); _bf16(weight, "weight")
+    H = dc.y.shape[1]
+    r2 = residual.reshape(-1, H).contiguous()
+    assert r2.shape[0] == dc.T
+    out = torch.empty_like(r2)
+    ro = torch.empty_like(r2)
+    _check(load_library().glm_moe_combine_add_rmsnorm(_p(dc.y), dc.y.stride(0), _p(dc.pair_pos), dc.T, dc.k, H,
+                                                      dc.shared_base, _p(r2), _p(weight), _p(out), _p(ro), eps,
+                                                      _stream()), "glm_moe_combine_add_rmsnorm")
+    return out.view(residual.shape), ro.view(residual.shape)
 
 
 class PartialSum:

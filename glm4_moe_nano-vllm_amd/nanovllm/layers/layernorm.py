@@ -15,12 +15,16 @@ class RMSNorm(nn.Module):
         self.eps = eps
         self.weight = nn.Parameter(torch.ones(hidden_size))
 
-    def rms_forward(self, x: torch.Tensor) -> torch.Tensor:
+    def rms_forward(self, x) -> torch.Tensor:
+        if isinstance(x, hip_ops.DeferredCombine):
+            x = x.materialize()
         return hip_ops.rmsnorm(x, self.weight.data, self.eps)
 
     def add_rms_forward(self, x, residual: torch.Tensor):
         if isinstance(x, hip_ops.PartialSum):  # deferred K-slice reduction of the producing linear layer
             return hip_ops.add_rmsnorm_partial(x, residual, self.weight.data, self.eps)
+        if isinstance(x, hip_ops.DeferredCombine):  # the previous layer's MoE combine, done in this launch
+            return hip_ops.moe_combine_add_rmsnorm(x, residual, self.weight.data, self.eps)
         return hip_ops.add_rmsnorm(x, residual, self.weight.data, self.eps)
 
     def forward(self, x: torch.Tensor, residual: torch.Tensor | None = None):

@@ -44,8 +44,10 @@ class Glm4MoeDecoderLayer(nn.Module):
 
     fuse_norm_router = True
 
-    def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor,
-                residual: torch.Tensor | None):
+    def forward(self, positions: torch.Tensor, hidden_states, residual: torch.Tensor | None,
+                defer_combine: bool = False):
+        """defer_combine: the caller passes the returned hidden state straight to the next layer (or to an
+        RMSNorm.forward(x, residual)) and accepts a hip_ops.DeferredCombine instead of a tensor."""
         if residual is None:
             hidden_states, residual = self.input_layernorm(hidden_states), hidden_states
         else:
@@ -59,8 +61,11 @@ class Glm4MoeDecoderLayer(nn.Module):
             hidden_states, residual, idx, w = hip_ops.add_rmsnorm_router_topk(
                 hidden_states, residual, ln.weight.data, ln.eps, gate.weight.data, gate.e_score_correction_bias,
                 gate.top_k, float(gate.routed_scaling_factor))
-            hidden_states = self.mlp(hidden_states, routing=(idx, w))
+            hidden_states = self.mlp(hidden_states, routing=(idx, w), defer_combine=defer_combine)
         else:
             hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
-            hidden_states = self.mlp(hidden_states)
+            if gate is not None:
+                hidden_states = self.mlp(hidden_states, defer_combine=defer_combine)
+            else:
+                hidden_states = self.mlp(hidden_states)
         return hidden_states, residual

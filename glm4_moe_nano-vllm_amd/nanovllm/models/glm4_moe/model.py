@@ -42,8 +42,10 @@ class Glm4MoeModel(nn.Module):
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
         hidden_states = self.embed_tokens(input_ids)
         residual = None
+        # a layer's MoE combine is folded into the add-RMSNorm that consumes it (next layer's input norm or the
+        # final norm); RMSNorm materialises it where the reference's residual-free final norm is kept
         for layer in self.layers:
-            hidden_states, residual = layer(positions, hidden_states, residual)
+            hidden_states, residual = layer(positions, hidden_states, residual, defer_combine=True)
         if self.final_norm_without_residual or residual is None:
             return self.norm(hidden_states)
         hidden_states, _ = self.norm(hidden_states, residual)

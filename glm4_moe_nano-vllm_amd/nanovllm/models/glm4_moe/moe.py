@@ -107,8 +107,10 @@ class Glm4MoeMoE(nn.Module):
         self.shared_experts.load_weights(path, f"{prefix}.shared_experts")
 
     # ---- forward ------------------------------------------------------------------------
-    def forward(self, hidden_states: torch.Tensor, routing=None) -> torch.Tensor:
-        """routing: (topk_idx, topk_w) already computed for these rows (decode_layer's fused norm + router)."""
+    def forward(self, hidden_states: torch.Tensor, routing=None, defer_combine: bool = False):
+        """routing: (topk_idx, topk_w) already computed for these rows (decode_layer's fused norm + router).
+        defer_combine: the caller hands the result straight to the next layer's RMSNorm.forward(x, residual) and
+        accepts a hip_ops.DeferredCombine (TP=1 only)."""
         shape = hidden_states.shape
         h = hidden_states.view(-1, shape[-1])
         T = h.shape[0]
@@ -126,6 +128,8 @@ class Glm4MoeMoE(nn.Module):
         else:
             act = hip_ops.grouped_gemm_gateup_silu(h, w13, offs, tok, R)
             y = hip_ops.grouped_gemm_down(act, w2, offs, scale, E)
+        if defer_combine and get_tp_group().world_size == 1 and shape[-1] % 8 == 0 and shape[-1] <= 16384:
+            return hip_ops.DeferredCombine(y, pos, T, k, T * k, shape)
         out = hip_ops.moe_combine(y, pos, T, k, T * k)
         if get_tp_group().world_size > 1:
             get_tp_group().all_reduce(out)

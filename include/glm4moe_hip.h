@@ -218,6 +218,12 @@ int glm_add_rmsnorm_router_topk(const void* x, const float* part, int nslices, i
                                 int64_t* topk_idx, void* topk_w, int64_t T, int H, int E, int k,
                                 float routed_scaling_factor, glm_stream_t stream);
 
+/* a12+a3 fused: glm_moe_combine of layer i and the input add-RMSNorm of layer i+1 (decode_layer.py:47-49) in one
+ *     launch at TP=1: out = normalised rows, residual_out = bf16(combine + residual_in).  H <= 16384.            */
+int glm_moe_combine_add_rmsnorm(const void* y, int64_t ldy, const int32_t* pair_pos, int64_t T, int k, int H,
+                                int64_t shared_base, const void* residual_in, const void* weight,
+                                void* out, void* residual_out, float eps, glm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

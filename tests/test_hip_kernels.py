@@ -344,6 +344,27 @@ def test_moe_combine_order_is_reference_order(ops):
     assert torch.equal(out, exp)
 
 
+@pytest.mark.parametrize("T,k,H,drop", [(9, 4, 256, False), (32, 8, 4096, False), (5, 2, 8192, True), (3, 8, 16384, False)])
+def test_moe_combine_fused_with_next_add_rmsnorm(ops, T, k, H, drop):
+    """One launch == moe_combine followed by add_rmsnorm(combined, residual), bit for bit."""
+    from nanovllm.hip_ops import DeferredCombine
+    R = T * k + T
+    y = rnd(R, H, seed=161, scale=2.0)
+    g = torch.Generator().manual_seed(162)
+    pos = torch.randperm(T * k, generator=g).view(T, k).to(torch.int32)
+    if drop:
+        pos[0, 1] = -1  # a dropped pair contributes nothing
+    res = rnd(T, H, seed=163)
+    nw = rnd(H, seed=164) * 0.1 + 1.0
+    yd, pd = dev(y), dev(pos.flatten().contiguous())
+    comb = ops.moe_combine(yd, pd, T, k, T * k)
+    y0, r0 = ops.add_rmsnorm(comb, dev(res), dev(nw), 1e-5)
+    dc = DeferredCombine(yd, pd, T, k, T * k, (T, H))
+    y1, r1 = ops.moe_combine_add_rmsnorm(dc, dev(res), dev(nw), 1e-5)
+    assert torch.equal(dc.materialize(), comb)
+    assert torch.equal(r0, r1) and torch.equal(y0, y1)
+
+
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K,bias", [
     (1, 64, 128, False), (5, 72, 4096, True), (32, 4096, 1408, False), (33, 512, 176, True),
