@@ -60,6 +60,52 @@ def init_weights(model, seed: int):
             b.uniform_(-0.1, 0.1, generator=g)
 
 
+def probe_capture_child() -> int:
+    """Child process of the N>1 pre-flight: can this node capture RCCL all-reduces (through torch.distributed) in a
+    HIP graph and replay them?  A failed capture leaves a process unusable, so the question is asked in a throwaway
+    process per rank (own rendezvous port) before the bench ranks touch their GPUs.  Exit code 0 = yes."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local_rank = 0 if os.environ.get("GLM_BENCH_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist.init_process_group("nccl", device_id=dev)
+    x = torch.full((32, 4096), float(rank + 1), dtype=torch.bfloat16, device=dev)
+    dist.all_reduce(x)  # brings the communicator up outside the capture
+    torch.cuda.synchronize()
+    y = torch.full((32, 4096), float(rank + 1), dtype=torch.bfloat16, device=dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        a = y * 2
+        dist.all_reduce(a)
+        b = a + 1
+        dist.all_reduce(b)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    s1 = 2.0 * sum(r + 1 for r in range(world))
+    ok = bool((a == s1).all()) and bool((b == world * (s1 + 1)).all())
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def probe_capture(world: int, timeout_s: int = 180) -> tuple[bool, str | None]:
+    """Parent side: run the probe child with this rank's environment on the next rendezvous port."""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 17)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-capture"], env=env,
+                           timeout=timeout_s, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    except subprocess.TimeoutExpired:
+        return False, "capture probe timed out"
+    if r.returncode != 0:
+        tail = r.stderr.decode(errors="replace").strip().splitlines()[-1:] or [""]
+        return False, f"capture probe exit {r.returncode}: {tail[0][:160]}"
+    return True, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,12 +120,15 @@ def main():
     ap.add_argument("--emulate-tp", type=int, default=1,
                     help="kernel-shape study on ONE GPU: run the per-rank shapes of TP=N (heads, kv heads, expert/MLP "
                          "intermediate size and vocabulary divided by N) without any collective; not a benchmark result")
+    ap.add_argument("--probe-capture", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--graph-body-only", action="store_true",
                     help="debug: at 1 GPU, capture only the layer stack and run the lm_head eagerly (the TP>1 arrangement)")
     ap.add_argument("--fp8-experts", action="store_true",
                     help="stream the experts as OCP fp8 e4m3 (weight-only, N4 / BASELINE config 5 flavour); "
                          "the default bf16 run is the one comparable with the reference")
     args = ap.parse_args()
+    if args.probe_capture:
+        sys.exit(probe_capture_child())
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -87,11 +136,30 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # rehearsal knobs for a one-GPU box (never set by the driver): all ranks on cuda:0 over gloo exercises this
+    # file's N>1 control flow (sharded build, collectives' order, rank-0-only sections) without RCCL
+    backend = os.environ.get("GLM_BENCH_BACKEND", "nccl")
+    if os.environ.get("GLM_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    # N>1 pre-flight, before this process touches its GPU: may the layer stack be captured with its collectives?
+    tp_graph_ok, tp_graph_note = True, None
+    if world > 1 and not args.no_graph:
+        if backend != "nccl" and os.environ.get("GLM_BENCH_FORCE_PROBE") != "1":
+            tp_graph_ok, tp_graph_note = False, f"{backend} collectives cannot be captured"
+        else:
+            tp_graph_ok, tp_graph_note = probe_capture(world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        flag = torch.tensor([1 if tp_graph_ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # every rank takes the same decision
+        if not int(flag.item()) and tp_graph_ok:
+            tp_graph_ok, tp_graph_note = False, "capture probe failed on another rank"
 
     from nanovllm import hip_ops
     from nanovllm.models.glm4_moe.model import Glm4MoeForCausalLM
@@ -162,9 +230,9 @@ def main():
     # and any failure falls back to eager on every rank.
     step()
     torch.cuda.synchronize()
-    use_graph = not args.no_graph
+    use_graph = not args.no_graph and (world == 1 or tp_graph_ok)
     whole = world == 1 and not args.graph_body_only
-    graph_note = None
+    graph_note = tp_graph_note
     if use_graph:
         ok = 1
         graph = torch.cuda.CUDAGraph()
@@ -176,6 +244,14 @@ def main():
                     body()
         except Exception as e:  # noqa: BLE001 - report and fall back
             ok, graph_note = 0, repr(e)[:200]
+            # torch.cuda.graph.__exit__ raised from capture_end() before restoring the stream: leave the (ended,
+            # invalidated) capture stream, otherwise every later call fails with "stream is capturing"
+            torch.cuda.set_stream(torch.cuda.default_stream(dev))
+            graph = None
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
         if world > 1:
             flag = torch.tensor([ok], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -359,7 +435,10 @@ def measure_kernels(model, cfg, ops, B, ctx, world, iters, dev):
 
     def f_o(i):  # as the decoder layer runs it: K-slice partial sums at TP=1 (reduced inside the next add-RMSNorm)
         a = attn_layers[i % len(attn_layers)]
-        a.o_proj(o_in, defer_reduce=True)
+        if world == 1:
+            a.o_proj(o_in, defer_reduce=True)
+        else:  # the module would all-reduce: only rank 0 runs these measurements, so call the kernel itself
+            ops.gemm_bf16(o_in, a.o_proj.weight.data, None)
     m, md = timeit(f_o, iters)
     rec("gemm_o", m, md, H * nh * hd * 2, "H*nh*hd*2 B of W_o")
     # ---- prefill shape of the same config: T = 16384 tokens (max_num_batched_tokens,
