@@ -355,6 +355,228 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_smallm_kernel(const GemmPara
     else smallm_body<MODE, NWAVES, WS, RT, MTMAX, XBUF, W8>(p, smem, grp, m0, mcnt);
 }
 
+// ==========================================================================================
+// LDS-DMA variant of the same weight-streaming GEMM (bf16 weights, decode row counts).
+// Structure of the paged-attention kernel: every wave owns a 2-stage LDS ring; one stage = the wave's 16*RT weight
+// rows and the 16*MT activation rows of ONE 128-wide K chunk (256 B per row), both brought in by
+// global_load_lds_dwordx4 (4 rows x 256 B per instruction, source-side chunk swizzle chunk ^ (row & 15) so the
+// ds_read_b128 fragment reads are conflict free).  No workgroup barrier in the loop: a wave waits only for its own
+// DMA with a counted vmcnt, reads the stage's fragments into registers and immediately refills the stage with the
+// chunk two steps ahead.  The weight DMAs carry the nt hint (read once, by this CU only); the activation rows do not
+// (every workgroup of the group re-reads them from L2).  Waves split K (WS) and rows (WR) as in the VGPR variant;
+// K-slice partials are reduced through LDS after the loop.
+typedef __attribute__((address_space(3))) void sm_lds_void;
+typedef __attribute__((address_space(1))) const void sm_glb_void;
+template <int AUX>
+__device__ __forceinline__ void sm_glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((sm_glb_void*)gsrc, (sm_lds_void*)lds_wave_base, 16, 0, AUX);
+}
+template <int OFF>
+__device__ __forceinline__ void sm_lds_read_b128(u32x4_t& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+// wait for every LDS read; all fragment registers are named so that no consumer is scheduled above the wait
+template <int NA, int NB>
+__device__ __forceinline__ void sm_lds_wait(u32x4_t (&a)[NA][4], u32x4_t (&b)[NB][4]) {
+    if constexpr (NA == 1 && NB == 1)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(b[0][0]), "+v"(b[0][1]),
+                       "+v"(b[0][2]), "+v"(b[0][3])::"memory");
+    else if constexpr (NA == 2 && NB == 1)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]),
+                       "+v"(a[1][2]), "+v"(a[1][3]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3])::"memory");
+    else if constexpr (NA == 1 && NB == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(b[0][0]), "+v"(b[0][1]),
+                       "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3])::"memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]),
+                       "+v"(a[1][2]), "+v"(a[1][3]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]),
+                       "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3])::"memory");
+}
+
+template <int MODE, int NWAVES, int WS, int RT, int MT>
+__device__ __forceinline__ void smallm_body_dma(const GemmParams& p, char* smem, int grp, int m0, int mcnt) {
+    static_assert(SM_KC == 128 && RT <= 2 && MT <= 2, "one stage row = 256 B; at most 2 row / token tiles");
+    constexpr int WR = NWAVES / WS;
+    constexpr int WROWS = 16 * RT, XROWS = 16 * MT;
+    constexpr int WT = WROWS * 256, STAGE = (WROWS + XROWS) * 256;
+    constexpr int NW_DMA = WROWS / 4, NX_DMA = XROWS / 4, NDMA = NW_DMA + NX_DMA;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ws = wid % WS, wr = wid / WS;
+    const int c = lane & 15, g4 = lane >> 4;
+    const int K = p.K;
+    const int nchunks = (K + SM_KC - 1) / SM_KC;
+    const int cps = (nchunks + WS - 1) / WS;  // chunks per K slice
+    const int cbeg = ws * cps;
+    const int nmine = max(0, min(cps, nchunks - cbeg));
+    char* ring = smem + wid * 2 * STAGE;
+
+    // ---- DMA sources: instruction i covers stage rows 4i .. 4i+3; lane -> row 4i + (lane >> 4), 16-B position lane & 15
+    const int r4 = lane >> 4, pch = lane & 15;
+    int ncol0;
+    if (MODE == GEMM_GATEUP) ncol0 = (blockIdx.x * WR + wr) * 16;
+    else ncol0 = (blockIdx.x * WR + wr) * (16 * RT);
+    const bf16_t* wg = p.w + (int64_t)grp * p.w_gstride;
+    const bf16_t* wsrc[NW_DMA];
+    const bf16_t* xsrc[NX_DMA];
+    int wk[NW_DMA], xk[NX_DMA];  // element offset of this lane's 16-B chunk inside a K chunk
+#pragma unroll
+    for (int i = 0; i < NW_DMA; ++i) {
+        const int row = 4 * i + r4;  // 0 .. WROWS-1
+        int wi;
+        if (MODE == GEMM_GATEUP) wi = (row < 16 ? 0 : p.N) + min(ncol0 + (row & 15), p.N - 1);
+        else wi = min(ncol0 + row, p.N - 1);
+        wsrc[i] = wg + (int64_t)wi * p.ldw;
+        wk[i] = (pch ^ (row & 15)) << 3;
+    }
+#pragma unroll
+    for (int i = 0; i < NX_DMA; ++i) {
+        const int row = 4 * i + r4;  // 0 .. XROWS-1
+        const int rr = row < mcnt ? row : 0;  // padding rows re-read row 0 (their columns are never stored)
+        const int64_t srow = p.src ? (int64_t)p.src[m0 + rr] : (int64_t)(m0 + rr);
+        xsrc[i] = p.x + srow * p.ldx;
+        xk[i] = (pch ^ (row & 15)) << 3;
+    }
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+    auto issue = [&](int it) {
+        char* st = ring + (it & 1) * STAGE;
+        const int k0 = (cbeg + it) * SM_KC;
+#pragma unroll
+        for (int i = 0; i < NW_DMA; ++i)  // out-of-range K reads the zero page (address select)
+            sm_glds16<2>(k0 + wk[i] < K ? wsrc[i] + k0 + wk[i] : zero, st + i * 1024);
+#pragma unroll
+        for (int i = 0; i < NX_DMA; ++i)
+            sm_glds16<0>(k0 + xk[i] < K ? xsrc[i] + k0 + xk[i] : zero, st + WT + i * 1024);
+    };
+
+    f32x4_t acc[RT][MT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[rt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: lane (c, g4) reads row +c, chunk (4ks + g4) ^ c; row tiles / token tiles as immediates
+    unsigned rel[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rel[ks] = c * 256 + (((4 * ks + g4) ^ c) << 4);
+
+    if (nmine > 0) issue(0);
+    if (nmine > 1) issue(1);
+    const unsigned rbase = (unsigned)(uintptr_t)(const sm_lds_void*)ring;
+    for (int it = 0; it < nmine; ++it) {
+        if (it + 1 < nmine) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned sb = rbase + (it & 1) * STAGE;
+        u32x4_t af[RT][4], bfr[MT][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            sm_lds_read_b128<0>(af[0][ks], sb + rel[ks]);
+            if (RT > 1) sm_lds_read_b128<4096>(af[RT - 1][ks], sb + rel[ks]);
+            sm_lds_read_b128<WT>(bfr[0][ks], sb + rel[ks]);
+            if (MT > 1) sm_lds_read_b128<WT + 4096>(bfr[MT - 1][ks], sb + rel[ks]);
+        }
+        sm_lds_wait<RT, MT>(af, bfr);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 2 < nmine) issue(it + 2);  // the stage is free again
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[rt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[rt][ks]),
+                                                                         __builtin_bit_cast(bf16x8_t, bfr[mt][ks]),
+                                                                         acc[rt][mt], 0, 0, 0);
+    }
+
+    // ---- K-slice reduction through LDS (WS > 1): slice 0 accumulates the others ----
+    if (WS > 1) {
+        __syncthreads();  // every wave is done with its ring before the scratch overwrites wave 0's
+        float* red = reinterpret_cast<float*>(smem);
+        if (ws != 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    *reinterpret_cast<f32x4_t*>(red + ((((wr * (WS - 1) + (ws - 1)) * RT + rt) * MT + mt) * 64 + lane) * 4) =
+                        acc[rt][mt];
+        }
+        __syncthreads();
+        if (ws != 0) return;
+#pragma unroll
+        for (int s = 1; s < WS; ++s)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[rt][mt] += *reinterpret_cast<const f32x4_t*>(
+                        red + ((((wr * (WS - 1) + (s - 1)) * RT + rt) * MT + mt) * 64 + lane) * 4);
+    }
+    smallm_epilogue<MODE, RT, MT>(p, acc, grp, m0, mcnt, ncol0, c, g4);
+}
+
+template <int MODE, int NWAVES, int WS, int RT, int MTMAX>
+__global__ __launch_bounds__(NWAVES * 64) void gemm_smallm_dma_kernel(const GemmParams p_in) {
+    GemmParams p = p_in;
+    if (MODE == GEMM_PLAIN && p_in.ksplit > 1) {
+        const int chunks = (p_in.K + SM_KC - 1) / SM_KC;
+        const int per = (chunks + p_in.ksplit - 1) / p_in.ksplit;
+        const int kb = blockIdx.z * per * SM_KC;
+        p.x = p_in.x + kb;
+        p.w = p_in.w + kb;
+        p.K = min(per * SM_KC, p_in.K - kb);
+        p.ypart = p_in.ypart + (int64_t)blockIdx.z * p_in.R * p_in.N;
+    }
+    constexpr int MB = 16 * MTMAX;
+    constexpr int RING = NWAVES * 2 * (16 * RT + 16 * MTMAX) * 256;
+    static_assert(MODE != GEMM_GATEUP || RT == 2, "gate|up needs two row tiles");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* sh = reinterpret_cast<int*>(smem + RING);
+    glm_locate_block(p.offs, p.G, p.R, MB, blockIdx.y, sh);
+    __syncthreads();
+    const int grp = sh[0];
+    if (grp < 0) return;
+    const int m0 = sh[1], mcnt = sh[2];
+    if (mcnt <= 16) smallm_body_dma<MODE, NWAVES, WS, RT, 1>(p, smem, grp, m0, mcnt);
+    else smallm_body_dma<MODE, NWAVES, WS, RT, (MTMAX < 2 ? MTMAX : 2)>(p, smem, grp, m0, mcnt);
+}
+
+template <int MODE, int NWAVES, int WS, int RT, int MTMAX>
+int launch_cfg_dma(const GemmParams& p, hipStream_t st) {
+    static_assert(MTMAX <= 2, "the DMA variant stages at most 32 token rows");
+    constexpr int WR = NWAVES / WS;
+    constexpr int MB = 16 * MTMAX;
+    constexpr int RING = NWAVES * 2 * (16 * RT + 16 * MTMAX) * 256;
+    constexpr int REDB = WS > 1 ? WR * (WS - 1) * RT * MTMAX * 64 * 16 : 0;
+    static_assert(REDB <= RING, "reduction scratch must fit in the rings");
+    constexpr int LDS = RING + 16;
+    const int cols_per_wg = MODE == GEMM_GATEUP ? WR * 16 : WR * RT * 16;
+    const unsigned gx = (unsigned)((p.N + cols_per_wg - 1) / cols_per_wg);
+    const int64_t combos = p.offs ? (p.R / MB + p.G) : (p.R + MB - 1) / MB;
+    if (combos <= 0 || gx == 0) return GLM_OK;
+    GLM_CHECK_ARG(combos <= 65535, GLM_ERR_UNSUPPORTED, "gemm_smallm: too many row blocks (%ld)", (long)combos);
+    auto kern = gemm_smallm_dma_kernel<MODE, NWAVES, WS, RT, MTMAX>;
+    if (LDS > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) {
+                glm_set_error("gemm_smallm(dma): hipFuncSetAttribute(%d): %s", LDS, hipGetErrorString(e));
+                return GLM_ERR_LAUNCH;
+            }
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(gx, (unsigned)combos, (unsigned)(p.ksplit > 1 ? p.ksplit : 1)), dim3(NWAVES * 64),
+                       LDS, st, p);
+    GLM_CHECK_LAUNCH("gemm_smallm(dma)");
+    return GLM_OK;
+}
+
 template <int MODE, int NWAVES, int WS, int RT, int MTMAX, bool W8 = false>
 int launch_cfg(const GemmParams& p, hipStream_t st) {
     constexpr int WR = NWAVES / WS;
@@ -408,6 +630,21 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
 #endif
     // a single sequence (k + 1 rows, as many active experts): the long unsplit streams win (42 vs 49 us); from two
     // sequences on the split config is ahead (74 vs 87 us at bs=2 ... 224 vs 231 us at bs=16; tools/sweep_batch.sh)
+    // LDS-DMA variant where it measured faster (tools/sweep_all.sh, C3 decode shape): gate|up 2 waves x 2-way K split
+    // 244 -> 214-218 us (6.5 TB/s); QKV 27.0 -> 25.6 us; o_proj partial sums 21.2 -> 19.7 us; down: no gain (short K).
+    // -DGLM_SM_NO_DMA builds the all-VGPR dispatch for A/B runs.
+#if !defined(GLM_SM_NO_DMA) && !defined(GLM_SM_DMA_GATEUP)
+#define GLM_SM_DMA_GATEUP 2, 2, 2, 2
+#endif
+#if !defined(GLM_SM_NO_DMA) && !defined(GLM_SM_DMA_MID)
+#define GLM_SM_DMA_MID 4, 2, 2, 2
+#endif
+#ifdef GLM_SM_DMA_GATEUP
+    if (mode == GEMM_GATEUP && p.R > 16) return launch_cfg_dma<GEMM_GATEUP, GLM_SM_DMA_GATEUP>(p, st);
+#endif
+#ifdef GLM_SM_DMA_DOWN
+    if (mode == GEMM_DOWN) return launch_cfg_dma<GEMM_DOWN, GLM_SM_DMA_DOWN>(p, st);
+#endif
     if (mode == GEMM_GATEUP && p.R <= 16) return launch_cfg<GEMM_GATEUP, 4, 1, 2, 2>(p, st);
     if (mode == GEMM_GATEUP) return launch_cfg<GEMM_GATEUP, GLM_SM_CFG_GATEUP>(p, st);
     if (mode == GEMM_DOWN) return launch_cfg<GEMM_DOWN, GLM_SM_CFG_DOWN>(p, st);
@@ -424,6 +661,9 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
 #endif
 #ifndef GLM_SM_CFG_SMALL
 #define GLM_SM_CFG_SMALL 8, 8, 1, 2
+#endif
+#ifdef GLM_SM_DMA_MID
+    if (tiles32 >= 384) return launch_cfg_dma<GEMM_PLAIN, GLM_SM_DMA_MID>(p, st);
 #endif
     if (tiles32 >= 384) return launch_cfg<GEMM_PLAIN, GLM_SM_CFG_MID>(p, st);
     return launch_cfg<GEMM_PLAIN, GLM_SM_CFG_SMALL>(p, st);
@@ -445,6 +685,12 @@ int glm_launch_gemm_smallm_partial(const GemmParams& p, hipStream_t st) {
                   "glm_smallm_partial_slices (M=%ld K=%d N=%d ksplit=%d)", (long)p.R, p.K, p.N, p.ksplit);
 #ifndef GLM_SM_CFG_PARTIAL
 #define GLM_SM_CFG_PARTIAL 4, 1, 1, 2
+#endif
+#if !defined(GLM_SM_NO_DMA) && !defined(GLM_SM_DMA_PARTIAL)
+#define GLM_SM_DMA_PARTIAL 4, 1, 2, 2
+#endif
+#ifdef GLM_SM_DMA_PARTIAL
+    return launch_cfg_dma<GEMM_PLAIN, GLM_SM_DMA_PARTIAL>(p, st);
 #endif
     return launch_cfg<GEMM_PLAIN, GLM_SM_CFG_PARTIAL>(p, st);
 }

@@ -37,8 +37,13 @@ constexpr int PA_LDS = PA_WAVES * PA_RING + PA_MAX_BT * 4;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
+// KV rows are read once per step: aux = 2 (nt) — 92.5 -> 84.5 us at C3 (6.37 TB/s); the same hint on the GEMMs'
+// plain global_load weight stream made those 15 % SLOWER, so it is used here only
+#ifndef GLM_PA_NT
+#define GLM_PA_NT 1
+#endif
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((glb_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, GLM_PA_NT ? 2 : 0);
 }
 
 // LDS fragment reads as inline asm: hipcc cannot tell a ds_read (in particular the tr16 builtin)
