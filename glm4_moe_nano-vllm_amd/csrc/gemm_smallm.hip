@@ -397,13 +397,18 @@ __device__ __forceinline__ void sm_lds_wait(u32x4_t (&a)[NA][4], u32x4_t (&b)[NB
                        "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3])::"memory");
 }
 
-template <int MODE, int NWAVES, int WS, int RT, int MT>
+// TPW > 1 (grouped modes, WS == 1): a wave walks TPW consecutive column tiles as ONE stream — the ring keeps
+// prefetching across tile boundaries, so the start-up and drain bubbles of a short K (down: 11 chunks) are paid once
+// per TPW tiles; results are stored at each tile's last chunk.
+template <int MODE, int NWAVES, int WS, int RT, int MT, int TPW>
 __device__ __forceinline__ void smallm_body_dma(const GemmParams& p, char* smem, int grp, int m0, int mcnt) {
     static_assert(SM_KC == 128 && RT <= 2 && MT <= 2, "one stage row = 256 B; at most 2 row / token tiles");
+    static_assert(TPW == 1 || (WS == 1 && MODE != GEMM_PLAIN), "column-tile streams: grouped modes without a K split");
     constexpr int WR = NWAVES / WS;
     constexpr int WROWS = 16 * RT, XROWS = 16 * MT;
     constexpr int WT = WROWS * 256, STAGE = (WROWS + XROWS) * 256;
     constexpr int NW_DMA = WROWS / 4, NX_DMA = XROWS / 4, NDMA = NW_DMA + NX_DMA;
+    constexpr int CPW = MODE == GEMM_GATEUP ? 16 : 16 * RT;  // output columns per wave per tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ws = wid % WS, wr = wid / WS;
@@ -417,9 +422,8 @@ __device__ __forceinline__ void smallm_body_dma(const GemmParams& p, char* smem,
 
     // ---- DMA sources: instruction i covers stage rows 4i .. 4i+3; lane -> row 4i + (lane >> 4), 16-B position lane & 15
     const int r4 = lane >> 4, pch = lane & 15;
-    int ncol0;
-    if (MODE == GEMM_GATEUP) ncol0 = (blockIdx.x * WR + wr) * 16;
-    else ncol0 = (blockIdx.x * WR + wr) * (16 * RT);
+    const int ncol_first = (blockIdx.x * TPW * WR + wr) * CPW;  // tile t adds t * WR * CPW columns
+    const int64_t wstep = (int64_t)WR * CPW * p.ldw;            // weight rows advance with the columns (host: no clamping)
     const bf16_t* wg = p.w + (int64_t)grp * p.w_gstride;
     const bf16_t* wsrc[NW_DMA];
     const bf16_t* xsrc[NX_DMA];
@@ -428,8 +432,8 @@ __device__ __forceinline__ void smallm_body_dma(const GemmParams& p, char* smem,
     for (int i = 0; i < NW_DMA; ++i) {
         const int row = 4 * i + r4;  // 0 .. WROWS-1
         int wi;
-        if (MODE == GEMM_GATEUP) wi = (row < 16 ? 0 : p.N) + min(ncol0 + (row & 15), p.N - 1);
-        else wi = min(ncol0 + row, p.N - 1);
+        if (MODE == GEMM_GATEUP) wi = (row < 16 ? 0 : p.N) + min(ncol_first + (row & 15), p.N - 1);
+        else wi = min(ncol_first + row, p.N - 1);
         wsrc[i] = wg + (int64_t)wi * p.ldw;
         wk[i] = (pch ^ (row & 15)) << 3;
     }
@@ -441,16 +445,42 @@ __device__ __forceinline__ void smallm_body_dma(const GemmParams& p, char* smem,
         xsrc[i] = p.x + srow * p.ldx;
         xk[i] = (pch ^ (row & 15)) << 3;
     }
+    // per-row scale of the down projection, fetched before the stream starts (a load inside the loop would have to
+    // wait behind every DMA in flight)
+    float sc_pre[MT];
+    bool scaled = false;
+    if (TPW > 1 && MODE == GEMM_DOWN) {
+        scaled = grp < p.n_scaled;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = 16 * mt + c;
+            sc_pre[mt] = (scaled && row < mcnt) ? bf2f(p.scale[m0 + row]) : 1.0f;
+        }
+    }
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
-    auto issue = [&](int it) {
-        char* st = ring + (it & 1) * STAGE;
-        const int k0 = (cbeg + it) * SM_KC;
+    // number of column tiles of this wave that exist
+    int ntv = 1;
+    if (TPW > 1) {
+        ntv = 0;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) ntv += (ncol_first + t * WR * CPW) < p.N ? 1 : 0;
+    }
+    const int total = ntv * nmine;
+    int is_t = 0, is_c = 0;  // (tile, chunk) of the next stage to issue
+    auto issue = [&](int j) {
+        char* st = ring + (j & 1) * STAGE;
+        const int k0 = (cbeg + is_c) * SM_KC;
+        const int64_t wo = TPW > 1 ? is_t * wstep : 0;
 #pragma unroll
         for (int i = 0; i < NW_DMA; ++i)  // out-of-range K reads the zero page (address select)
-            sm_glds16<2>(k0 + wk[i] < K ? wsrc[i] + k0 + wk[i] : zero, st + i * 1024);
+            sm_glds16<2>(k0 + wk[i] < K ? wsrc[i] + wo + k0 + wk[i] : zero, st + i * 1024);
 #pragma unroll
         for (int i = 0; i < NX_DMA; ++i)
             sm_glds16<0>(k0 + xk[i] < K ? xsrc[i] + k0 + xk[i] : zero, st + WT + i * 1024);
+        if (++is_c == nmine) {
+            is_c = 0;
+            ++is_t;
+        }
     };
 
     f32x4_t acc[RT][MT];
@@ -464,11 +494,12 @@ __device__ __forceinline__ void smallm_body_dma(const GemmParams& p, char* smem,
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) rel[ks] = c * 256 + (((4 * ks + g4) ^ c) << 4);
 
-    if (nmine > 0) issue(0);
-    if (nmine > 1) issue(1);
+    if (total > 0) issue(0);
+    if (total > 1) issue(1);
     const unsigned rbase = (unsigned)(uintptr_t)(const sm_lds_void*)ring;
-    for (int it = 0; it < nmine; ++it) {
-        if (it + 1 < nmine) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NDMA) : "memory");
+    int cs_t = 0, cs_c = 0;  // (tile, chunk) being consumed
+    for (int it = 0; it < total; ++it) {
+        if (it + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned sb = rbase + (it & 1) * STAGE;
         u32x4_t af[RT][4], bfr[MT][4];
@@ -481,7 +512,7 @@ __device__ __forceinline__ void smallm_body_dma(const GemmParams& p, char* smem,
         }
         sm_lds_wait<RT, MT>(af, bfr);
         __builtin_amdgcn_sched_barrier(0);
-        if (it + 2 < nmine) issue(it + 2);  // the stage is free again
+        if (it + 2 < total) issue(it + 2);  // the stage is free again
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -491,8 +522,48 @@ __device__ __forceinline__ void smallm_body_dma(const GemmParams& p, char* smem,
                     acc[rt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[rt][ks]),
                                                                          __builtin_bit_cast(bf16x8_t, bfr[mt][ks]),
                                                                          acc[rt][mt], 0, 0, 0);
+        if (TPW > 1 && ++cs_c == nmine) {
+            // last chunk of a column tile: store it (stores only; the counted vmcnt stays valid because loads return
+            // in order among themselves) and start the next tile from zero
+            const int ncol0 = ncol_first + cs_t * WR * CPW;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = 16 * mt + c;
+                if (row >= mcnt) continue;
+                bf16_t* yrow = p.y + (int64_t)(m0 + row) * p.ldy;
+                if (MODE == GEMM_GATEUP) {
+                    const int n = ncol0 + 4 * g4;
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = rbf(glm_silu(rbf(acc[0][mt][r]))) * rbf(acc[RT - 1][mt][r]);
+                    const u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                    *reinterpret_cast<u32x2_t*>(yrow + n) = v;
+                } else {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const int n = ncol0 + 16 * rt + 4 * g4;
+                        float o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float a = acc[rt][mt][r];
+                            o[r] = scaled ? rbf(a) * sc_pre[mt] : a;
+                        }
+                        const u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                        *reinterpret_cast<u32x2_t*>(yrow + n) = v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[rt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            cs_c = 0;
+            ++cs_t;
+        }
     }
+    if (TPW > 1) return;
 
+    const int ncol0 = ncol_first;
     // ---- K-slice reduction through LDS (WS > 1): slice 0 accumulates the others ----
     if (WS > 1) {
         __syncthreads();  // every wave is done with its ring before the scratch overwrites wave 0's
@@ -519,7 +590,7 @@ __device__ __forceinline__ void smallm_body_dma(const GemmParams& p, char* smem,
     smallm_epilogue<MODE, RT, MT>(p, acc, grp, m0, mcnt, ncol0, c, g4);
 }
 
-template <int MODE, int NWAVES, int WS, int RT, int MTMAX>
+template <int MODE, int NWAVES, int WS, int RT, int MTMAX, int TPW>
 __global__ __launch_bounds__(NWAVES * 64) void gemm_smallm_dma_kernel(const GemmParams p_in) {
     GemmParams p = p_in;
     if (MODE == GEMM_PLAIN && p_in.ksplit > 1) {
@@ -541,25 +612,29 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_smallm_dma_kernel(const Gemm
     const int grp = sh[0];
     if (grp < 0) return;
     const int m0 = sh[1], mcnt = sh[2];
-    if (mcnt <= 16) smallm_body_dma<MODE, NWAVES, WS, RT, 1>(p, smem, grp, m0, mcnt);
-    else smallm_body_dma<MODE, NWAVES, WS, RT, (MTMAX < 2 ? MTMAX : 2)>(p, smem, grp, m0, mcnt);
+    if (mcnt <= 16) smallm_body_dma<MODE, NWAVES, WS, RT, 1, TPW>(p, smem, grp, m0, mcnt);
+    else smallm_body_dma<MODE, NWAVES, WS, RT, (MTMAX < 2 ? MTMAX : 2), TPW>(p, smem, grp, m0, mcnt);
 }
 
-template <int MODE, int NWAVES, int WS, int RT, int MTMAX>
+template <int MODE, int NWAVES, int WS, int RT, int MTMAX, int TPW = 1>
 int launch_cfg_dma(const GemmParams& p, hipStream_t st) {
     static_assert(MTMAX <= 2, "the DMA variant stages at most 32 token rows");
+    if (TPW > 1) {  // column-tile streams need whole tiles everywhere, else the plain one-tile kernel
+        const int step = (MODE == GEMM_GATEUP ? (NWAVES / WS) * 16 : (NWAVES / WS) * RT * 16) * TPW;
+        if (p.N % step != 0) return launch_cfg_dma<MODE, NWAVES, WS, RT, MTMAX, 1>(p, st);
+    }
     constexpr int WR = NWAVES / WS;
     constexpr int MB = 16 * MTMAX;
     constexpr int RING = NWAVES * 2 * (16 * RT + 16 * MTMAX) * 256;
     constexpr int REDB = WS > 1 ? WR * (WS - 1) * RT * MTMAX * 64 * 16 : 0;
     static_assert(REDB <= RING, "reduction scratch must fit in the rings");
     constexpr int LDS = RING + 16;
-    const int cols_per_wg = MODE == GEMM_GATEUP ? WR * 16 : WR * RT * 16;
+    const int cols_per_wg = (MODE == GEMM_GATEUP ? WR * 16 : WR * RT * 16) * TPW;
     const unsigned gx = (unsigned)((p.N + cols_per_wg - 1) / cols_per_wg);
     const int64_t combos = p.offs ? (p.R / MB + p.G) : (p.R + MB - 1) / MB;
     if (combos <= 0 || gx == 0) return GLM_OK;
     GLM_CHECK_ARG(combos <= 65535, GLM_ERR_UNSUPPORTED, "gemm_smallm: too many row blocks (%ld)", (long)combos);
-    auto kern = gemm_smallm_dma_kernel<MODE, NWAVES, WS, RT, MTMAX>;
+    auto kern = gemm_smallm_dma_kernel<MODE, NWAVES, WS, RT, MTMAX, TPW>;
     if (LDS > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -642,8 +717,11 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
 #ifdef GLM_SM_DMA_GATEUP
     if (mode == GEMM_GATEUP && p.R > 16) return launch_cfg_dma<GEMM_GATEUP, GLM_SM_DMA_GATEUP>(p, st);
 #endif
+#if !defined(GLM_SM_NO_DMA) && !defined(GLM_SM_DMA_DOWN)
+#define GLM_SM_DMA_DOWN 1, 1, 2, 2  // one-wave workgroups (32 KiB of LDS each): 122 -> 115 us; 4,1,2,2 and 2,1,2,2: 116-117
+#endif
 #ifdef GLM_SM_DMA_DOWN
-    if (mode == GEMM_DOWN) return launch_cfg_dma<GEMM_DOWN, GLM_SM_DMA_DOWN>(p, st);
+    if (mode == GEMM_DOWN && p.R > 16) return launch_cfg_dma<GEMM_DOWN, GLM_SM_DMA_DOWN>(p, st);
 #endif
     if (mode == GEMM_GATEUP && p.R <= 16) return launch_cfg<GEMM_GATEUP, 4, 1, 2, 2>(p, st);
     if (mode == GEMM_GATEUP) return launch_cfg<GEMM_GATEUP, GLM_SM_CFG_GATEUP>(p, st);
