@@ -11,6 +11,7 @@ namespace {
 
 constexpr int ROUTER_MAX_E = 256;
 constexpr int ROUTER_EB = 4;  // experts per dot-product pass (x chunk reused 4x)
+constexpr int ROUTER_RU = 4;  // K steps whose gate-row loads are in flight together
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -132,16 +133,33 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
         float acc[ROUTER_EB];
 #pragma unroll
         for (int j = 0; j < ROUTER_EB; ++j) acc[j] = 0.f;
-        for (int c = lane; c < nvec; c += 64) {
-            const u32x4_t xv = reinterpret_cast<const u32x4_t*>(xs)[c];
+        // the gate rows come from L2 (~1 us per round trip): ROUTER_RU x ROUTER_EB row chunks are requested before the
+        // first FMA (a wave has only nvec/64 = 8 steps at H=4096, waiting for each one separately cost ~8 us);
+        // the FMAs keep the ascending-k order, so the sums are bit-identical to the one-step-at-a-time loop
+        for (int c0 = lane; c0 < nvec; c0 += 64 * ROUTER_RU) {
+            u32x4_t wv[ROUTER_RU][ROUTER_EB];
 #pragma unroll
-            for (int j = 0; j < ROUTER_EB; ++j) {
-                const int e = e0 + j < E ? e0 + j : E - 1;
-                const u32x4_t wv = reinterpret_cast<const u32x4_t*>(gw + (int64_t)e * H)[c];
+            for (int u = 0; u < ROUTER_RU; ++u) {
+                const int cc = c0 + 64 * u < nvec ? c0 + 64 * u : lane;  // clamped re-read, not accumulated
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc[j] = fmaf(bflo(xv[q]), bflo(wv[q]), acc[j]);
-                    acc[j] = fmaf(bfhi(xv[q]), bfhi(wv[q]), acc[j]);
+                for (int j = 0; j < ROUTER_EB; ++j) {
+                    const int e = e0 + j < E ? e0 + j : E - 1;
+                    wv[u][j] = reinterpret_cast<const u32x4_t*>(gw + (int64_t)e * H)[cc];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < ROUTER_RU; ++u) {
+                const int c = c0 + 64 * u;
+                if (c < nvec) {
+                    const u32x4_t xv = reinterpret_cast<const u32x4_t*>(xs)[c];
+#pragma unroll
+                    for (int j = 0; j < ROUTER_EB; ++j) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc[j] = fmaf(bflo(xv[q]), bflo(wv[u][j][q]), acc[j]);
+                            acc[j] = fmaf(bfhi(xv[q]), bfhi(wv[u][j][q]), acc[j]);
+                        }
+                    }
                 }
             }
         }

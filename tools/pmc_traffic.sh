@@ -14,10 +14,10 @@ done
 python3 - <<PY
 import csv, glob, json, statistics, collections, re
 names = {  # kernel-name pattern -> bench.py kernel key
-    r"gemm_smallm_kernel<1, 4, 4, 2, 2": "grouped_gemm_gateup_silu",
-    r"gemm_smallm_kernel<2, 4, 2, 1, 2": "grouped_gemm_down",
-    r"gemm_smallm_kernel<0, 8, 2, 1, 2": "gemm_qkv",
-    r"gemm_smallm_kernel<0, 4, 1, 1, 2": "gemm_o",
+    r"gemm_smallm_dma_kernel<1,": "grouped_gemm_gateup_silu",
+    r"gemm_smallm_dma_kernel<2,": "grouped_gemm_down",
+    r"gemm_smallm_dma_kernel<0, 4, 2, 2, 2": "gemm_qkv",
+    r"gemm_smallm_dma_kernel<0, 4, 1, 2, 2": "gemm_o",
     r"paged_attn_decode_kernel": "paged_attn_decode",
     r"gemm_largem_kernel<1,": "grouped_gemm_gateup_silu@prefill16k",
     r"gemm_largem_kernel<2,": "grouped_gemm_down@prefill16k",
