@@ -712,7 +712,7 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
 #define GLM_SM_DMA_GATEUP 2, 2, 2, 2
 #endif
 #if !defined(GLM_SM_NO_DMA) && !defined(GLM_SM_DMA_MID)
-#define GLM_SM_DMA_MID 4, 2, 2, 2
+#define GLM_SM_DMA_MID 2, 1, 2, 2  // 23.7 us (4,2,2,2: 25.6; 1,1,2,2: 24.4; 4,1,2,2: 39.8)
 #endif
 #ifdef GLM_SM_DMA_GATEUP
     if (mode == GEMM_GATEUP && p.R > 16) return launch_cfg_dma<GEMM_GATEUP, GLM_SM_DMA_GATEUP>(p, st);
