@@ -733,6 +733,10 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
 #if GLM_SM_KS != 4  // experimental chunk widths: the K-split configs would exceed the LDS
     return launch_cfg<GEMM_PLAIN, 4, 1, 2, 4>(p, st);
 #endif
+#ifndef GLM_SM_NO_DMA
+    // very wide outputs at decode batch sizes (lm_head: 151552 x 4096): the DMA body, 2-wave workgroups
+    if (p.G <= 1 && rows <= 32 && tiles32 >= 1024 && p.K >= 512) return launch_cfg_dma<GEMM_PLAIN, 2, 1, 2, 2>(p, st);
+#endif
     if (p.G > 1 || rows > 32 || tiles32 >= 1024) return launch_cfg<GEMM_PLAIN, 4, 1, 2, 4>(p, st);
     // (waves, K-split waves, row tiles per wave, max 16-row activation tiles); overridable for A/B builds
 #ifndef GLM_SM_CFG_MID
