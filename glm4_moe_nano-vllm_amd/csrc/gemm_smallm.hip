@@ -390,11 +390,25 @@ __device__ __forceinline__ void sm_lds_wait(u32x4_t (&a)[NA][4], u32x4_t (&b)[NB
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(b[0][0]), "+v"(b[0][1]),
                        "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3])::"memory");
-    else
+    else if constexpr (NA == 2 && NB == 2)
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]),
                        "+v"(a[1][2]), "+v"(a[1][3]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]),
                        "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3])::"memory");
+    else if constexpr (NA == 4 && NB == 1)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]),
+                       "+v"(a[1][2]), "+v"(a[1][3]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[2][2]), "+v"(a[2][3]),
+                       "+v"(a[3][0]), "+v"(a[3][1]), "+v"(a[3][2]), "+v"(a[3][3]), "+v"(b[0][0]), "+v"(b[0][1]),
+                       "+v"(b[0][2]), "+v"(b[0][3])::"memory");
+    else {
+        static_assert(NA == 4 && NB == 2, "fragment counts covered: 1/2/4 row tiles x 1/2 token tiles");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]),
+                       "+v"(a[1][2]), "+v"(a[1][3]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[2][2]), "+v"(a[2][3]),
+                       "+v"(a[3][0]), "+v"(a[3][1]), "+v"(a[3][2]), "+v"(a[3][3]), "+v"(b[0][0]), "+v"(b[0][1]),
+                       "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3])::"memory");
+    }
 }
 
 // TPW > 1 (grouped modes, WS == 1): a wave walks TPW consecutive column tiles as ONE stream — the ring keeps
@@ -402,7 +416,7 @@ __device__ __forceinline__ void sm_lds_wait(u32x4_t (&a)[NA][4], u32x4_t (&b)[NB
 // per TPW tiles; results are stored at each tile's last chunk.
 template <int MODE, int NWAVES, int WS, int RT, int MT, int TPW>
 __device__ __forceinline__ void smallm_body_dma(const GemmParams& p, char* smem, int grp, int m0, int mcnt) {
-    static_assert(SM_KC == 128 && RT <= 2 && MT <= 2, "one stage row = 256 B; at most 2 row / token tiles");
+    static_assert(SM_KC == 128 && (RT == 1 || RT == 2 || RT == 4) && MT <= 2, "one stage row = 256 B; 1/2/4 row tiles, at most 2 token tiles");
     static_assert(TPW == 1 || (WS == 1 && MODE != GEMM_PLAIN), "column-tile streams: grouped modes without a K split");
     constexpr int WR = NWAVES / WS;
     constexpr int WROWS = 16 * RT, XROWS = 16 * MT;
@@ -506,7 +520,11 @@ __device__ __forceinline__ void smallm_body_dma(const GemmParams& p, char* smem,
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             sm_lds_read_b128<0>(af[0][ks], sb + rel[ks]);
-            if (RT > 1) sm_lds_read_b128<4096>(af[RT - 1][ks], sb + rel[ks]);
+            if (RT > 1) sm_lds_read_b128<4096>(af[1 % RT][ks], sb + rel[ks]);
+            if (RT > 2) {
+                sm_lds_read_b128<8192>(af[2 % RT][ks], sb + rel[ks]);
+                sm_lds_read_b128<12288>(af[3 % RT][ks], sb + rel[ks]);
+            }
             sm_lds_read_b128<WT>(bfr[0][ks], sb + rel[ks]);
             if (MT > 1) sm_lds_read_b128<WT + 4096>(bfr[MT - 1][ks], sb + rel[ks]);
         }
@@ -628,6 +646,7 @@ int launch_cfg_dma(const GemmParams& p, hipStream_t st) {
     constexpr int RING = NWAVES * 2 * (16 * RT + 16 * MTMAX) * 256;
     constexpr int REDB = WS > 1 ? WR * (WS - 1) * RT * MTMAX * 64 * 16 : 0;
     static_assert(REDB <= RING, "reduction scratch must fit in the rings");
+    static_assert(RING + 16 <= 160 * 1024, "the rings of all waves must fit the CU's 160 KiB of LDS");
     constexpr int LDS = RING + 16;
     const int cols_per_wg = (MODE == GEMM_GATEUP ? WR * 16 : WR * RT * 16) * TPW;
     const unsigned gx = (unsigned)((p.N + cols_per_wg - 1) / cols_per_wg);
