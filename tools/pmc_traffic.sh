@@ -16,7 +16,7 @@ import csv, glob, json, statistics, collections, re
 names = {  # kernel-name pattern -> bench.py kernel key
     r"gemm_smallm_dma_kernel<1,": "grouped_gemm_gateup_silu",
     r"gemm_smallm_dma_kernel<2,": "grouped_gemm_down",
-    r"gemm_smallm_dma_kernel<0, 4, 2, 2, 2": "gemm_qkv",
+    r"gemm_smallm_dma_kernel<0, 2, 1, 2, 2": "gemm_qkv",  # lm_head shares the config; the median over launches is QKV
     r"gemm_smallm_dma_kernel<0, 4, 1, 2, 2": "gemm_o",
     r"paged_attn_decode_kernel": "paged_attn_decode",
     r"gemm_largem_kernel<1,": "grouped_gemm_gateup_silu@prefill16k",
