@@ -81,14 +81,18 @@ __device__ __forceinline__ void smallm_epilogue(const GemmParams& p, f32x4_t (&a
         if (row >= mcnt) continue;
         bf16_t* yrow = p.y + (int64_t)(m0 + row) * p.ldy;
         if (MODE == GEMM_GATEUP) {
-            const int n = ncol0 + 4 * g4;
-            if (n < p.N) {  // N % 4 == 0 is checked on the host
-                float o[4];
+            // row tiles [0, RT/2) are gate columns, [RT/2, RT) the matching up columns
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    o[r] = rbf(glm_silu(rbf(acc[0][mt][r]))) * rbf(acc[RT - 1][mt][r]);
-                u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-                *reinterpret_cast<u32x2_t*>(yrow + n) = v;
+            for (int j = 0; j < RT / 2; ++j) {
+                const int n = ncol0 + 16 * j + 4 * g4;
+                if (n < p.N) {  // N % 4 == 0 is checked on the host
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        o[r] = rbf(glm_silu(rbf(acc[j][mt][r]))) * rbf(acc[RT / 2 + j][mt][r]);
+                    u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                    *reinterpret_cast<u32x2_t*>(yrow + n) = v;
+                }
             }
         } else {
             float sc = 1.0f;
@@ -422,7 +426,7 @@ __device__ __forceinline__ void smallm_body_dma(const GemmParams& p, char* smem,
     constexpr int WROWS = 16 * RT, XROWS = 16 * MT;
     constexpr int WT = WROWS * 256, STAGE = (WROWS + XROWS) * 256;
     constexpr int NW_DMA = WROWS / 4, NX_DMA = XROWS / 4, NDMA = NW_DMA + NX_DMA;
-    constexpr int CPW = MODE == GEMM_GATEUP ? 16 : 16 * RT;  // output columns per wave per tile
+    constexpr int CPW = MODE == GEMM_GATEUP ? 8 * RT : 16 * RT;  // output columns per wave per tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ws = wid % WS, wr = wid / WS;
@@ -446,7 +450,8 @@ __device__ __forceinline__ void smallm_body_dma(const GemmParams& p, char* smem,
     for (int i = 0; i < NW_DMA; ++i) {
         const int row = 4 * i + r4;  // 0 .. WROWS-1
         int wi;
-        if (MODE == GEMM_GATEUP) wi = (row < 16 ? 0 : p.N) + min(ncol_first + (row & 15), p.N - 1);
+        if (MODE == GEMM_GATEUP)  // first half of the stage rows = gate columns, second half = the same up columns
+            wi = (row < WROWS / 2 ? 0 : p.N) + min(ncol_first + row % (WROWS / 2), p.N - 1);
         else wi = min(ncol_first + row, p.N - 1);
         wsrc[i] = wg + (int64_t)wi * p.ldw;
         wk[i] = (pch ^ (row & 15)) << 3;
@@ -550,12 +555,16 @@ __device__ __forceinline__ void smallm_body_dma(const GemmParams& p, char* smem,
                 if (row >= mcnt) continue;
                 bf16_t* yrow = p.y + (int64_t)(m0 + row) * p.ldy;
                 if (MODE == GEMM_GATEUP) {
-                    const int n = ncol0 + 4 * g4;
-                    float o[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = rbf(glm_silu(rbf(acc[0][mt][r]))) * rbf(acc[RT - 1][mt][r]);
-                    const u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-                    *reinterpret_cast<u32x2_t*>(yrow + n) = v;
+                    for (int j = 0; j < RT / 2; ++j) {
+                        const int n = ncol0 + 16 * j + 4 * g4;
+                        float o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            o[r] = rbf(glm_silu(rbf(acc[j][mt][r]))) * rbf(acc[RT / 2 + j][mt][r]);
+                        const u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                        *reinterpret_cast<u32x2_t*>(yrow + n) = v;
+                    }
                 } else {
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
@@ -622,7 +631,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_smallm_dma_kernel(const Gemm
     }
     constexpr int MB = 16 * MTMAX;
     constexpr int RING = NWAVES * 2 * (16 * RT + 16 * MTMAX) * 256;
-    static_assert(MODE != GEMM_GATEUP || RT == 2, "gate|up needs two row tiles");
+    static_assert(MODE != GEMM_GATEUP || RT == 2 || RT == 4, "gate|up: gate and up tiles come in pairs");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sh = reinterpret_cast<int*>(smem + RING);
     glm_locate_block(p.offs, p.G, p.R, MB, blockIdx.y, sh);
@@ -638,7 +647,7 @@ template <int MODE, int NWAVES, int WS, int RT, int MTMAX, int TPW = 1>
 int launch_cfg_dma(const GemmParams& p, hipStream_t st) {
     static_assert(MTMAX <= 2, "the DMA variant stages at most 32 token rows");
     if (TPW > 1) {  // column-tile streams need whole tiles everywhere, else the plain one-tile kernel
-        const int step = (MODE == GEMM_GATEUP ? (NWAVES / WS) * 16 : (NWAVES / WS) * RT * 16) * TPW;
+        const int step = (MODE == GEMM_GATEUP ? (NWAVES / WS) * 8 * RT : (NWAVES / WS) * RT * 16) * TPW;
         if (p.N % step != 0) return launch_cfg_dma<MODE, NWAVES, WS, RT, MTMAX, 1>(p, st);
     }
     constexpr int WR = NWAVES / WS;
@@ -648,7 +657,7 @@ int launch_cfg_dma(const GemmParams& p, hipStream_t st) {
     static_assert(REDB <= RING, "reduction scratch must fit in the rings");
     static_assert(RING + 16 <= 160 * 1024, "the rings of all waves must fit the CU's 160 KiB of LDS");
     constexpr int LDS = RING + 16;
-    const int cols_per_wg = (MODE == GEMM_GATEUP ? WR * 16 : WR * RT * 16) * TPW;
+    const int cols_per_wg = (MODE == GEMM_GATEUP ? WR * 8 * RT : WR * RT * 16) * TPW;
     const unsigned gx = (unsigned)((p.N + cols_per_wg - 1) / cols_per_wg);
     const int64_t combos = p.offs ? (p.R / MB + p.G) : (p.R + MB - 1) / MB;
     if (combos <= 0 || gx == 0) return GLM_OK;
