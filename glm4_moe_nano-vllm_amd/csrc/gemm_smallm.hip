@@ -4,24 +4,27 @@
 //
 // Roofline: HBM.  At bs=32 every weight byte is used for <= 64 FLOP, so the kernel is a
 // streaming reader: algorithmic bytes = all touched weight bytes, read exactly once.
-//   * out^T = W · x^T with mfma_f32_16x16x32_bf16: the 16 weight rows of a tile sit on the
-//     MFMA row axis (A operand, loaded straight from HBM into VGPRs in fragment order, 64 B
-//     contiguous per row per instruction), tokens sit on the lane/column axis (B operand).
-//   * the (tiny, L2-resident) activation chunk is staged once per workgroup per 128-wide K
-//     chunk in LDS, XOR-swizzled (chunk ^ (row & 15)) so the 16-row fragment reads
-//     (ds_read_b128) are bank-conflict free; double-buffered, one barrier per chunk.
-//   * each weight register is refilled for the NEXT chunk right after its last MFMA, so one
-//     full chunk (8 x 1 KiB per wave) stays in flight across the barrier; the activation loads
-//     are issued before it in program order, so waiting for them never drains the stream.
-//     (Measured alternatives that lost on the same box: B fragments straight from L2 without LDS
-//     and barriers, 298 vs 267 us for the grouped gate|up; two-chunk-deep weight registers at
-//     half the resident waves, 281 us.)
-//   * waves of a workgroup either own different weight rows (WS=1, grouped experts: 64/128
-//     rows per workgroup) or different K slices of the same rows (WS>1, dense projections with
-//     few rows: keeps >= 256 workgroups); K-slice partials are reduced through LDS.
-//   * grouped mode: blockIdx.y enumerates (expert, 64-row block) pairs, located by a wave
-//     scan over expert_offsets — no host sync, graph-capturable (the reference's per-expert
-//     Python loop with .any()/where host syncs is moe.py:135-151).
+// out^T = W · x^T with mfma_f32_16x16x32_bf16: the 16 weight rows of a tile sit on the MFMA row axis (A operand),
+// tokens on the lane/column axis (B operand).  Two bodies share the work decomposition, the K-slice reduction and
+// the epilogues:
+//
+//   * LDS-DMA body (smallm_body_dma, further down; what the decode step runs for bf16 weights): per-wave 2-stage
+//     LDS rings filled by global_load_lds (weights with the nt hint), no workgroup barrier — see its header.
+//   * VGPR body (smallm_body): weights straight from HBM into VGPRs in fragment order (64 B contiguous per row per
+//     instruction); the (tiny, L2-resident) activation chunk is staged once per workgroup per 128-wide K chunk in
+//     LDS, XOR-swizzled (chunk ^ (row & 15)) so the 16-row fragment reads (ds_read_b128) are bank-conflict free,
+//     double-buffered, one barrier per chunk.  Each weight register is refilled for the NEXT chunk right after its
+//     last MFMA, so one full chunk (8 x 1 KiB per wave) stays in flight across the barrier; the activation loads are
+//     issued before it in program order, so waiting for them never drains the stream.  Used for fp8 weights, for
+//     single-sequence decode, very short K and more than 32 rows per block.
+//     (Measured alternatives that lost on the same box: B fragments straight from L2 without LDS and barriers,
+//     298 vs 267 us for the grouped gate|up; two-chunk-deep weight registers at half the resident waves, 281 us.)
+//
+//   * waves of a workgroup own different weight rows (WR) and/or different K slices of the same rows (WS); K-slice
+//     partials are reduced through LDS.  Config sweeps (tools/sweep_*.sh) picked small workgroups everywhere.
+//   * grouped mode: blockIdx.y enumerates (expert, 32-row block) pairs, located by a wave scan over
+//     expert_offsets — no host sync, graph-capturable (the reference's per-expert Python loop with
+//     .any()/where host syncs is moe.py:135-151).
 #include "gemm_internal.h"
 #include <stdlib.h>
 #include <type_traits>
