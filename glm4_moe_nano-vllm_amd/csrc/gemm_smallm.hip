@@ -752,6 +752,14 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
 #define GLM_SM_DMA_DOWN 1, 1, 2, 2  // one-wave workgroups (32 KiB of LDS each): 122 -> 115 us; 4,1,2,2 and 2,1,2,2: 116-117
 #endif
 #ifdef GLM_SM_DMA_DOWN
+#ifndef GLM_SM_NO_DMA
+    // one group with a long reduction (the dense layer's down projection, 4096 x 10944): too few column blocks for
+    // one wave each (47.7 us = 1.9 TB/s) — split K over the waves of the workgroup instead
+#ifndef GLM_SM_DMA_DOWN_DENSE
+#define GLM_SM_DMA_DOWN_DENSE 4, 4, 1, 2
+#endif
+    if (mode == GEMM_DOWN && p.G == 1 && p.R > 16 && p.K >= 4096) return launch_cfg_dma<GEMM_DOWN, GLM_SM_DMA_DOWN_DENSE>(p, st);
+#endif
     // a K of one or two chunks (TP=8 shard: 176) leaves the ring nothing to overlap: 37 vs 31 us for the VGPR body
     if (mode == GEMM_DOWN && p.R > 16 && p.K >= 512) return launch_cfg_dma<GEMM_DOWN, GLM_SM_DMA_DOWN>(p, st);
 #endif
