@@ -195,28 +195,47 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
 #pragma unroll
     for (int i = 0; i < EPL; ++i)
         if (!(ch[i] == ch[i])) ch[i] = -INFINITY;
+    // Each candidate becomes one 64-bit key (order-preserving image of the score, then ~id so that the lowest id wins
+    // a tie); "no candidate" is key 0.  The wave maximum runs on DPP row permutations and the two lane-swap
+    // instructions instead of 12 LDS round trips (ds_bpermute) per round.
+    unsigned kh[EPL], kl[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int e = lane + 64 * i;
+        const unsigned u = __float_as_uint(ch[i] + 0.0f);  // -0 -> +0: equal scores must give equal keys
+        kh[i] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        kl[i] = ~(unsigned)e;
+        if (e >= E) kh[i] = 0u, kl[i] = 0u;
+    }
+    auto take_max = [](unsigned& hi, unsigned& lo, unsigned ohi, unsigned olo) {
+        const bool take = ohi > hi || (ohi == hi && olo > lo);
+        hi = take ? ohi : hi;
+        lo = take ? olo : lo;
+    };
     for (int r = 0; r < k; ++r) {
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;  // "no candidate"
+        unsigned hi = 0u, lo = 0u;
 #pragma unroll
-        for (int i = 0; i < EPL; ++i) {
-            const int e = lane + 64 * i;  // ascending ids: strict > keeps the lowest id on ties
-            if (e < E && !sel[i] && (bi == 0x7fffffff || ch[i] > bv)) {
-                bv = ch[i];
-                bi = e;
-            }
+        for (int i = 0; i < EPL; ++i)
+            if (!sel[i]) take_max(hi, lo, kh[i], kl[i]);
+#define GLM_DPP_STEP(CTRL)                                                                                      \
+    take_max(hi, lo, (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xF, 0xF, true),                   \
+             (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xF, 0xF, true))
+        GLM_DPP_STEP(0xB1);   // quad_perm [1,0,3,2]: lane ^ 1
+        GLM_DPP_STEP(0x4E);   // quad_perm [2,3,0,1]: lane ^ 2
+        GLM_DPP_STEP(0x141);  // row_half_mirror: the other quad of the 8
+        GLM_DPP_STEP(0x140);  // row_mirror: the other 8 of the row
+#undef GLM_DPP_STEP
+        {
+            const u32x2_t a = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+            const u32x2_t b = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+            hi = a[0], lo = b[0];
+            take_max(hi, lo, a[1], b[1]);
+            const u32x2_t c2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+            const u32x2_t d = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+            hi = c2[0], lo = d[0];
+            take_max(hi, lo, c2[1], d[1]);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            const bool take = (oi != 0x7fffffff) && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi));
-            if (take) {
-                bv = ov;
-                bi = oi;
-            }
-        }
-        // bi is wave-uniform now
+        const int bi = (int)~lo;  // wave-uniform; k <= E guarantees a candidate
 #pragma unroll
         for (int i = 0; i < EPL; ++i)
             if (lane + 64 * i == bi) sel[i] = true;
