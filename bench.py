@@ -454,7 +454,7 @@ def measure_kernels(model, cfg, ops, B, ctx, world, iters, dev):
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense
 
 
-def measure_prefill_gemm(layer, cfg, ops, world, dev, T=16384, iters=3):
+def measure_prefill_gemm(layer, cfg, ops, world, dev, T=16384, iters=10, warm=5):
     import torch
     H, E, k, I = cfg.hidden_size, cfg.n_routed_experts, cfg.num_experts_per_tok, cfg.moe_intermediate_size // world
     x = torch.randn(T, H, device=dev).to(torch.bfloat16)
@@ -465,7 +465,11 @@ def measure_prefill_gemm(layer, cfg, ops, world, dev, T=16384, iters=3):
     out = {}
 
     def timed(fn):
-        fn()
+        # the chip needs a few launches of MFMA-bound work to settle its clock after the HBM-bound decode kernels
+        # (tools/prefill_gemm_sustained.py: 999 TFLOP/s over the first five launches, 1046-1054 over the next 55):
+        # warm up first, then time a sustained stretch
+        for _ in range(warm):
+            fn()
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
