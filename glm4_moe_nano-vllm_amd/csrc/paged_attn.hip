@@ -21,6 +21,7 @@
 //   * per-wave online softmax (fp32), merged across the 4 waves through LDS at the end, and
 //     across kv-splits by a small second kernel when num_splits > 1.
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -81,13 +82,44 @@ __device__ __forceinline__ void issue_group(const bf16_t* __restrict__ kc, const
     }
 }
 
-template <int DUMMY>
+// FUSED = 1: the kernel starts from the packed QKV projection output instead of a rotated Q and an already updated
+// cache (attention_new.py:329-357 + layers/attention.py:10-42 folded in, head RMSNorm off, rotary_dim 64):
+//   * Q: lane (head c, g) holds dims [32ks + 8g, +8) of its head; NeoX pairs (d, d+32) for d < 32 are this lane's
+//     ks=0 / ks=1 fragments, so the rotation is lane-local (same arithmetic and rounding as rope8 in elementwise.hip).
+//   * K/V of the new token: the workgroup whose key range holds position len-1 rotates the K row, writes K and V
+//     to the cache slot, waits for the writes and only then (workgroup barrier) lets its waves start their DMA.
+struct PaFuse {
+    const bf16_t* qkv;     // [B, (nh + 2 nkv) * 128]
+    int64_t qkv_stride;    // elements per row
+    const int64_t* pos;    // [B]
+    const float* cos_sin;  // [max_pos, rotary_dim] fp32: cos | sin halves
+    const int32_t* slots;  // [B] cache slot of the new token
+    int64_t n_slots;
+    bf16_t* kc_w;          // writable views of the caches
+    bf16_t* vc_w;
+};
+
+// NeoX rotation of 8 packed bf16 pairs: y1 = a*cos - b*sin, y2 = b*cos + a*sin (rope8, elementwise.hip)
+__device__ __forceinline__ void pa_rope8(const u32x4_t a, const u32x4_t b, const float* cosp, const float* sinp,
+                                         u32x4_t& y1, u32x4_t& y2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float c0 = cosp[2 * j], c1 = cosp[2 * j + 1];
+        const float s0 = sinp[2 * j], s1 = sinp[2 * j + 1];
+        const float a0 = bflo(a[j]), a1 = bfhi(a[j]);
+        const float b0 = bflo(b[j]), b1 = bfhi(b[j]);
+        y1[j] = pack2bf(a0 * c0 - b0 * s0, a1 * c1 - b1 * s1);
+        y2[j] = pack2bf(b0 * c0 + a0 * s0, b1 * c1 + a1 * s1);
+    }
+}
+
+template <int FUSED>
 __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
     const int32_t* __restrict__ context_lens, const int32_t* __restrict__ block_tables,
     int64_t bt_stride, bf16_t* __restrict__ out, float* __restrict__ part_o,
     float* __restrict__ part_ml, int nh, int nkv, int block_size, float scale_log2e,
-    int num_splits) {
+    int num_splits, const PaFuse fu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int split = blockIdx.x, kvh = blockIdx.y;
     const int64_t b = blockIdx.z;
@@ -115,15 +147,53 @@ __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
     bf16x8_t qf[4];
     {
         const bool hv = c < gq;
-        const bf16_t* qrow = q + (b * nh + (int64_t)kvh * gq + (hv ? c : 0)) * PA_HD;
+        const bf16_t* qrow = FUSED ? fu.qkv + b * fu.qkv_stride + ((int64_t)kvh * gq + (hv ? c : 0)) * PA_HD
+                                   : q + (b * nh + (int64_t)kvh * gq + (hv ? c : 0)) * PA_HD;
+        u32x4_t v[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            u32x4_t v = {0, 0, 0, 0};
-            if (hv) v = *reinterpret_cast<const u32x4_t*>(qrow + 32 * ks + 8 * g);
-            qf[ks] = __builtin_bit_cast(bf16x8_t, v);
+            v[ks] = u32x4_t{0, 0, 0, 0};
+            if (hv) v[ks] = *reinterpret_cast<const u32x4_t*>(qrow + 32 * ks + 8 * g);
+        }
+        if (FUSED) {  // rotary_dim 64: chunk g of the first half pairs with chunk g of the second half
+            const float* cosp = fu.cos_sin + fu.pos[b] * 64 + 8 * g;
+            u32x4_t y1, y2;
+            pa_rope8(v[0], v[1], cosp, cosp + 32, y1, y2);
+            v[0] = y1;
+            v[1] = y2;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_bit_cast(bf16x8_t, v[ks]);
+    }
+    if (FUSED && len > 0) {
+        const int glast = (len - 1) / PA_GK;
+        if (glast >= G0 && glast < G1 && wid == 0 && lane < 32) {
+            // this workgroup reads the new token's key: lanes 0-15 rotate and store the K row (16 chunks of 8 dims),
+            // lanes 16-31 copy the V row
+            const int sub = lane & 15;
+            const bool is_k = lane < 16;
+            const bf16_t* row = fu.qkv + b * fu.qkv_stride + ((int64_t)nh + (is_k ? 0 : nkv) + kvh) * PA_HD;
+            u32x4_t xv = *reinterpret_cast<const u32x4_t*>(row + sub * 8);
+            if (is_k && sub < 8) {
+                const int partner = sub < 4 ? sub + 4 : sub - 4;
+                const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(row + partner * 8);
+                const float* cosp = fu.cos_sin + fu.pos[b] * 64 + 8 * (sub & 3);
+                u32x4_t y1, y2;
+                if (sub < 4) {
+                    pa_rope8(xv, pv, cosp, cosp + 32, y1, y2);
+                    xv = y1;
+                } else {
+                    pa_rope8(pv, xv, cosp, cosp + 32, y1, y2);
+                    xv = y2;
+                }
+            }
+            const int64_t slot = fu.slots[b];
+            if (slot >= 0 && slot < fu.n_slots)
+                *reinterpret_cast<u32x4_t*>((is_k ? fu.kc_w : fu.vc_w) + (slot * nkv + kvh) * PA_HD + sub * 8) = xv;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row is in L2 before the barrier releases the DMA
         }
     }
-    __syncthreads();  // bt_lds visible
+    __syncthreads();  // bt_lds visible; FUSED: new K/V row written
 
     f32x4_t acc[8];
 #pragma unroll
@@ -332,25 +402,18 @@ extern "C" size_t glm_paged_attn_decode_workspace_bytes(int64_t B, int nh, int h
     return (size_t)B * nh * s * (hd + 2) * sizeof(float);
 }
 
-extern "C" int glm_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache,
-                                     const int32_t* context_lens, const int32_t* block_tables,
-                                     int64_t bt_stride, void* out, int64_t B, int nh, int nkv, int hd,
-                                     int block_size, int64_t n_blocks, float scale, int num_splits,
-                                     int max_context_len, void* workspace, size_t workspace_bytes,
-                                     glm_stream_t stream) {
-    GLM_CHECK_ARG(q && k_cache && v_cache && context_lens && block_tables && out, GLM_ERR_INVALID,
-                  "glm_paged_attn_decode: null pointer");
+static int pa_launch(const void* q, const void* k_cache, const void* v_cache, const int32_t* context_lens,
+                     const int32_t* block_tables, int64_t bt_stride, void* out, int64_t B, int nh, int nkv, int hd,
+                     int block_size, float scale, int num_splits, int max_context_len, void* workspace,
+                     size_t workspace_bytes, glm_stream_t stream, const PaFuse* fuse, const char* name) {
     GLM_CHECK_ARG(B >= 0 && nh > 0 && nkv > 0 && nh % nkv == 0 && block_size > 0 && bt_stride > 0,
-                  GLM_ERR_INVALID, "glm_paged_attn_decode: bad shape");
+                  GLM_ERR_INVALID, "%s: bad shape", name);
     GLM_CHECK_ARG(hd == PA_HD && nh / nkv <= 16 && block_size % PA_GK == 0 && bt_stride <= PA_MAX_BT &&
                       nkv <= 65535 && B <= 65535,
                   GLM_ERR_UNSUPPORTED,
-                  "glm_paged_attn_decode: needs head_dim=128, nh/nkv<=16, block_size%%32==0, "
+                  "%s: needs head_dim=128, nh/nkv<=16, block_size%%32==0, "
                   "<=%d blocks per sequence (hd=%d group=%d block_size=%d bt_stride=%ld)",
-                  PA_MAX_BT, hd, nh / nkv, block_size, (long)bt_stride);
-    GLM_CHECK_ARG(glm_aligned16(q) && glm_aligned16(k_cache) && glm_aligned16(v_cache) &&
-                      glm_aligned16(out),
-                  GLM_ERR_INVALID, "glm_paged_attn_decode: pointers must be 16-byte aligned");
+                  name, PA_MAX_BT, hd, nh / nkv, block_size, (long)bt_stride);
     if (B == 0) return GLM_OK;
     if (max_context_len <= 0) max_context_len = (int)(bt_stride * block_size);
     int splits = num_splits > 0 ? num_splits : choose_splits(B, nkv, max_context_len);
@@ -360,32 +423,79 @@ extern "C" int glm_paged_attn_decode(const void* q, const void* k_cache, const v
     if (splits > 1) {
         const size_t need = (size_t)B * nh * splits * (PA_HD + 2) * sizeof(float);
         GLM_CHECK_ARG(workspace != nullptr && workspace_bytes >= need, GLM_ERR_WORKSPACE,
-                      "glm_paged_attn_decode: workspace %zu < %zu bytes", workspace_bytes, need);
+                      "%s: workspace %zu < %zu bytes", name, workspace_bytes, need);
         part_o = (float*)workspace;
         part_ml = part_o + (size_t)B * nh * splits * PA_HD;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)paged_attn_decode_kernel<0>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, PA_LDS);
+    static bool attr_set[2] = {false, false};
+    const int fz = fuse != nullptr;
+    if (!attr_set[fz]) {
+        const void* fn = fz ? (const void*)paged_attn_decode_kernel<1> : (const void*)paged_attn_decode_kernel<0>;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PA_LDS);
         if (e != hipSuccess) {
-            glm_set_error("glm_paged_attn_decode: hipFuncSetAttribute(%d B LDS): %s", PA_LDS,
-                          hipGetErrorString(e));
+            glm_set_error("%s: hipFuncSetAttribute(%d B LDS): %s", name, PA_LDS, hipGetErrorString(e));
             return GLM_ERR_LAUNCH;
         }
-        attr_set = true;
+        attr_set[fz] = true;
     }
     hipStream_t st = glm_s(stream);
     const float scale_log2e = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL((paged_attn_decode_kernel<0>), dim3((unsigned)splits, (unsigned)nkv, (unsigned)B),
-                       dim3(256), PA_LDS, st, (const bf16_t*)q, (const bf16_t*)k_cache,
-                       (const bf16_t*)v_cache, context_lens, block_tables, bt_stride, (bf16_t*)out,
-                       part_o, part_ml, nh, nkv, block_size, scale_log2e, splits);
-    GLM_CHECK_LAUNCH("glm_paged_attn_decode");
+    const dim3 grid((unsigned)splits, (unsigned)nkv, (unsigned)B);
+    PaFuse fu;
+    memset(&fu, 0, sizeof(fu));
+    if (fz) {
+        fu = *fuse;
+        hipLaunchKernelGGL((paged_attn_decode_kernel<1>), grid, dim3(256), PA_LDS, st, (const bf16_t*)nullptr,
+                           (const bf16_t*)k_cache, (const bf16_t*)v_cache, context_lens, block_tables, bt_stride,
+                           (bf16_t*)out, part_o, part_ml, nh, nkv, block_size, scale_log2e, splits, fu);
+    } else {
+        hipLaunchKernelGGL((paged_attn_decode_kernel<0>), grid, dim3(256), PA_LDS, st, (const bf16_t*)q,
+                           (const bf16_t*)k_cache, (const bf16_t*)v_cache, context_lens, block_tables, bt_stride,
+                           (bf16_t*)out, part_o, part_ml, nh, nkv, block_size, scale_log2e, splits, fu);
+    }
+    GLM_CHECK_LAUNCH(name);
     if (splits > 1) {
         hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3((unsigned)(B * nh)), dim3(128), 0, st, part_o,
                            part_ml, (bf16_t*)out, splits);
-        GLM_CHECK_LAUNCH("glm_paged_attn_decode(reduce)");
+        GLM_CHECK_LAUNCH(name);
     }
     return GLM_OK;
+}
+
+extern "C" int glm_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache,
+                                     const int32_t* context_lens, const int32_t* block_tables,
+                                     int64_t bt_stride, void* out, int64_t B, int nh, int nkv, int hd,
+                                     int block_size, int64_t n_blocks, float scale, int num_splits,
+                                     int max_context_len, void* workspace, size_t workspace_bytes,
+                                     glm_stream_t stream) {
+    (void)n_blocks;
+    GLM_CHECK_ARG(q && k_cache && v_cache && context_lens && block_tables && out, GLM_ERR_INVALID,
+                  "glm_paged_attn_decode: null pointer");
+    GLM_CHECK_ARG(glm_aligned16(q) && glm_aligned16(k_cache) && glm_aligned16(v_cache) &&
+                      glm_aligned16(out),
+                  GLM_ERR_INVALID, "glm_paged_attn_decode: pointers must be 16-byte aligned");
+    return pa_launch(q, k_cache, v_cache, context_lens, block_tables, bt_stride, out, B, nh, nkv, hd, block_size, scale,
+                     num_splits, max_context_len, workspace, workspace_bytes, stream, nullptr, "glm_paged_attn_decode");
+}
+
+extern "C" int glm_paged_attn_decode_qkv(const void* qkv, int64_t qkv_stride, const int64_t* positions,
+                                         const float* cos_sin_cache, int rotary_dim, const int32_t* slot_mapping,
+                                         void* k_cache, void* v_cache, const int32_t* context_lens,
+                                         const int32_t* block_tables, int64_t bt_stride, void* out, int64_t B,
+                                         int nh, int nkv, int hd, int block_size, int64_t n_blocks, float scale,
+                                         int num_splits, int max_context_len, void* workspace,
+                                         size_t workspace_bytes, glm_stream_t stream) {
+    GLM_CHECK_ARG(qkv && positions && cos_sin_cache && slot_mapping && k_cache && v_cache && context_lens &&
+                      block_tables && out, GLM_ERR_INVALID, "glm_paged_attn_decode_qkv: null pointer");
+    GLM_CHECK_ARG(rotary_dim == 64 && qkv_stride >= (int64_t)(nh + 2 * nkv) * hd && qkv_stride % 8 == 0 && n_blocks > 0,
+                  GLM_ERR_UNSUPPORTED, "glm_paged_attn_decode_qkv: needs rotary_dim=64 (got %d) and a packed qkv row",
+                  rotary_dim);
+    GLM_CHECK_ARG(glm_aligned16(qkv) && glm_aligned16(k_cache) && glm_aligned16(v_cache) && glm_aligned16(out),
+                  GLM_ERR_INVALID, "glm_paged_attn_decode_qkv: pointers must be 16-byte aligned");
+    PaFuse fu;
+    fu.qkv = (const bf16_t*)qkv; fu.qkv_stride = qkv_stride; fu.pos = positions; fu.cos_sin = cos_sin_cache;
+    fu.slots = slot_mapping; fu.n_slots = n_blocks * block_size; fu.kc_w = (bf16_t*)k_cache; fu.vc_w = (bf16_t*)v_cache;
+    return pa_launch(nullptr, k_cache, v_cache, context_lens, block_tables, bt_stride, out, B, nh, nkv, hd, block_size,
+                     scale, num_splits, max_context_len, workspace, workspace_bytes, stream, &fu,
+                     "glm_paged_attn_decode_qkv");
 }

@@ -41,6 +41,9 @@ _SIGNATURES = {
     "glm_paged_attn_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64,
                                       c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "glm_paged_attn_decode_qkv": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                                          c_int64, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "glm_varlen_attn_prefill": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                         c_int, c_int, c_float, c_void_p]),
@@ -275,6 +278,39 @@ def paged_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
                                      _p(block_tables), block_tables.stride(0), _p(out), B, nh, nkv,
                                      hd, block_size, n_blocks, scale, num_splits, max_context_len,
                                      _p(ws), need, _stream()), "glm_paged_attn_decode")
+    return out
+
+
+def paged_attn_decode_qkv(qkv: torch.Tensor, nh: int, nkv: int, hd: int, positions: torch.Tensor,
+                          cos_sin_cache: torch.Tensor, rotary_dim: int, slot_mapping: torch.Tensor,
+                          k_cache: torch.Tensor, v_cache: torch.Tensor, context_lens: torch.Tensor,
+                          block_tables: torch.Tensor, scale: float, num_splits: int = 0,
+                          max_context_len: int = 0) -> torch.Tensor:
+    """Decode attention straight from the packed QKV rows [B, (nh+2nkv)*hd]: rotary on Q/K, K/V cache store and the
+    paged attention in one launch (no head RMSNorm, rotary_dim 64)."""
+    _bf16(qkv, "qkv"); _bf16(k_cache, "k_cache"); _bf16(v_cache, "v_cache")
+    B = qkv.shape[0]
+    n_blocks, block_size, nkv_c, _ = k_cache.shape
+    assert qkv.dim() == 2 and qkv.stride(1) == 1 and nkv_c == nkv
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and cos_sin_cache.dtype == torch.float32
+    assert cos_sin_cache.is_contiguous() and cos_sin_cache.shape[-1] == rotary_dim
+    assert positions.dtype == torch.int64 and slot_mapping.dtype == torch.int32
+    assert context_lens.dtype == torch.int32 and block_tables.dtype == torch.int32 and block_tables.stride(1) == 1
+    lib = load_library()
+    need = lib.glm_paged_attn_decode_workspace_bytes(B, nh, hd, num_splits)
+    ws = None
+    if need:
+        key = (qkv.device, need)
+        ws = _attn_ws.get(key)
+        if ws is None:
+            ws = torch.empty(need, dtype=torch.uint8, device=qkv.device)
+            _attn_ws[key] = ws
+    out = torch.empty((B, nh, hd), dtype=qkv.dtype, device=qkv.device)
+    _check(lib.glm_paged_attn_decode_qkv(_p(qkv), qkv.stride(0), _p(positions), _p(cos_sin_cache), rotary_dim,
+                                         _p(slot_mapping), _p(k_cache), _p(v_cache), _p(context_lens),
+                                         _p(block_tables), block_tables.stride(0), _p(out), B, nh, nkv, hd,
+                                         block_size, n_blocks, scale, num_splits, max_context_len, _p(ws), need,
+                                         _stream()), "glm_paged_attn_decode_qkv")
     return out
 
 

@@ -58,6 +58,8 @@ class Glm4MoeAttention(nn.Module):
         self.attn = Attention(self.num_heads, self.head_dim, self.scaling, self.num_kv_heads,
                               cache_config=None, quant_config=quant_config, prefix=f"{prefix}.attn")
 
+    fuse_decode_attention = True
+
     def _fusable(self) -> bool:
         lph = self.head_dim // 8
         return (self.head_dim % 8 == 0 and lph >= 2 and lph <= 64 and (lph & (lph - 1)) == 0
@@ -70,6 +72,15 @@ class Glm4MoeAttention(nn.Module):
         ctx = get_context()
         attn = self.attn
         has_cache = attn.k_cache.numel() > 0 and attn.v_cache.numel() > 0
+        if (self.fuse_decode_attention and not ctx.is_prefill and has_cache and not self.use_qk_norm
+                and self.head_dim == 128 and self.rotary_emb.rotary_dim == 64 and qkv.dim() == 2
+                and self.num_heads // self.num_kv_heads <= 16 and attn.k_cache.shape[1] % 32 == 0):
+            # decode: rotary, K/V cache store and paged attention in one launch, straight from the QKV rows
+            o = hip_ops.paged_attn_decode_qkv(
+                qkv, self.num_heads, self.num_kv_heads, self.head_dim, positions, self.rotary_emb.cos_sin_cache,
+                self.rotary_emb.rotary_dim, ctx.slot_mapping, attn.k_cache, attn.v_cache, ctx.context_lens,
+                ctx.block_tables, attn.scale)
+            return self.o_proj(o.reshape(o.shape[0], -1), defer_reduce=defer_o_reduce)
         if self._fusable():
             need_kv = ctx.is_prefill and ctx.block_tables is None
             q, k, v = hip_ops.qkv_split_norm_rope_store(

@@ -224,6 +224,18 @@ int glm_moe_combine_add_rmsnorm(const void* y, int64_t ldy, const int32_t* pair_
                                 int64_t shared_base, const void* residual_in, const void* weight,
                                 void* out, void* residual_out, float eps, glm_stream_t stream);
 
+/* a6+a7+a8 fused for decode (no head RMSNorm, rotary_dim 64): glm_paged_attn_decode that starts from the packed QKV
+ *     projection output [B, (nh+2nkv)*hd] — rotates Q in registers, and the workgroup that owns position len-1 rotates
+ *     the new K row and stores K/V at slot_mapping[b] (layers/attention.py:10-42) before it reads them back.
+ *     Same results as glm_qkv_split_norm_rope_store followed by glm_paged_attn_decode.                       */
+int glm_paged_attn_decode_qkv(const void* qkv, int64_t qkv_stride, const int64_t* positions,
+                              const float* cos_sin_cache, int rotary_dim, const int32_t* slot_mapping,
+                              void* k_cache, void* v_cache, const int32_t* context_lens,
+                              const int32_t* block_tables, int64_t bt_stride, void* out, int64_t B,
+                              int nh, int nkv, int hd, int block_size, int64_t n_blocks, float scale,
+                              int num_splits, int max_context_len, void* workspace,
+                              size_t workspace_bytes, glm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

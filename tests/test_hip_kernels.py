@@ -172,6 +172,32 @@ def test_paged_attn_decode(ops, lens, nh, nkv, splits):
     assert_mixed(out, ref, 1.6e-2, 4e-3, f"paged decode lens={lens} splits={splits}")
 
 
+@pytest.mark.parametrize("lens,nh,nkv,splits", [([300, 256, 5, 33], 4, 2, 0), ([1, 31, 32, 33, 1000], 24, 2, 3),
+                                                 ([2048, 129], 96, 8, 0), ([17], 16, 1, 2), ([513, 512], 12, 1, 5)])
+def test_paged_attn_decode_from_qkv(ops, lens, nh, nkv, splits):
+    """One launch (rotary + K/V cache store + attention from the packed QKV rows) == split/rope/store followed by
+    the paged attention, bit for bit: outputs and cache contents."""
+    _, kc, vc, cl, bt = _paged_case(lens, nh, nkv, seed=len(lens) * 11 + nh)
+    B, hd, bs, rd = len(lens), 128, 256, 64
+    g = torch.Generator().manual_seed(1234 + nh)
+    qkv = (torch.randn(B, (nh + 2 * nkv) * hd, generator=g) * 1.5).to(BF)
+    pos = torch.tensor([n - 1 for n in lens], dtype=torch.int64)
+    slots = torch.tensor([int(bt[b, (n - 1) // bs]) * bs + (n - 1) % bs for b, n in enumerate(lens)], dtype=torch.int32)
+    inv = 1.0 / (1e6 ** (torch.arange(0, rd, 2, dtype=torch.float) / rd))
+    fr = torch.outer(torch.arange(4096, dtype=torch.float), inv)
+    cs = torch.cat((fr.cos(), fr.sin()), -1).unsqueeze(1).contiguous()
+    scale = hd ** -0.5
+    kc0, vc0, kc1, vc1 = dev(kc), dev(vc), dev(kc), dev(vc)
+    q, _, _ = ops.qkv_split_norm_rope_store(dev(qkv), nh, nkv, hd, dev(pos), dev(cs), rd, None, None, 1e-5,
+                                            kc0, vc0, dev(slots), False)
+    out0 = ops.paged_attn_decode(q, kc0, vc0, dev(cl), dev(bt), scale, num_splits=splits)
+    out1 = ops.paged_attn_decode_qkv(dev(qkv), nh, nkv, hd, dev(pos), dev(cs), rd, dev(slots), kc1, vc1, dev(cl),
+                                     dev(bt), scale, num_splits=splits)
+    assert torch.equal(kc0, kc1) and torch.equal(vc0, vc1), "cache contents differ"
+    assert not torch.equal(kc1.cpu(), kc), "the new rows must have been written"
+    assert torch.equal(out0, out1)
+
+
 def test_paged_attn_decode_spiky_scores(ops):
     """Force the online-softmax rescale: one key far above the rest late in the sequence."""
     q, kc, vc, cl, bt = _paged_case([777], 12, 1, seed=99)
