@@ -176,14 +176,15 @@ def mlp(x, w_gate_up, w_down):
 
 # ---------------------------------------------------------------------------------------------
 # a11  models/glm4_moe/moe.py:28-50
-def router(x, gate_w, e_score_correction_bias, top_k: int, routed_scaling_factor: float):
+def router(x, gate_w, e_score_correction_bias, top_k: int, routed_scaling_factor: float, force_idx=None):
     """R1..R7 of SURVEY.md §8a: bf16 logits → bf16 sigmoid → +fp32 bias → top-k (unsorted) →
-    gather un-biased scores → renormalise (always) → scale."""
+    gather un-biased scores → renormalise (always) → scale.  `force_idx` (test aid, no reference counterpart)
+    replaces the top-k DECISION R4 only; the weights R5-R7 are still computed here from this call's scores."""
     h = x.reshape(-1, x.shape[-1])
     logits = F.linear(h, gate_w)
     scores = logits.sigmoid()
     choice = scores + e_score_correction_bias.unsqueeze(0)
-    idx = torch.topk(choice, k=top_k, dim=-1, sorted=False)[1]
+    idx = torch.topk(choice, k=top_k, dim=-1, sorted=False)[1] if force_idx is None else force_idx
     w = scores.gather(1, idx)
     w = w / (w.sum(dim=-1, keepdim=True) + 1e-20)
     w = w * routed_scaling_factor
@@ -200,12 +201,14 @@ def router_scores(x, gate_w, e_score_correction_bias):
 
 # a12  models/glm4_moe/moe.py:128-176
 def moe(x, gate_w, bias, top_k, routed_scaling_factor, w13, w2, shared_w13, shared_w2,
-        topk=None):
+        topk=None, force_idx=None, trace=None):
     """Per-expert loop in ascending expert id, accumulation in the tensor dtype (index_add_),
     then + shared expert.  w13 [E,2I,H], w2 [E,H,I].  `topk` overrides the routing decision
     (used to isolate the expert arithmetic from router rounding in tests)."""
     h = x.reshape(-1, x.shape[-1])
-    idx, w = router(h, gate_w, bias, top_k, routed_scaling_factor) if topk is None else topk
+    idx, w = router(h, gate_w, bias, top_k, routed_scaling_factor, force_idx) if topk is None else topk
+    if trace is not None:
+        trace.update(h_router=h, idx=idx, w=w)
     acc = torch.zeros_like(h)
     for e in range(w13.shape[0]):
         hit = idx == e
@@ -240,6 +243,17 @@ class LayerWeights:
         # dense layer
         self.dense_w13 = kw.get("dense_w13")
         self.dense_w2 = kw.get("dense_w2")
+
+
+    def to(self, dtype):
+        """Same tensors in another floating dtype (integer/None fields untouched).  Every function of this file is
+        dtype-generic: with fp32 tensors each `.to(dt)` / F.linear rounding point of the reference vanishes, so
+        `lw.to(torch.float32)` + fp32 activations IS the rounding-free fp32 evaluation of the same algorithm
+        (used by the tests to state the HIP path's error against exact arithmetic next to its error against the
+        reference's bf16 arithmetic)."""
+        kw = {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v)
+              for k, v in self.__dict__.items()}
+        return LayerWeights(**kw)
 
 
 class AttnMeta:
@@ -284,34 +298,45 @@ def attention_block(h, positions, lw: LayerWeights, cfg, cos_sin_cache, k_cache,
 
 
 def decoder_layer(positions, h, residual, lw: LayerWeights, cfg, cos_sin_cache, k_cache,
-                  v_cache, meta: AttnMeta):
+                  v_cache, meta: AttnMeta, force_idx=None, trace=None):
     """decode_layer.py:79-100 — returns (mlp_out, residual); mlp_out is NOT added to the
-    residual here (the next layer's add_rms does it)."""
+    residual here (the next layer's add_rms does it).  `trace` (a dict) receives the intermediates the tests
+    compare (attention output, router input, routing); `force_idx` is handed to `router`."""
     eps = cfg["rms_norm_eps"]
     if residual is None:
         h, residual = rms_forward(h, lw.input_ln, eps), h
     else:
         h, residual = add_rms_forward(h, residual, lw.input_ln, eps)
     h = attention_block(h, positions, lw, cfg, cos_sin_cache, k_cache, v_cache, meta)
+    if trace is not None:
+        trace["attn_out"] = h
     h, residual = add_rms_forward(h, residual, lw.post_ln, eps)
     if lw.gate_w is not None:
         h = moe(h, lw.gate_w, lw.gate_bias, cfg["num_experts_per_tok"],
-                cfg["routed_scaling_factor"], lw.w13, lw.w2, lw.shared_w13, lw.shared_w2)
+                cfg["routed_scaling_factor"], lw.w13, lw.w2, lw.shared_w13, lw.shared_w2,
+                force_idx=force_idx, trace=trace)
     else:
         h = mlp(h, lw.dense_w13, lw.dense_w2)
     return h, residual
 
 
 def model_forward(input_ids, positions, embed_w, layers, final_norm_w, cfg, cos_sin_cache,
-                  kv_caches, meta: AttnMeta):
+                  kv_caches, meta: AttnMeta, final_norm_without_residual: bool = True, force_idx=None,
+                  traces=None):
     """models/glm4_moe/model.py:64-78 — note the final norm is applied to the last MLP output
-    WITHOUT the residual (model.py:75-76)."""
+    WITHOUT the residual (model.py:75-76, the add+norm line is commented out there);
+    `final_norm_without_residual=False` evaluates that commented-out add+norm instead (what a full-depth
+    checkpoint needs).  force_idx / traces: per-layer lists handed to decoder_layer."""
     h = F.embedding(input_ids, embed_w)
     residual = None
     for i, lw in enumerate(layers):
         kc, vc = kv_caches[i] if kv_caches is not None else (None, None)
-        h, residual = decoder_layer(positions, h, residual, lw, cfg, cos_sin_cache, kc, vc, meta)
-    return rms_forward(h, final_norm_w, cfg["rms_norm_eps"])
+        h, residual = decoder_layer(positions, h, residual, lw, cfg, cos_sin_cache, kc, vc, meta,
+                                    force_idx=None if force_idx is None else force_idx[i],
+                                    trace=None if traces is None else traces[i])
+    if final_norm_without_residual or residual is None:
+        return rms_forward(h, final_norm_w, cfg["rms_norm_eps"])
+    return add_rms_forward(h, residual, final_norm_w, cfg["rms_norm_eps"])[0]
 
 
 def greedy_sample(logits):

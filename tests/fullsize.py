@@ -1,0 +1,198 @@
+"""Shared helpers of the FULL-SIZE parity tests (BASELINE configs C2/C3 at GLM-4.5-Air "Air-64E" dims).
+
+Inputs follow SURVEY.md §8d: weights ~ N(0, 0.02^2) bf16, norm weights 1 + N(0, 0.02^2), qkv bias N(0, 0.02^2),
+e_score_correction_bias ~ U(-0.1, 0.1) fp32, hidden ~ N(0, 1), KV cache pre-filled N(0, 1), block tables a seeded
+permutation of the block ids, slot = last position of every sequence.  The tensors are drawn on the GPU (seeded
+generator) and copied to the CPU oracle, so both sides see the same bytes."""
+from __future__ import annotations
+
+import json
+import os
+import time
+import types
+
+import torch
+
+from oracle import from_product
+from oracle import glm4_moe_oracle as O
+from util import bf16_ulp_diff
+
+BF = torch.bfloat16
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+REPORT = os.path.join(ROOT, "gpurun_out", "parity_fullsize.jsonl")
+
+AIR64E = dict(
+    hidden_size=4096, num_attention_heads=96, num_key_value_heads=8, head_dim=128, attention_bias=True,
+    use_qk_norm=False, partial_rotary_factor=0.5, rope_theta=1000000.0, rope_scaling=None,
+    max_position_embeddings=4096, rms_norm_eps=1e-5, n_routed_experts=64, num_experts_per_tok=8, n_group=1,
+    topk_group=1, routed_scaling_factor=1.0, moe_intermediate_size=1408, intermediate_size=10944,
+    first_k_dense_replace=1, hidden_act="silu", vocab_size=151552, num_hidden_layers=2, num_layers_to_load=2,
+    tie_word_embeddings=False)
+
+
+def air_cfg(**over):
+    return types.SimpleNamespace(**dict(AIR64E, **over))
+
+
+def init_seeded(module, seed: int) -> None:
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    for name, p in module.named_parameters():
+        if "layernorm" in name or name.endswith("norm.weight"):
+            p.data.normal_(0.0, 0.02, generator=g).add_(1.0)
+        else:
+            p.data.normal_(0.0, 0.02, generator=g)
+    for name, b in module.named_buffers():
+        if name.endswith("e_score_correction_bias"):
+            b.uniform_(-0.1, 0.1, generator=g)
+
+
+def build_layer(cfg, layer_idx: int, seed: int = 0):
+    from nanovllm.layers.rotary_embedding import get_rope
+    from nanovllm.models.glm4_moe.decode_layer import Glm4MoeDecoderLayer
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(BF)
+    get_rope.cache_clear()
+    try:
+        with torch.device("cuda"):
+            layer = Glm4MoeDecoderLayer(cfg, prefix=f"model.layers.{layer_idx}")
+    finally:
+        torch.set_default_dtype(old)
+    init_seeded(layer, seed)
+    return layer
+
+
+def build_model(cfg, seed: int = 0):
+    from nanovllm.layers.rotary_embedding import get_rope
+    from nanovllm.models.glm4_moe.model import Glm4MoeForCausalLM
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(BF)
+    get_rope.cache_clear()
+    try:
+        with torch.device("cuda"):
+            model = Glm4MoeForCausalLM(cfg)
+    finally:
+        torch.set_default_dtype(old)
+    init_seeded(model, seed)
+    return model
+
+
+def paged_decode_inputs(B: int, ctx: int, nkv: int, hd: int, seed: int, n_layers: int = 1, bs: int = 256,
+                        pad_rows: int = 0):
+    """KV caches [L][2] of [nblk, bs, nkv, hd] pre-filled N(0,1), permuted block tables, decode metadata for B
+    sequences of length ctx (positions ctx-1, the token being written).  `pad_rows` extra batch rows are graph
+    padding: slot -1, context_len 0, block table -1 (model_runner.py:207-209)."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    per = (ctx + bs - 1) // bs
+    nblk = B * per + 8
+    caches = [(torch.randn(nblk, bs, nkv, hd, device="cuda", generator=g).to(BF),
+               torch.randn(nblk, bs, nkv, hd, device="cuda", generator=g).to(BF)) for _ in range(n_layers)]
+    perm = torch.randperm(nblk, generator=torch.Generator().manual_seed(seed + 1))[: B * per].view(B, per)
+    bt = perm.to(torch.int32)
+    cl = torch.full((B,), ctx, dtype=torch.int32)
+    pos = torch.full((B,), ctx - 1, dtype=torch.int64)
+    slots = (bt[:, (ctx - 1) // bs].to(torch.int64) * bs + (ctx - 1) % bs).to(torch.int32)
+    if pad_rows:
+        bt = torch.cat([bt, torch.full((pad_rows, per), -1, dtype=torch.int32)])
+        cl = torch.cat([cl, torch.zeros(pad_rows, dtype=torch.int32)])
+        pos = torch.cat([pos, torch.zeros(pad_rows, dtype=torch.int64)])
+        slots = torch.cat([slots, torch.full((pad_rows,), -1, dtype=torch.int32)])
+    return caches, bt, cl, pos, slots
+
+
+def randn_bf16(*shape, seed: int, scale: float = 1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(*shape, device="cuda", generator=g) * scale).to(BF)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def err_stats(actual: torch.Tensor, expected: torch.Tensor, rows=None) -> dict:
+    """Error figures of `actual` against `expected` (both moved to CPU fp32): max |err|, max |err| / max |ref|,
+    the fraction of elements outside the reference scripts' own rtol = atol = 1e-2 (tests/moe.py:40), and — for
+    bf16 pairs — the ulp distance distribution."""
+    a, e = actual.detach().cpu(), expected.detach().cpu()
+    if rows is not None:
+        a, e = a[rows], e[rows]
+    af, ef = a.float(), e.float()
+    err = (af - ef).abs()
+    out = {"max_abs": float(err.max()), "max_ref": float(ef.abs().max()),
+           "max_rel_to_max": float(err.max() / ef.abs().max().clamp_min(1e-30)),
+           "rms_rel": float(err.norm() / ef.norm().clamp_min(1e-30)),
+           "frac_outside_1e-2": float((err > 1e-2 + 1e-2 * ef.abs()).float().mean()),
+           "frac_outside_1e-3": float((err > 1e-3 + 1e-3 * ef.abs()).float().mean())}
+    if a.dtype == BF and e.dtype == BF:
+        d = bf16_ulp_diff(a, e)
+        out.update(max_ulp=int(d.max()), frac_inexact=float((d > 0).float().mean()))
+    return out
+
+
+def report(case: str, **fields) -> None:
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    rec = {"case": case, "time": time.strftime("%Y-%m-%dT%H:%M:%S"), **fields}
+    with open(REPORT, "a") as f:
+        f.write(json.dumps(rec) + "\n")
+    print("PARITY", json.dumps(rec))
+
+
+def assert_allclose_ref_tol(actual, expected, what: str, rows=None, rtol: float = 1e-2, atol: float = 1e-2):
+    """The reference scripts' own acceptance test (torch.allclose(rtol=atol=1e-2), tests/moe.py:40, tests/mlp.py:65)."""
+    a, e = actual.detach().cpu().float(), expected.detach().cpu().float()
+    if rows is not None:
+        a, e = a[rows], e[rows]
+    err = (a - e).abs()
+    bad = err > atol + rtol * e.abs()
+    assert not bool(bad.any()), (f"{what}: {int(bad.sum())}/{a.numel()} elements outside rtol={rtol} atol={atol}; "
+                                 f"max err {float(err.max()):.4g} at ref magnitude {float(e.abs().max()):.4g}")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def router_proof(ops, h_router: torch.Tensor, gate_w, bias, k: int, rsf: float, idx_fused: torch.Tensor,
+                 w_fused: torch.Tensor, n_valid: int | None = None) -> dict:
+    """Bit-exactness of the top-k expert sets on the product's OWN router input (so upstream rounding is out of the
+    picture).  A row whose set differs from the CPU oracle's must be proven to be either an exact fp32 tie at the
+    selection boundary or a row whose bf16 logits themselves rounded differently (fp32 summation order of the
+    H-long dot product).  Returns counts; raises on an unexplained row."""
+    idx_s, w_s, logits = ops.router_topk(h_router, gate_w, bias, k, rsf, return_logits=True)
+    assert torch.equal(idx_s, idx_fused) and torch.equal(w_s, w_fused), \
+        "fused add-RMSNorm+router and the stand-alone router disagree on the same input"
+    T = n_valid if n_valid is not None else h_router.shape[0]  # rows beyond n_valid are graph padding
+    h, gw, b = h_router.cpu()[:T], gate_w.detach().cpu(), bias.detach().cpu()
+    ridx, rw = O.router(h, gw, b, k, rsf)
+    rlogits, _, rchoice = O.router_scores(h, gw, b)
+    idx, w, logits = idx_s.cpu()[:T], w_s.cpu()[:T], logits.cpu()[:T]
+    flips = ties = weight_ulp_rows = 0
+    for t in range(T):
+        if set(idx[t].tolist()) == set(ridx[t].tolist()):
+            order = torch.argsort(ridx[t])
+            if not torch.equal(w[t], rw[t][order]):
+                d = bf16_ulp_diff(w[t], rw[t][order])
+                assert int(d.max()) <= 1 and not torch.equal(logits[t], rlogits[t]), \
+                    f"row {t}: routing weights differ with identical logits"
+                weight_ulp_rows += 1
+            continue
+        sel = torch.zeros(gw.shape[0], dtype=torch.bool)
+        sel[ridx[t]] = True
+        tie = float(rchoice[t][sel].min()) == float(rchoice[t][~sel].max())
+        ldiff = not torch.equal(logits[t], rlogits[t])
+        assert tie or ldiff, f"row {t}: different expert set with identical logits and no tie"
+        ties += int(tie)
+        flips += int(ldiff and not tie)
+    return {"rows": T, "set_flips_from_logit_rounding": flips, "set_flips_from_ties": ties,
+            "rows_with_1ulp_weight": weight_ulp_rows,
+            "logit_elements_differing": float((logits != rlogits).float().mean())}
+
+
+def same_set_rows(idx_a: torch.Tensor, idx_b: torch.Tensor, margin: torch.Tensor, max_margin: float):
+    """Rows where two routings chose the same expert set; the others must be near-ties of the reference routing."""
+    keep, moved = [], []
+    for r in range(idx_a.shape[0]):
+        if set(idx_a[r].tolist()) == set(idx_b[r].tolist()):
+            keep.append(r)
+        else:
+            assert float(margin[r]) <= max_margin, \
+                f"row {r}: expert set differs although the reference's routing margin is {float(margin[r]):.4g}"
+            moved.append(r)
+    return torch.tensor(keep, dtype=torch.long), moved
+
+
+def oracle_layer_inputs(layer, cfg):
+    return from_product.layer_weights_from_module(layer), from_product.cfg_dict(cfg), from_product.cos_sin_cache(cfg)

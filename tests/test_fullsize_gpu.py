@@ -1,0 +1,329 @@
+"""FULL-SIZE parity: the instantiations bench.py times, compared with the CPU oracle at the BASELINE configs' own
+dimensions (GLM-4.5-Air "Air-64E": H=4096, 96/8 heads x 128, E=64 top-8 + shared, I=1408, dense I=10944).
+
+    C3  bs=32, ctx=4096  (the config the metric is quoted on)   -> test_c3_*
+    C2  bs=1,  ctx=1024  (greedy single-sequence decode)         -> test_c2_*
+
+Every test appends its observed error figures to gpurun_out/parity_fullsize.jsonl (copied to profiles/ per round):
+HIP vs the reference's bf16 arithmetic (oracle), HIP vs the rounding-free fp32 evaluation of the same algorithm, and
+the oracle's own distance from that fp32 evaluation.  Acceptance = the reference scripts' own rtol = atol = 1e-2
+(nanovllm/tests/moe.py:40, tests/mlp.py:65) on every row whose expert set agrees; rows whose set differs must be
+near-ties of the reference routing (margin below 2 bf16 ulp of a score), and on the product's own router input the
+expert sets must be bit-exact up to PROVEN logit-rounding flips / fp32 ties (fullsize.router_proof).
+Reference path: models/glm4_moe/decode_layer.py:79-100."""
+import pytest
+import torch
+
+import fullsize as F
+from oracle import glm4_moe_oracle as O
+from util import assert_close_bf16, router_margin
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from nanovllm import hip_ops
+    hip_ops.load_library()
+    return hip_ops
+
+
+def _layer_decode_case(ops, tag: str, B: int, ctx: int, layer_idx: int, pad_rows: int = 0):
+    from nanovllm.utils.context import reset_context, set_context
+    cfg = F.air_cfg()
+    layer = F.build_layer(cfg, layer_idx, seed=0)
+    nkv, hd, H = cfg.num_key_value_heads, cfg.head_dim, cfg.hidden_size
+    caches, bt, cl, pos, slots = F.paged_decode_inputs(B, ctx, nkv, hd, seed=7, pad_rows=pad_rows)
+    kc, vc = caches[0]
+    kc0, vc0 = kc.cpu(), vc.cpu()
+    Bp = B + pad_rows
+    h, res = F.randn_bf16(Bp, H, seed=1), F.randn_bf16(Bp, H, seed=2)
+    layer.self_attn.attn.k_cache, layer.self_attn.attn.v_cache = kc, vc
+    cap = {}
+    is_moe = hasattr(layer.mlp, "gate")
+    if is_moe:
+        layer.mlp.register_forward_pre_hook(
+            lambda m, a, kw: cap.update(h_router=a[0], routing=kw.get("routing")), with_kwargs=True)
+    set_context(False, slot_mapping=slots.cuda(), context_lens=cl.cuda(), block_tables=bt.cuda())
+    with torch.inference_mode():
+        out, res_out = layer(pos.cuda(), h, res)
+    reset_context()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all() and torch.isfinite(res_out.float()).all()
+
+    # ---- oracle: the reference's bf16 arithmetic, then the rounding-free fp32 evaluation on the same routing ----
+    lw, cfgd, cs = F.oracle_layer_inputs(layer, cfg)
+    meta = O.AttnMeta(False, slot_mapping=slots[:B], context_lens=cl[:B], block_tables=bt[:B])
+    hc, rc = h.cpu()[:B], res.cpu()[:B]
+    kc_ref, vc_ref = kc0.clone(), vc0.clone()
+    tr = {}
+    ref_out, ref_res = O.decoder_layer(pos[:B], hc, rc, lw, cfgd, cs, kc_ref, vc_ref, meta, trace=tr)
+    tr32 = {}
+    out32, res32 = O.decoder_layer(pos[:B], hc.float(), rc.float(), lw.to(torch.float32), cfgd, cs, kc0.float(),
+                                   vc0.float(), meta, force_idx=tr.get("idx"), trace=tr32)
+
+    # ---- KV cache: the new rows, and nothing else touched ----
+    D = nkv * hd
+    s = slots[:B].long()
+    kg, vg = kc.cpu().view(-1, D), vc.cpu().view(-1, D)
+    st_k, st_v = F.err_stats(kg[s], kc_ref.view(-1, D)[s]), F.err_stats(vg[s], vc_ref.view(-1, D)[s])
+    untouched = torch.ones(kg.shape[0], dtype=torch.bool)
+    untouched[s] = False
+    assert torch.equal(kg[untouched], kc0.view(-1, D)[untouched]) and torch.equal(vg[untouched], vc0.view(-1, D)[untouched])
+    st_res = F.err_stats(res_out[:B], ref_res)
+
+    # ---- routing ----
+    routing = {}
+    rows = None
+    if is_moe:
+        idx_f, w_f = cap["routing"]
+        gate = layer.mlp.gate
+        routing = F.router_proof(ops, cap["h_router"], gate.weight.data, gate.e_score_correction_bias, gate.top_k,
+                                 float(gate.routed_scaling_factor), idx_f, w_f, n_valid=B)
+        _, _, choice = O.router_scores(tr["h_router"], lw.gate_w, lw.gate_bias)
+        rows, moved = F.same_set_rows(idx_f[:B].cpu(), tr["idx"], router_margin(choice, gate.top_k), 0.016)
+        routing["rows_moved_by_upstream_rounding"] = len(moved)
+        assert len(rows) >= (3 * B + 3) // 4, f"{tag}: {len(moved)}/{B} rows routed differently"
+
+    st_out = F.err_stats(out[:B], ref_out, rows)
+    st_out32 = F.err_stats(out[:B], out32, rows)
+    st_ref32 = F.err_stats(ref_out, out32, rows)
+    F.report(tag, B=B, ctx=ctx, layer_idx=layer_idx, pad_rows=pad_rows, k_rows=st_k, v_rows=st_v, residual=st_res,
+             out_vs_oracle_bf16=st_out, out_vs_fp32=st_out32, oracle_bf16_vs_fp32=st_ref32, routing=routing)
+
+    if pad_rows:  # graph padding rows (slot -1, context_len 0) must come out finite; they are never read
+        assert torch.isfinite(out[B:].float()).all()
+    # V rows: qkv GEMM + bias only (one fp32 reduction); K rows: the same through the rotary
+    assert_close_bf16(vg[s], vc_ref.view(-1, D)[s], 1, 0.05, atol=2 ** -9, what=f"{tag} v rows")
+    assert_close_bf16(kg[s], kc_ref.view(-1, D)[s], 2, 0.05, atol=2 ** -5, what=f"{tag} k rows")
+    assert_close_bf16(res_out[:B], ref_res, 2, 0.05, atol=2 ** -7, what=f"{tag} residual")
+    F.assert_allclose_ref_tol(out[:B], ref_out, f"{tag} out", rows)
+    # the HIP path must be as close to exact arithmetic as the reference's own bf16 evaluation is
+    assert st_out32["rms_rel"] <= 1.25 * st_ref32["rms_rel"] + 1e-4, (st_out32, st_ref32)
+
+
+def test_c3_moe_layer_decode(ops):
+    """(i) one MoE decoder layer, decode B=32 ctx=4096 over a permuted block table."""
+    _layer_decode_case(ops, "C3.layer_moe_decode", 32, 4096, 1)
+
+
+def test_c2_moe_layer_decode(ops):
+    """(ii) bs=1 ctx=1024: the R<=16 gate|up configuration and the split + reduce attention."""
+    _layer_decode_case(ops, "C2.layer_moe_decode", 1, 1024, 1)
+
+
+def test_c2_dense_layer_decode(ops):
+    """(ii) layer 0 (dense MLP, I=10944) at bs=1 ctx=1024: the dense down-projection configuration."""
+    _layer_decode_case(ops, "C2.layer_dense_decode", 1, 1024, 0)
+
+
+def test_graph_bucket_padding_rows(ops):
+    """bs=3 in a 4-bucket at Air dims: the padding row (slot -1, context_len 0, block table -1) goes through the fused
+    decode attention (paged_attn.hip) without touching the cache or producing NaNs; the real rows still match."""
+    _layer_decode_case(ops, "pad.layer_moe_decode_3of4", 3, 777, 1, pad_rows=1)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def _bench_routing(ops, cfg, T, seed):
+    """x, router weights and the sorted-row structure exactly as bench.py's kernel measurements build them."""
+    H, E, k = cfg.hidden_size, cfg.n_routed_experts, cfg.num_experts_per_tok
+    x = F.randn_bf16(T, H, seed=seed)
+    gw = F.randn_bf16(E, H, seed=seed + 1, scale=0.02)
+    bias = (torch.rand(E, generator=torch.Generator().manual_seed(seed + 2)) * 0.2 - 0.1).float().cuda()
+    idx, w = ops.router_topk(x, gw, bias, k, 1.0)
+    offs, tok, scale, pos = ops.moe_align(idx, w, E, True)
+    return x, idx, w, offs, tok, scale, pos
+
+
+def _check_groups(tag, x, w13, w2, offs, tok, scale, act, y, E, groups, row_sel):
+    """Per-expert rows of the two grouped GEMMs against the oracle's expert MLP pieces (mlp.py:49-54, moe.py:149)."""
+    offs_c, tok_c, scale_c = offs.cpu(), tok.cpu(), scale.cpu()
+    worst = {"act": None, "y": None}
+    for e in groups:
+        lo, hi = int(offs_c[e]), int(offs_c[e + 1])
+        if lo == hi:
+            continue
+        rr = row_sel(lo, hi)                           # slice or CPU index tensor
+        rg = rr.cuda() if torch.is_tensor(rr) else rr
+        xe = x[tok[rg].long()].cpu()
+        a_ref = O.silu_and_mul(O.linear(xe, w13[e].cpu()))
+        a_got = act[rg].cpu()
+        # gate, up and bf16(silu) can each flip one ulp through the fp32 summation order: <= 3 ulp stacked
+        assert_close_bf16(a_got, a_ref, 3, 0.06, atol=1e-3, what=f"{tag} act group {e}")
+        y_ref = O.linear(a_got, w2[e].cpu())          # the product's own act rows: isolates the down GEMM
+        if e < E:
+            y_ref = y_ref * scale_c[rr].unsqueeze(-1)  # bf16 multiply by the routing weight (moe.py:149)
+        assert_close_bf16(y[rg].cpu(), y_ref, 1, 0.05, atol=2 ** -9, what=f"{tag} y group {e}")
+        for name, got, ref in (("act", a_got, a_ref), ("y", y[rg].cpu(), y_ref)):
+            st = F.err_stats(got, ref)
+            if worst[name] is None or st["max_ulp"] > worst[name]["max_ulp"] or st["frac_inexact"] > worst[name]["frac_inexact"]:
+                worst[name] = st
+    return worst
+
+
+def test_c3_grouped_gemms_decode_shape(ops):
+    """(iii) grouped gate|up+SiLU and down at H=4096, I=1408, G=65 with the bench's routing at T=32 — the
+    gemm_smallm LDS-DMA instantiations — every group, every row."""
+    cfg = F.air_cfg()
+    H, E, k, I = cfg.hidden_size, cfg.n_routed_experts, cfg.num_experts_per_tok, cfg.moe_intermediate_size
+    T = 32
+    x, idx, w, offs, tok, scale, pos = _bench_routing(ops, cfg, T, seed=101)
+    w13 = ops.padded_weight(2 * I, H, E + 1, dtype=BF, device="cuda")
+    w2 = ops.padded_weight(H, I, E + 1, dtype=BF, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    w13.normal_(0.0, 0.02, generator=g)
+    w2.normal_(0.0, 0.02, generator=g)
+    R = T * k + T
+    act = ops.grouped_gemm_gateup_silu(x, w13, offs, tok, R)
+    y = ops.grouped_gemm_down(act, w2, offs, scale, E)
+    torch.cuda.synchronize()
+    worst = _check_groups("C3 decode", x, w13, w2, offs, tok, scale, act, y, E, range(E + 1),
+                          lambda lo, hi: slice(lo, hi))
+    touched = int((offs.cpu()[1:E + 1] - offs.cpu()[:E] > 0).sum())
+    # single sequence (C2): R <= 16 configuration
+    x1, idx1, w1, offs1, tok1, scale1, pos1 = _bench_routing(ops, cfg, 1, seed=111)
+    act1 = ops.grouped_gemm_gateup_silu(x1, w13, offs1, tok1, k + 1)
+    y1 = ops.grouped_gemm_down(act1, w2, offs1, scale1, E)
+    worst1 = _check_groups("C2 decode", x1, w13, w2, offs1, tok1, scale1, act1, y1, E, range(E + 1),
+                           lambda lo, hi: slice(lo, hi))
+    F.report("C3.grouped_gemms_T32", touched_groups=touched, worst=worst)
+    F.report("C2.grouped_gemms_T1", worst=worst1)
+
+
+def test_c3_grouped_gemms_prefill_shape(ops):
+    """(iii) the MFMA-bound instantiation bench.py times (gemm_largem, T=16384 -> 147456 rows): sampled row ranges of
+    sampled groups (first rows, and the partial last row block) against the oracle, then — over ALL rows — the
+    size-independent property that the MoE block is permutation-equivariant bit for bit (a token's result may not
+    depend on where its rows land inside the expert groups / tiles)."""
+    cfg = F.air_cfg()
+    H, E, k, I = cfg.hidden_size, cfg.n_routed_experts, cfg.num_experts_per_tok, cfg.moe_intermediate_size
+    T = 16384
+    x, idx, w, offs, tok, scale, pos = _bench_routing(ops, cfg, T, seed=201)
+    w13 = ops.padded_weight(2 * I, H, E + 1, dtype=BF, device="cuda")
+    w2 = ops.padded_weight(H, I, E + 1, dtype=BF, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(6)
+    w13.normal_(0.0, 0.02, generator=g)
+    w2.normal_(0.0, 0.02, generator=g)
+    R = T * k + T
+    act = ops.grouped_gemm_gateup_silu(x, w13, offs, tok, R)
+    y = ops.grouped_gemm_down(act, w2, offs, scale, E)
+    out = ops.moe_combine(y, pos, T, k, T * k)
+    torch.cuda.synchronize()
+
+    def sel(lo, hi):  # first 384 rows + the last 200 (covers the group's partial last 256-row block)
+        n = hi - lo
+        return torch.cat([torch.arange(0, min(384, n)), torch.arange(max(0, n - 200), n)]).unique() + lo
+    worst = _check_groups("C3 prefill16k", x, w13, w2, offs, tok, scale, act, y, E, (0, 31, 63, 64), sel)
+    F.report("C3.grouped_gemms_T16384", worst=worst, rows=R)
+    # permutation equivariance over all 16384 tokens, bit for bit
+    perm = torch.randperm(T, generator=torch.Generator().manual_seed(9)).cuda()
+    xp = x[perm].contiguous()
+    idx2, w2r = idx[perm].contiguous(), w[perm].contiguous()
+    offs2, tok2, scale2, pos2 = ops.moe_align(idx2, w2r, E, True)
+    assert torch.equal(offs2, offs)
+    act2 = ops.grouped_gemm_gateup_silu(xp, w13, offs2, tok2, R)
+    y2 = ops.grouped_gemm_down(act2, w2, offs2, scale2, E)
+    out2 = ops.moe_combine(y2, pos2, T, k, T * k)
+    assert torch.equal(out2, out[perm]), "MoE block is not permutation-equivariant at T=16384"
+
+
+def test_c3_paged_attention_full_size(ops):
+    """(iv) paged decode attention at B=32, nh=96, nkv=8, ctx=4096 (the no-split instantiation bench.py times) and at
+    B=1 ctx=1024 (split + reduce), stand-alone and fused-from-QKV."""
+    nh, nkv, hd, rd = 96, 8, 128, 64
+    scale = hd ** -0.5
+    for tag, B, ctx in (("C3", 32, 4096), ("C2", 1, 1024)):
+        caches, bt, cl, pos, slots = F.paged_decode_inputs(B, ctx, nkv, hd, seed=17)
+        kc, vc = caches[0]
+        q = F.randn_bf16(B, nh, hd, seed=18)
+        out = ops.paged_attn_decode(q, kc, vc, cl.cuda(), bt.cuda(), scale)
+        torch.cuda.synchronize()
+        ref = O.attn_decode_paged(q.cpu(), kc.cpu(), vc.cpu(), cl, bt, scale)
+        ref32 = O.attn_decode_paged(q.cpu().float(), kc.cpu().float(), vc.cpu().float(), cl, bt, scale)
+        st, st32, so = F.err_stats(out, ref), F.err_stats(out, ref32), F.err_stats(ref, ref32)
+        F.report(f"{tag}.paged_attn_decode", B=B, ctx=ctx, vs_oracle=st, vs_fp32=st32, oracle_vs_fp32=so)
+        # outputs are averages of ~ctx N(0,1) values (|o| ~ 0.02-0.1): the reference's attention tolerance
+        # rtol = atol = 1e-3 (tests/attention.py:37, fp16) is met in absolute terms
+        F.assert_allclose_ref_tol(out, ref, f"{tag} paged attention", rtol=1.6e-2, atol=1e-3)
+        # fused: rotary + cache store + attention straight from the packed QKV rows == the unfused sequence
+        qkv = F.randn_bf16(B, (nh + 2 * nkv) * hd, seed=19, scale=1.3)
+        cs = O.build_cos_sin_cache(rd, 4096, 1e6).cuda()
+        kc0, vc0, kc1, vc1 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
+        qr, _, _ = ops.qkv_split_norm_rope_store(qkv, nh, nkv, hd, pos.cuda(), cs, rd, None, None, 1e-5, kc0, vc0,
+                                                 slots.cuda(), False)
+        o0 = ops.paged_attn_decode(qr, kc0, vc0, cl.cuda(), bt.cuda(), scale)
+        o1 = ops.paged_attn_decode_qkv(qkv, nh, nkv, hd, pos.cuda(), cs, rd, slots.cuda(), kc1, vc1, cl.cuda(),
+                                       bt.cuda(), scale)
+        assert torch.equal(kc0, kc1) and torch.equal(vc0, vc1) and torch.equal(o0, o1), f"{tag}: fused != unfused"
+        # and against the oracle chain split -> rope -> store -> attention
+        qc, kcpu, vcpu = qkv.cpu().split([nh * hd, nkv * hd, nkv * hd], dim=-1)
+        qo, ko = O.rope_neox(pos, qc.reshape(B, nh, hd), kcpu.reshape(B, nkv, hd), cs.cpu(), rd)
+        kr, vr = kc.cpu(), vc.cpu()
+        O.store_kvcache(ko, vcpu.reshape(B, nkv, hd), kr, vr, slots)
+        assert torch.equal(kc1.cpu(), kr) and torch.equal(vc1.cpu(), vr), "rotary + cache store must be bit-exact"
+        ref1 = O.attn_decode_paged(qo, kr, vr, cl, bt, scale)
+        F.report(f"{tag}.paged_attn_decode_qkv", vs_oracle=F.err_stats(o1, ref1))
+        F.assert_allclose_ref_tol(o1, ref1, f"{tag} fused paged attention", rtol=1.6e-2, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def test_c3_model_logits(ops):
+    """Numeric logits parity (north star: "logits within 1e-3 bf16 rtol"): the model wrapper at Air dims, L=2 (layer
+    0 dense, layer 1 MoE — the reference's own instantiation, model.py:21-22), decode B=32 ctx=4096, final norm quirk
+    and lm_head (model.py:141-145, embed_head.py:57-67).  bf16 logits cannot agree to 1e-3 elementwise (one bf16 ulp
+    is 3.9e-3 relative); what is asserted is (a) max |logit error| relative to max |logit| <= 1e-2, (b) the HIP
+    logits are no further from the fp32 evaluation than the reference's own bf16 evaluation is, (c) greedy tokens
+    agree wherever the oracle's top-2 margin exceeds the observed error.  The 1e-3 figure is printed beside them."""
+    from nanovllm.utils.context import reset_context, set_context
+    B, ctx = 32, 4096
+    cfg = F.air_cfg()
+    model = F.build_model(cfg, seed=3)
+    model.model.embed_tokens.weight.data.normal_(0.0, 1.0, generator=torch.Generator(device="cuda").manual_seed(4))
+    nkv, hd = cfg.num_key_value_heads, cfg.head_dim
+    caches, bt, cl, pos, slots = F.paged_decode_inputs(B, ctx, nkv, hd, seed=27, n_layers=2)
+    cpu_caches = [(k.cpu(), v.cpu()) for k, v in caches]
+    for layer, (kc, vc) in zip(model.model.layers, caches):
+        layer.self_attn.attn.k_cache, layer.self_attn.attn.v_cache = kc, vc
+    ids = torch.randint(0, cfg.vocab_size, (B,), generator=torch.Generator().manual_seed(28))
+    caps = [{} for _ in model.model.layers]
+    for layer, cap in zip(model.model.layers, caps):
+        if hasattr(layer.mlp, "gate"):
+            layer.mlp.register_forward_pre_hook(
+                lambda m, a, kw, cap=cap: cap.update(idx=kw["routing"][0]), with_kwargs=True)
+    set_context(False, slot_mapping=slots.cuda(), context_lens=cl.cuda(), block_tables=bt.cuda())
+    with torch.inference_mode():
+        hid = model(ids.cuda(), pos.cuda())
+        logits = model.compute_logits(hid)
+    reset_context()
+    torch.cuda.synchronize()
+    from oracle import from_product
+    lws = [from_product.layer_weights_from_module(l) for l in model.model.layers]
+    cfgd, cs = from_product.cfg_dict(cfg), from_product.cos_sin_cache(cfg)
+    meta = O.AttnMeta(False, slot_mapping=slots, context_lens=cl, block_tables=bt)
+    embed, normw, headw = (model.model.embed_tokens.weight.detach().cpu(), model.model.norm.weight.detach().cpu(),
+                           model.lm_head.weight.detach().cpu())
+    traces = [{} for _ in lws]
+    href = O.model_forward(ids, pos, embed, lws, normw, cfgd, cs, [(k.clone(), v.clone()) for k, v in cpu_caches],
+                           meta, traces=traces)
+    lref = O.linear(href, headw)
+    forced = [t.get("idx") for t in traces]
+    h32 = O.model_forward(ids, pos, embed.float(), [l.to(torch.float32) for l in lws], normw.float(), cfgd, cs,
+                          [(k.float(), v.float()) for k, v in cpu_caches], meta, force_idx=forced)
+    l32 = O.linear(h32, headw.float())
+    # rows where the MoE layer routed like the oracle (others: near-ties, checked by the layer tests)
+    keep = [r for r in range(B) if set(caps[1]["idx"][r].tolist()) == set(traces[1]["idx"][r].tolist())]
+    rows = torch.tensor(keep, dtype=torch.long)
+    st, st32, so = F.err_stats(logits, lref, rows), F.err_stats(logits, l32, rows), F.err_stats(lref, l32, rows)
+    lg, lr = logits.float().cpu()[rows], lref.float()[rows]
+    top2 = torch.topk(lr, 2, dim=-1)
+    margin = top2.values[:, 0] - top2.values[:, 1]
+    agree = lg.argmax(-1) == top2.indices[:, 0]
+    err_row = (lg - lr).abs().amax(-1)
+    F.report("C3.model_logits_L2", rows_compared=len(keep), vs_oracle=st, vs_fp32=st32, oracle_vs_fp32=so,
+             north_star_rtol=1e-3, greedy_agree=int(agree.sum()), greedy_rows=len(keep),
+             min_margin_where_disagree=float(margin[~agree].min()) if bool((~agree).any()) else None)
+    assert len(keep) >= 24
+    F.assert_allclose_ref_tol(logits, lref, "logits", rows)
+    assert st32["rms_rel"] <= 1.25 * so["rms_rel"] + 1e-4, (st32, so)
+    assert bool((agree | (margin <= 2 * err_row)).all()), "greedy token differs beyond the logit error"

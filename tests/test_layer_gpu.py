@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import glm4_moe_oracle as O
-from util import build_product_layer, layer_weights_from_golden, load_golden, router_margin
+from util import assert_close_bf16, build_product_layer, layer_weights_from_golden, load_golden, router_margin
 
 pytestmark = pytest.mark.gpu
 
@@ -95,8 +95,8 @@ def test_decoder_layer_decode(tag, split_o):
         hip_ops.add_rmsnorm_router_topk = orig
         assert seen, "the partial-sum path was not taken"
     s = t["slot_mapping"].long()
-    assert torch.equal(vc.cpu().view(-1, 256)[s], t["v_rows"]) or True  # V rows: GEMM rounding only
-    _mixed(vc.cpu().view(-1, 256)[s], t["v_rows"], f"{tag} v cache rows")
+    # V rows: qkv GEMM + bias only (one fp32 reduction) -> at most one bf16 ulp on a few elements
+    assert_close_bf16(vc.cpu().view(-1, 256)[s], t["v_rows"], 1, 0.05, atol=2 ** -9, what=f"{tag} v cache rows")
     _mixed(kc.cpu().view(-1, 256)[s], t["k_rows"], f"{tag} k cache rows")
     _mixed(res, t["res"], f"{tag} residual")
     meta = O.AttnMeta(False, slot_mapping=t["slot_mapping"], context_lens=t["context_lens"],
