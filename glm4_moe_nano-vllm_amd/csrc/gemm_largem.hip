@@ -27,6 +27,7 @@
 //     whose operand panels are shared through that XCD's L2.
 #include "gemm_internal.h"
 #include <stdlib.h>
+#include <type_traits>
 
 
 namespace {
@@ -37,6 +38,12 @@ constexpr int LM_BN = 256;    // weight rows per tile (MFMA row axis); 4 waves x
 #endif
 #ifndef GLM_LM_STAGE_POS
 #define GLM_LM_STAGE_POS 0  // 0: DMA issue before the fragment reads (measured best, +0.8 %), 1: between, 2: after
+#endif
+#ifndef GLM_LM_DEFAULT_VAR
+#define GLM_LM_DEFAULT_VAR 0
+#endif
+#ifndef GLM_LM_STUDY
+#define GLM_LM_STUDY 1  // also build the timing-study variants (no-store epilogue)
 #endif
 #ifndef GLM_LM_SCHED
 #define GLM_LM_SCHED 0  // 0: two barriers per K tile with waves 4-7 one barrier behind; 1: one barrier per K tile
@@ -88,12 +95,38 @@ __device__ unsigned long long g_lm_stamps[2][8];
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_void_t*)gsrc, (lds_void_t*)lds_wave_base, 16, 0, 0);
 }
+// buffer_load_dwordx4 ... offen lds: per-lane byte offset in a VGPR, K position in the scalar offset
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rsrc, void* lds_wave_base, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
 __device__ __forceinline__ void lds_read_b128(u32x4_t& dst, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(uintptr_t)(const lds_void_t*)p;
 }
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128_o(u32x4_t& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+// Kernel variants (template parameter VAR, bit set; glm_debug_largem_variant() selects one for A/B runs):
+//   LM_LEAN   the load phase carries no vector ALU work: operand tiles come in by buffer_load ... lds with a per-lane
+//             byte offset that is fixed for the whole tile and the K position in the SCALAR offset; fragment reads
+//             use one base register per k-step plus immediate offsets.  Needs K % BK == 0 and x/W spans < 2 GiB.
+//   LM_WIDEST 16-byte epilogue stores: the packed results of two neighbouring 16-column tiles are exchanged between
+//             the lane rows (v_permlane16_swap), so a lane stores 8 consecutive columns.
+//   LM_NOSTORE timing study only: the epilogue computes everything and stores nothing.
+constexpr int LM_LEAN = 1, LM_WIDEST = 2, LM_NOSTORE = 4;
 // wait for all LDS reads; every fragment register is named so that no consumer moves above it
 __device__ __forceinline__ void lds_wait(u32x4_t (&f)[12]) {
     asm volatile("s_waitcnt lgkmcnt(0)"
@@ -120,8 +153,9 @@ __device__ __forceinline__ void dma_wait_leave(int tiles) {
 // Persistent: one workgroup per CU walks its XCD's contiguous run of tiles with a stride of (workgroups per XCD).
 // Between two tiles the next tile's first ring stages are put in flight BEFORE the finished tile's epilogue, so the
 // ring-fill latency and the workgroup relaunch (~6 % of a 256x256x1408 tile) hide behind the epilogue's stores.
-template <int MODE, class C>
+template <int MODE, class C, int VAR>
 __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, int n_tiles, int total_tiles) {
+    constexpr bool LEAN = (VAR & LM_LEAN) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sh = reinterpret_cast<int*>(smem + C::NSTAGE * C::STAGE);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -172,7 +206,33 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
     const bf16_t* wsrc[C::W_DMA];
     const bf16_t* xsrc[C::X_DMA];
     int wch[C::W_DMA], xch[C::X_DMA];
+    unsigned wvo[C::W_DMA], xvo[C::X_DMA];  // LEAN: byte offsets of this lane's chunk at k = 0
+    __amdgpu_buffer_rsrc_t wrs, xrs;
+    if (LEAN) xrs = make_rsrc(p.x);
     auto setup_sources = [&]() {
+        if (LEAN) {
+            // descriptor of the group's weights (wave-uniform; grp came through LDS, so make that provable)
+            const int64_t goff = (int64_t)__builtin_amdgcn_readfirstlane(grp) * p.w_gstride;
+            wrs = make_rsrc(p.w + goff);
+#pragma unroll
+            for (int i = 0; i < C::W_DMA; ++i) {
+                const int row = (wid * C::W_DMA + i) * C::RPI + lane / C::CPR;
+                const int ch = (lane % C::CPR) ^ C::swz(row);
+                int wr;
+                if (MODE == GEMM_GATEUP) wr = (row >> 7) * p.N + min(ntile * 128 + (row & 127), p.N - 1);
+                else wr = min(ntile * LM_BN + row, p.N - 1);
+                wvo[i] = (unsigned)(wr * (int)p.ldw + ch * 8) * 2u;
+            }
+#pragma unroll
+            for (int i = 0; i < C::X_DMA; ++i) {
+                const int row = (wid * C::X_DMA + i) * C::RPI + lane / C::CPR;
+                const int ch = (lane % C::CPR) ^ C::swz(row);
+                const int mr = row < mcnt ? row : 0;
+                const int srow = p.src ? p.src[m0 + mr] : m0 + mr;
+                xvo[i] = (unsigned)(srow * (int)p.ldx + ch * 8) * 2u;
+            }
+            return;
+        }
         const bf16_t* wg = p.w + (int64_t)grp * p.w_gstride;
 #pragma unroll
         for (int i = 0; i < C::W_DMA; ++i) {
@@ -203,6 +263,15 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         char* wdst = smem + slot * C::STAGE + wid * C::W_DMA * 1024;
         char* xdst = smem + slot * C::STAGE + C::WT + wid * C::X_DMA * 1024;
         const int k0 = kt * C::BK;
+        if (LEAN) {
+#pragma unroll
+            for (int i = 0; i < C::W_DMA; ++i)
+                blds16(wrs, wdst + i * 1024, wvo[i], k0 * 2);
+#pragma unroll
+            for (int i = 0; i < C::X_DMA; ++i)
+                blds16(xrs, xdst + i * 1024, xvo[i], k0 * 2);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < C::W_DMA; ++i) glds16(k0 + wch[i] * 8 < K ? wsrc[i] + k0 : zero, wdst + i * 1024);
 #pragma unroll
@@ -232,6 +301,33 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         }
     }
     const unsigned base = lds_addr(smem);
+    // LEAN: one base per k-step and operand; the tile index inside the operand is an immediate offset
+    // (the swizzle depends on the low bits of the row only, i.e. on c)
+    unsigned fbw[C::KS], fbx[C::KS];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+        fbw[ks] = base + rel[ks * (4 + C::MT)];
+        fbx[ks] = base + rel[ks * (4 + C::MT) + 4];
+    }
+    // all fragment reads of a K tile (slot byte offset so, wave-uniform)
+    auto read_frags = [&](u32x4_t (&f)[C::NF], unsigned so, auto half_tag) {
+        constexpr int HALF = decltype(half_tag)::value;  // 0: all, 1: first half, 2: second half (index order as rel[])
+        static_for<C::KS>([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            const unsigned aw = fbw[ks] + so, ax = fbx[ks] + so;
+            static_for<4>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int idx = ks * (4 + C::MT) + t;
+                constexpr int off = MODE == GEMM_GATEUP ? (t < 2 ? 16 * t : 128 + 16 * (t - 2)) * C::RB : 16 * t * C::RB;
+                if (HALF == 0 || (HALF == 1) == (idx < C::NF / 2)) lds_read_b128_o<off>(f[idx], aw);
+            });
+            static_for<C::MT>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int idx = ks * (4 + C::MT) + 4 + t;
+                if (HALF == 0 || (HALF == 1) == (idx < C::NF / 2)) lds_read_b128_o<16 * t * C::RB>(f[idx], ax);
+            });
+        });
+    };
 
     if (!find_tile()) return;
     setup_sources();
@@ -275,11 +371,15 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             LM_T(0);
             if (GLM_LM_STAGE_POS == 0 && kt + C::DIST < nk) stage(nslot, kt + C::DIST);
             LM_T(1);  // 0: DMA issue
+            if (LEAN) {
+                read_frags(f, slot * C::STAGE, std::integral_constant<int, 0>{});
+            } else {
 #pragma unroll
-            for (int i = 0; i < C::NF / 2; ++i) lds_read_b128(f[i], sb + rel[i]);
-            if (GLM_LM_STAGE_POS == 1 && kt + C::DIST < nk) stage(nslot, kt + C::DIST);
+                for (int i = 0; i < C::NF / 2; ++i) lds_read_b128(f[i], sb + rel[i]);
+                if (GLM_LM_STAGE_POS == 1 && kt + C::DIST < nk) stage(nslot, kt + C::DIST);
 #pragma unroll
-            for (int i = C::NF / 2; i < C::NF; ++i) lds_read_b128(f[i], sb + rel[i]);
+                for (int i = C::NF / 2; i < C::NF; ++i) lds_read_b128(f[i], sb + rel[i]);
+            }
             if (GLM_LM_STAGE_POS == 2 && kt + C::DIST < nk) stage(nslot, kt + C::DIST);
             LM_T(2);  // 1: LDS read issue
             // this wave's share of tile kt+1: leave only the tiles newer than kt+1 in flight
@@ -333,8 +433,12 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             u32x4_t f[C::NF];
             const int nslot = slot == 0 ? C::NSTAGE - 1 : slot - 1;  // slot of tile kt-1
             if (kt + C::DIST < nk) stage(nslot, kt + C::DIST);
+            if (LEAN) {
+                read_frags(f, slot * C::STAGE, std::integral_constant<int, 0>{});
+            } else {
 #pragma unroll
-            for (int i = 0; i < C::NF; ++i) lds_read_b128(f[i], sb + rel[i]);
+                for (int i = 0; i < C::NF; ++i) lds_read_b128(f[i], sb + rel[i]);
+            }
             dma_wait_leave<C::DPW>(min(kt + C::DIST, nk - 1) - (kt + 1));
             lds_wait(f);
             __builtin_amdgcn_sched_barrier(0);
@@ -366,44 +470,53 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         }
 
         // ---- epilogue of the finished tile ----
+        constexpr bool WIDE = (VAR & LM_WIDEST) != 0, NOSTORE = (VAR & LM_NOSTORE) != 0;
+        constexpr int NOUT = MODE == GEMM_GATEUP ? 2 : 4;  // 16-column output tiles per wave
+        const int ncol_w = MODE == GEMM_GATEUP ? ntile_c * 128 + wn * 32 : ntile_c * LM_BN + wn * 64;
+        const bool scaled = MODE == GEMM_DOWN && grp_c < p.n_scaled;
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt) {
             const int row = wm * (C::BM / 2) + 16 * mt + c;
-            if (row >= mcnt_c) continue;
-            bf16_t* yrow = p.y + (int64_t)(m0_c + row) * p.ldy;
-            if (MODE == GEMM_GATEUP) {
+            const bool row_ok = row < mcnt_c;
+            bf16_t* yrow = p.y + (int64_t)(m0_c + (row_ok ? row : 0)) * p.ldy;
+            const float sc = (scaled && row_ok) ? bf2f(p.scale[m0_c + row]) : 1.0f;
+            u32x2_t v[NOUT];  // packed columns 4*g4 .. 4*g4+3 of output tile t
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int n = ntile_c * 128 + wn * 32 + 16 * t + 4 * g4;
-                    if (n >= p.N) continue;
-                    float o[4];
+            for (int t = 0; t < NOUT; ++t) {
+                float o[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r) {
+                    if (MODE == GEMM_GATEUP) {
                         o[r] = rbf(glm_silu(rbf(acc[t][mt][r]))) * rbf(acc[t + 2][mt][r]);
-                    u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-                    *reinterpret_cast<u32x2_t*>(yrow + n) = v;
-                }
-            } else {
-                float sc = 1.0f;
-                bool scaled = false;
-                if (MODE == GEMM_DOWN && grp_c < p.n_scaled) {
-                    sc = bf2f(p.scale[m0_c + row]);
-                    scaled = true;
-                }
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const int n = ntile_c * LM_BN + wn * 64 + 16 * nt + 4 * g4;
-                    if (n >= p.N) continue;
-                    float o[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float a = acc[nt][mt][r];
-                        if (MODE == GEMM_PLAIN && p.bias) a += bf2f(p.bias[n + r]);
+                    } else {
+                        float a = acc[t][mt][r];
+                        if (MODE == GEMM_PLAIN && p.bias) a += bf2f(p.bias[min(ncol_w + 16 * t + 4 * g4 + r, p.N - 1)]);
                         if (scaled) a = rbf(a) * sc;
                         o[r] = a;
                     }
-                    u32x2_t v = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-                    *reinterpret_cast<u32x2_t*>(yrow + n) = v;
+                }
+                v[t] = u32x2_t{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+            }
+            if (NOSTORE) {
+#pragma unroll
+                for (int t = 0; t < NOUT; ++t) asm volatile("" ::"v"(v[t][0]), "v"(v[t][1]));
+                continue;
+            }
+            if (WIDE) {
+                // tiles (t, t+1): after the swaps lane row g4 holds 8 consecutive columns of tile t + (g4 & 1),
+                // starting at column 8 * (g4 >> 1)
+#pragma unroll
+                for (int t = 0; t < NOUT; t += 2) {
+                    const u32x2_t a = __builtin_amdgcn_permlane16_swap(v[t][0], v[t + 1][0], false, false);
+                    const u32x2_t b = __builtin_amdgcn_permlane16_swap(v[t][1], v[t + 1][1], false, false);
+                    const int n = ncol_w + 16 * (t + (g4 & 1)) + 8 * (g4 >> 1);
+                    if (row_ok && n < p.N) *reinterpret_cast<u32x4_t*>(yrow + n) = u32x4_t{a[0], b[0], a[1], b[1]};
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NOUT; ++t) {
+                    const int n = ncol_w + 16 * t + 4 * g4;
+                    if (row_ok && n < p.N) *reinterpret_cast<u32x2_t*>(yrow + n) = v[t];
                 }
             }
         }
@@ -411,7 +524,9 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
     }
 }
 
-template <int MODE, class C>
+int g_largem_variant = -1;  // < 0: the default for the shape
+
+template <int MODE, class C, int VAR>
 int launch_largem_cfg(const GemmParams& p, hipStream_t st) {
     const int cols_per_wg = MODE == GEMM_GATEUP ? 128 : LM_BN;
     const int n_tiles = (p.N + cols_per_wg - 1) / cols_per_wg;
@@ -419,7 +534,7 @@ int launch_largem_cfg(const GemmParams& p, hipStream_t st) {
     const int64_t total = (combos + LM_BAND - 1) / LM_BAND * LM_BAND * n_tiles;
     if (total <= 0) return GLM_OK;
     GLM_CHECK_ARG(total < (1ll << 31), GLM_ERR_UNSUPPORTED, "gemm_largem: grid too large");
-    auto kern = gemm_largem_kernel<MODE, C>;
+    auto kern = gemm_largem_kernel<MODE, C, VAR>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
@@ -465,7 +580,28 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
     const int ch = cfg_choice();
     const int64_t avg_rows = p.R / (p.G > 0 ? p.G : 1);
     const bool use_b = ch == 2 || (ch == 0 && avg_rows >= 192);
-    return use_b ? launch_largem_cfg<MODE, LmCfgB>(p, st) : launch_largem_cfg<MODE, LmCfgA>(p, st);
+    // the lean load phase addresses x and the group's weights through 32-bit buffer offsets and has no K tail path
+    const int bk = use_b ? LmCfgB::BK : LmCfgA::BK;
+    const int64_t wrows = MODE == GEMM_GATEUP ? 2 * (int64_t)p.N : (int64_t)p.N;
+    const bool lean_ok = p.K % bk == 0 && p.R * p.ldx * 2 < (1ll << 31) && wrows * p.ldw * 2 < (1ll << 31) &&
+                         p.N % 8 == 0 && p.ldy % 8 == 0 && glm_aligned16(p.y);
+    int var = g_largem_variant >= 0 ? g_largem_variant : GLM_LM_DEFAULT_VAR;
+    if (!lean_ok) var = 0;
+#define GLM_LM_CASE(V)                                                                                         \
+    case V:                                                                                                    \
+        return use_b ? launch_largem_cfg<MODE, LmCfgB, V>(p, st) : launch_largem_cfg<MODE, LmCfgA, V>(p, st)
+    switch (var) {
+        GLM_LM_CASE(1);
+        GLM_LM_CASE(2);
+        GLM_LM_CASE(3);
+#if GLM_LM_STUDY
+        GLM_LM_CASE(4);
+        GLM_LM_CASE(7);
+#endif
+        default:
+            GLM_LM_CASE(0);
+    }
+#undef GLM_LM_CASE
 }
 
 }  // namespace
@@ -479,6 +615,13 @@ int glm_launch_gemm_largem(int mode, const GemmParams& p, hipStream_t st) {
     if (mode == GEMM_GATEUP) return launch_largem<GEMM_GATEUP>(p, st);
     if (mode == GEMM_DOWN) return launch_largem<GEMM_DOWN>(p, st);
     return launch_largem<GEMM_PLAIN>(p, st);
+}
+
+// A/B studies: kernel variant for the next launches (bit set of LM_LEAN | LM_WIDEST | LM_NOSTORE; < 0 = default)
+extern "C" int glm_debug_largem_variant(int v) {
+    const int old = g_largem_variant;
+    g_largem_variant = v;
+    return old;
 }
 
 #if GLM_LM_STAMP

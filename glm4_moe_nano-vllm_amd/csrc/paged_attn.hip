@@ -396,6 +396,19 @@ int choose_splits(int64_t B, int nkv, int max_ctx) {
 
 }  // namespace
 
+// the split count pa_launch uses for these arguments (kept in one place so that callers can size the workspace exactly)
+static int pa_effective_splits(int64_t B, int nkv, int block_size, int64_t bt_stride, int num_splits, int max_context_len) {
+    if (max_context_len <= 0) max_context_len = (int)(bt_stride * block_size);
+    int splits = num_splits > 0 ? num_splits : choose_splits(B, nkv, max_context_len);
+    return splits > 64 ? 64 : splits;
+}
+
+extern "C" int glm_paged_attn_decode_splits(int64_t B, int nkv, int block_size, int64_t bt_stride, int num_splits,
+                                            int max_context_len) {
+    if (B <= 0 || nkv <= 0) return 1;
+    return pa_effective_splits(B, nkv, block_size, bt_stride, num_splits, max_context_len);
+}
+
 extern "C" size_t glm_paged_attn_decode_workspace_bytes(int64_t B, int nh, int hd, int num_splits) {
     const int s = num_splits <= 0 ? 64 : num_splits;
     if (s == 1) return 0;
@@ -415,9 +428,7 @@ static int pa_launch(const void* q, const void* k_cache, const void* v_cache, co
                   "<=%d blocks per sequence (hd=%d group=%d block_size=%d bt_stride=%ld)",
                   name, PA_MAX_BT, hd, nh / nkv, block_size, (long)bt_stride);
     if (B == 0) return GLM_OK;
-    if (max_context_len <= 0) max_context_len = (int)(bt_stride * block_size);
-    int splits = num_splits > 0 ? num_splits : choose_splits(B, nkv, max_context_len);
-    if (splits > 64) splits = 64;
+    const int splits = pa_effective_splits(B, nkv, block_size, bt_stride, num_splits, max_context_len);
     float* part_o = nullptr;
     float* part_ml = nullptr;
     if (splits > 1) {

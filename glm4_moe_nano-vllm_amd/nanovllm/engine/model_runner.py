@@ -49,6 +49,7 @@ class ModelRunner:
                 self.model.load_weights(config.model)
                 self.sampler = Sampler()
                 self.warmup_model()
+                self.reserve_workspaces()
                 self.allocate_kv_cache()
                 if not self.enforce_eager:
                     self.capture_graphs()
@@ -87,6 +88,19 @@ class ModelRunner:
         n = max(1, min(cfg.max_num_batched_tokens // cfg.max_model_len, cfg.max_num_seqs))
         self.run([Sequence([0] * cfg.max_model_len) for _ in range(n)], True)
         torch.cuda.empty_cache()
+
+    def reserve_workspaces(self):
+        """Persistent scratch that must exist before the KV cache takes the rest of the memory: the split-KV partials
+        of the decode attention, sized for every batch size up to max_num_seqs (a few MB: no splits at all once
+        batch x kv-heads covers the chip)."""
+        from nanovllm import hip_ops
+        cfg, hf = self.config, self.config.hf_config
+        nh = hf.num_attention_heads // self.world_size
+        nkv = max(1, hf.num_key_value_heads // self.world_size)
+        max_blocks = (cfg.max_model_len + self.block_size - 1) // self.block_size
+        if hf.head_dim == 128:
+            hip_ops.reserve_attn_workspace(self.device, min(cfg.max_num_seqs, 512), nh, nkv, hf.head_dim,
+                                           self.block_size, max_blocks)
 
     def allocate_kv_cache(self):
         cfg, hf = self.config, self.config.hf_config

@@ -38,6 +38,7 @@ _SIGNATURES = {
                                               c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "glm_silu_and_mul": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "glm_paged_attn_decode_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "glm_paged_attn_decode_splits": (c_int, [c_int64, c_int, c_int, c_int64, c_int, c_int]),
     "glm_paged_attn_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64,
                                       c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
@@ -251,7 +252,39 @@ def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------------
 # attention
+# Split-KV scratch of the decode attention: ONE grow-only buffer per (device, stream), sized for the split count the
+# launch really uses (none at all once B * nkv >= 256).  A replaced buffer stays referenced: HIP graphs captured earlier
+# hold its address.  reserve_attn_workspace() lets the runner size it for max_num_seqs BEFORE the KV cache takes the
+# rest of the memory.
 _attn_ws: dict = {}
+_attn_ws_retired: list = []
+
+
+def _attn_workspace(device, need: int) -> torch.Tensor | None:
+    if need <= 0:
+        return None
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _attn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        if ws is not None:
+            _attn_ws_retired.append(ws)
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _attn_ws[key] = ws
+    return ws
+
+
+def attn_workspace_bytes(B: int, nh: int, nkv: int, hd: int, block_size: int, bt_stride: int, num_splits: int = 0,
+                         max_context_len: int = 0) -> int:
+    lib = load_library()
+    s = lib.glm_paged_attn_decode_splits(B, nkv, block_size, bt_stride, num_splits, max_context_len)
+    return lib.glm_paged_attn_decode_workspace_bytes(B, nh, hd, s) if s > 1 else 0
+
+
+def reserve_attn_workspace(device, max_batch: int, nh: int, nkv: int, hd: int, block_size: int, bt_stride: int) -> int:
+    """Size the split-KV scratch for every decode batch size up to max_batch (worst case over B); returns the bytes."""
+    need = max((attn_workspace_bytes(b, nh, nkv, hd, block_size, bt_stride) for b in range(1, max_batch + 1)), default=0)
+    _attn_workspace(device, need)
+    return need
 
 
 def paged_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
@@ -265,19 +298,13 @@ def paged_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
     assert context_lens.dtype == torch.int32 and block_tables.dtype == torch.int32
     assert block_tables.stride(1) == 1
     lib = load_library()
-    need = lib.glm_paged_attn_decode_workspace_bytes(B, nh, hd, num_splits)
-    ws = None
-    if need:
-        key = (q.device, need)
-        ws = _attn_ws.get(key)
-        if ws is None:
-            ws = torch.empty(need, dtype=torch.uint8, device=q.device)
-            _attn_ws[key] = ws
+    need = attn_workspace_bytes(B, nh, nkv, hd, block_size, block_tables.stride(0), num_splits, max_context_len)
+    ws = _attn_workspace(q.device, need)
     out = torch.empty_like(q)
     _check(lib.glm_paged_attn_decode(_p(q), _p(k_cache), _p(v_cache), _p(context_lens),
                                      _p(block_tables), block_tables.stride(0), _p(out), B, nh, nkv,
                                      hd, block_size, n_blocks, scale, num_splits, max_context_len,
-                                     _p(ws), need, _stream()), "glm_paged_attn_decode")
+                                     _p(ws), ws.numel() if ws is not None else 0, _stream()), "glm_paged_attn_decode")
     return out
 
 
@@ -297,20 +324,14 @@ def paged_attn_decode_qkv(qkv: torch.Tensor, nh: int, nkv: int, hd: int, positio
     assert positions.dtype == torch.int64 and slot_mapping.dtype == torch.int32
     assert context_lens.dtype == torch.int32 and block_tables.dtype == torch.int32 and block_tables.stride(1) == 1
     lib = load_library()
-    need = lib.glm_paged_attn_decode_workspace_bytes(B, nh, hd, num_splits)
-    ws = None
-    if need:
-        key = (qkv.device, need)
-        ws = _attn_ws.get(key)
-        if ws is None:
-            ws = torch.empty(need, dtype=torch.uint8, device=qkv.device)
-            _attn_ws[key] = ws
+    need = attn_workspace_bytes(B, nh, nkv, hd, block_size, block_tables.stride(0), num_splits, max_context_len)
+    ws = _attn_workspace(qkv.device, need)
     out = torch.empty((B, nh, hd), dtype=qkv.dtype, device=qkv.device)
     _check(lib.glm_paged_attn_decode_qkv(_p(qkv), qkv.stride(0), _p(positions), _p(cos_sin_cache), rotary_dim,
                                          _p(slot_mapping), _p(k_cache), _p(v_cache), _p(context_lens),
                                          _p(block_tables), block_tables.stride(0), _p(out), B, nh, nkv, hd,
-                                         block_size, n_blocks, scale, num_splits, max_context_len, _p(ws), need,
-                                         _stream()), "glm_paged_attn_decode_qkv")
+                                         block_size, n_blocks, scale, num_splits, max_context_len, _p(ws),
+                                         ws.numel() if ws is not None else 0, _stream()), "glm_paged_attn_decode_qkv")
     return out
 
 

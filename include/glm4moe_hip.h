@@ -99,8 +99,12 @@ int glm_silu_and_mul(const void* x, void* y, int64_t T, int I, glm_stream_t stre
  *     q: [B,nh,hd] contiguous; caches: [n_blocks, block_size, nkv, hd]; context_lens int32[B]
  *     (0 ⇒ zero output row); block_tables int32 [B, bt_stride] (-1 padded); out [B,nh,hd].
  *     workspace: glm_paged_attn_decode_workspace_bytes() bytes (may be NULL when that is 0).
- *     num_splits: 0 = choose; ≥1 = forced number of KV splits per (sequence, kv-head).       */
+ *     num_splits: 0 = choose; ≥1 = forced number of KV splits per (sequence, kv-head).
+ *     glm_paged_attn_decode_splits() = the split count a launch with these arguments uses (1 ⇒ no workspace is
+ *     read); size the workspace with THAT count — workspace_bytes(…, 0) is the worst case (64 splits).        */
 size_t glm_paged_attn_decode_workspace_bytes(int64_t B, int nh, int hd, int num_splits);
+int glm_paged_attn_decode_splits(int64_t B, int nkv, int block_size, int64_t bt_stride, int num_splits,
+                                 int max_context_len);
 int glm_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache,
                           const int32_t* context_lens, const int32_t* block_tables,
                           int64_t bt_stride, void* out,

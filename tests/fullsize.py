@@ -133,15 +133,52 @@ def report(case: str, **fields) -> None:
     print("PARITY", json.dumps(rec))
 
 
-def assert_allclose_ref_tol(actual, expected, what: str, rows=None, rtol: float = 1e-2, atol: float = 1e-2):
-    """The reference scripts' own acceptance test (torch.allclose(rtol=atol=1e-2), tests/moe.py:40, tests/mlp.py:65)."""
+def assert_allclose_ref_tol(actual, expected, what: str, rows=None, rtol: float = 1e-2, atol: float = 1e-2,
+                            outlier_frac: float = 0.0, outlier_factor: float = 2.0):
+    """The reference scripts' own acceptance test, torch.allclose(rtol=atol=1e-2) (tests/moe.py:40, tests/mlp.py:65 —
+    written for fp16, whose ulp is 8x finer than bf16's).  `outlier_frac` of the elements may exceed it by at most
+    `outlier_factor`: a bf16 result of magnitude 2..4 that lands two ulp (0.031) from the reference's is already
+    outside 1e-2, and the reference's OWN bf16 evaluation is outside 1e-2 of exact arithmetic for ~0.5 % of a
+    layer's outputs (measured, profiles/r02/parity_fullsize.jsonl: oracle_bf16_vs_fp32)."""
     a, e = actual.detach().cpu().float(), expected.detach().cpu().float()
     if rows is not None:
         a, e = a[rows], e[rows]
     err = (a - e).abs()
     bad = err > atol + rtol * e.abs()
-    assert not bool(bad.any()), (f"{what}: {int(bad.sum())}/{a.numel()} elements outside rtol={rtol} atol={atol}; "
-                                 f"max err {float(err.max()):.4g} at ref magnitude {float(e.abs().max()):.4g}")
+    worse = err > outlier_factor * (atol + rtol * e.abs())
+    frac = float(bad.float().mean())
+    assert frac <= outlier_frac and not bool(worse.any()), (
+        f"{what}: {int(bad.sum())}/{a.numel()} elements ({frac:.3%}) outside rtol={rtol} atol={atol} "
+        f"(allowed {outlier_frac:.3%}), {int(worse.sum())} beyond {outlier_factor}x; "
+        f"max err {float(err.max()):.4g} at ref magnitude {float(e.abs().max()):.4g}")
+
+
+def assert_close_like_reference(actual, ref_bf16, ref_fp32, what: str, rows=None, cap_factor: float = 4.0) -> dict:
+    """Acceptance of a bf16 result that sits behind long chains of bf16 rounding points (a whole decoder layer, the
+    logits).  The reference scripts accept rtol = atol = 1e-2 (tests/moe.py:40, tests/mlp.py:65; written for fp16,
+    whose ulp is 8x finer).  In bf16 the reference's OWN evaluation misses that bound against exact arithmetic on
+    0.5 % (MoE layer) to 15 % (logits) of the elements (measured: oracle_bf16_vs_fp32 in the parity report), so the
+    bound cannot be demanded elementwise of a second bf16 evaluation with another fp32 summation order.  Demanded:
+      (1) the HIP result is outside 1e-2 of the reference's bf16 result on NO MORE elements than the reference's bf16
+          result is outside 1e-2 of the exact (fp32) evaluation of the same algorithm (floor 0.1 %);
+      (2) its rms distance from the reference's bf16 result is at most 1.5x the reference's own rms distance from exact
+          (two evaluations, each eps from exact, are at most ~sqrt(2) eps apart);
+      (3) it is as close to exact arithmetic as the reference's bf16 evaluation is (rms, within 25 %);
+      (4) no element is beyond cap_factor x (1e-2 + 1e-2 |ref|)."""
+    st = err_stats(actual, ref_bf16, rows)
+    st32 = err_stats(actual, ref_fp32, rows)
+    so = err_stats(ref_bf16, ref_fp32, rows)
+    a, e = actual.detach().cpu().float(), ref_bf16.detach().cpu().float()
+    if rows is not None:
+        a, e = a[rows], e[rows]
+    err = (a - e).abs()
+    beyond = int((err > cap_factor * (1e-2 + 1e-2 * e.abs())).sum())
+    msg = f"{what}: vs oracle {st}, vs fp32 {st32}, oracle vs fp32 {so}"
+    assert st["frac_outside_1e-2"] <= max(1e-3, so["frac_outside_1e-2"]), "(1) " + msg
+    assert st["rms_rel"] <= 1.5 * so["rms_rel"] + 1e-4, "(2) " + msg
+    assert st32["rms_rel"] <= 1.25 * so["rms_rel"] + 1e-4, "(3) " + msg
+    assert beyond == 0, f"(4) {beyond} elements beyond {cap_factor}x the reference tolerance; " + msg
+    return {"vs_oracle_bf16": st, "vs_fp32": st32, "oracle_bf16_vs_fp32": so}
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -84,7 +84,7 @@ def _layer_decode_case(ops, tag: str, B: int, ctx: int, layer_idx: int, pad_rows
         _, _, choice = O.router_scores(tr["h_router"], lw.gate_w, lw.gate_bias)
         rows, moved = F.same_set_rows(idx_f[:B].cpu(), tr["idx"], router_margin(choice, gate.top_k), 0.016)
         routing["rows_moved_by_upstream_rounding"] = len(moved)
-        assert len(rows) >= (3 * B + 3) // 4, f"{tag}: {len(moved)}/{B} rows routed differently"
+        assert len(moved) <= max(1, B // 4), f"{tag}: {len(moved)}/{B} rows routed differently"
 
     st_out = F.err_stats(out[:B], ref_out, rows)
     st_out32 = F.err_stats(out[:B], out32, rows)
@@ -97,10 +97,10 @@ def _layer_decode_case(ops, tag: str, B: int, ctx: int, layer_idx: int, pad_rows
     # V rows: qkv GEMM + bias only (one fp32 reduction); K rows: the same through the rotary
     assert_close_bf16(vg[s], vc_ref.view(-1, D)[s], 1, 0.05, atol=2 ** -9, what=f"{tag} v rows")
     assert_close_bf16(kg[s], kc_ref.view(-1, D)[s], 2, 0.05, atol=2 ** -5, what=f"{tag} k rows")
-    assert_close_bf16(res_out[:B], ref_res, 2, 0.05, atol=2 ** -7, what=f"{tag} residual")
-    F.assert_allclose_ref_tol(out[:B], ref_out, f"{tag} out", rows)
-    # the HIP path must be as close to exact arithmetic as the reference's own bf16 evaluation is
-    assert st_out32["rms_rel"] <= 1.25 * st_ref32["rms_rel"] + 1e-4, (st_out32, st_ref32)
+    # residual = bf16(o_proj + residual_in): the small o_proj term (attention P rounded to bf16 in the kernel, fp32 in the
+    # stand-in oracle) flips the rounding of the sum by one ulp on a few per cent of the elements
+    assert_close_bf16(res_out[:B], ref_res, 1, 0.10, atol=2 ** -7, what=f"{tag} residual")
+    F.assert_close_like_reference(out[:B], ref_out, out32, f"{tag} out", rows)
 
 
 def test_c3_moe_layer_decode(ops):
@@ -149,8 +149,10 @@ def _check_groups(tag, x, w13, w2, offs, tok, scale, act, y, E, groups, row_sel)
         xe = x[tok[rg].long()].cpu()
         a_ref = O.silu_and_mul(O.linear(xe, w13[e].cpu()))
         a_got = act[rg].cpu()
-        # gate, up and bf16(silu) can each flip one ulp through the fp32 summation order: <= 3 ulp stacked
-        assert_close_bf16(a_got, a_ref, 3, 0.06, atol=1e-3, what=f"{tag} act group {e}")
+        # gate, up and bf16(silu) can each flip one ulp through the fp32 summation order: <= 3 ulp stacked.  Where the
+        # gate is well below zero silu is ill-conditioned in ulp terms (one ulp of g = -4 moves silu(g) by 3.4 of ITS
+        # ulps, g = -6 by 6): such elements are tiny in absolute terms, |d act| <= ulp(g) |silu'(g)| |u| < 2^-7
+        assert_close_bf16(a_got, a_ref, 3, 0.06, atol=2 ** -7, what=f"{tag} act group {e}")
         y_ref = O.linear(a_got, w2[e].cpu())          # the product's own act rows: isolates the down GEMM
         if e < E:
             y_ref = y_ref * scale_c[rr].unsqueeze(-1)  # bf16 multiply by the routing weight (moe.py:149)
@@ -324,6 +326,5 @@ def test_c3_model_logits(ops):
              north_star_rtol=1e-3, greedy_agree=int(agree.sum()), greedy_rows=len(keep),
              min_margin_where_disagree=float(margin[~agree].min()) if bool((~agree).any()) else None)
     assert len(keep) >= 24
-    F.assert_allclose_ref_tol(logits, lref, "logits", rows)
-    assert st32["rms_rel"] <= 1.25 * so["rms_rel"] + 1e-4, (st32, so)
+    F.assert_close_like_reference(logits, lref, l32, "logits", rows)
     assert bool((agree | (margin <= 2 * err_row)).all()), "greedy token differs beyond the logit error"
