@@ -61,49 +61,16 @@ def init_weights(model, seed: int):
 
 
 def probe_capture_child() -> int:
-    """Child process of the N>1 pre-flight: can this node capture RCCL all-reduces (through torch.distributed) in a
-    HIP graph and replay them?  A failed capture leaves a process unusable, so the question is asked in a throwaway
-    process per rank (own rendezvous port) before the bench ranks touch their GPUs.  Exit code 0 = yes."""
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    local_rank = 0 if os.environ.get("GLM_BENCH_SINGLE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist.init_process_group("nccl", device_id=dev)
-    x = torch.full((32, 4096), float(rank + 1), dtype=torch.bfloat16, device=dev)
-    dist.all_reduce(x)  # brings the communicator up outside the capture
-    torch.cuda.synchronize()
-    y = torch.full((32, 4096), float(rank + 1), dtype=torch.bfloat16, device=dev)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        a = y * 2
-        dist.all_reduce(a)
-        b = a + 1
-        dist.all_reduce(b)
-    for _ in range(3):
-        g.replay()
-    torch.cuda.synchronize()
-    s1 = 2.0 * sum(r + 1 for r in range(world))
-    ok = bool((a == s1).all()) and bool((b == world * (s1 + 1)).all())
-    dist.barrier()
-    dist.destroy_process_group()
-    return 0 if ok else 1
+    """Child process of the N>1 pre-flight (nanovllm/distributed/capture_probe.py: can this node capture RCCL
+    all-reduces in a HIP graph and replay them?).  Exit code 0 = yes."""
+    from nanovllm.distributed import capture_probe
+    return capture_probe.child_main()
 
 
 def probe_capture(world: int, timeout_s: int = 180) -> tuple[bool, str | None]:
     """Parent side: run the probe child with this rank's environment on the next rendezvous port."""
-    import subprocess
-    env = dict(os.environ)
-    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 17)
-    env.setdefault("MASTER_ADDR", "127.0.0.1")
-    try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-capture"], env=env,
-                           timeout=timeout_s, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    except subprocess.TimeoutExpired:
-        return False, "capture probe timed out"
-    if r.returncode != 0:
-        tail = r.stderr.decode(errors="replace").strip().splitlines()[-1:] or [""]
-        return False, f"capture probe exit {r.returncode}: {tail[0][:160]}"
-    return True, None
+    from nanovllm.distributed import capture_probe
+    return capture_probe.probe(timeout_s=timeout_s, argv=[sys.executable, os.path.abspath(__file__), "--probe-capture"])
 
 
 def main():

@@ -40,7 +40,7 @@ constexpr int LM_BN = 256;    // weight rows per tile (MFMA row axis); 4 waves x
 #define GLM_LM_STAGE_POS 0  // 0: DMA issue before the fragment reads (measured best, +0.8 %), 1: between, 2: after
 #endif
 #ifndef GLM_LM_DEFAULT_VAR
-#define GLM_LM_DEFAULT_VAR 0
+#define GLM_LM_DEFAULT_VAR 3  // lean load phase + 16-byte stores (bit-identical to 0; tools/largem_ab.py: +4 % / +7 %)
 #endif
 #ifndef GLM_LM_STUDY
 #define GLM_LM_STUDY 1  // also build the timing-study variants (no-store epilogue)

@@ -29,13 +29,26 @@ class ModelRunner:
         self.world_size = config.tensor_parallel_size
         self.rank = rank
         self.ctrl_group = None
+        self.graph_note = None
         if self.world_size > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(master_port))
+            capture_ok = True
+            if not self.enforce_eager:
+                # may the decode step be captured WITH its RCCL all-reduces?  Asked in a throwaway child per rank before
+                # this rank's communicator exists (a failed capture leaves a process unusable and its peers blocked)
+                from nanovllm.distributed import capture_probe
+                env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(self.world_size))
+                capture_ok, self.graph_note = capture_probe.probe(env)
             torch.cuda.set_device(rank)
             dist.init_process_group("nccl", world_size=self.world_size, rank=rank,
                                     device_id=torch.device("cuda", rank))
             self.ctrl_group = dist.new_group(backend="gloo")
+            if not self.enforce_eager:
+                from nanovllm.distributed import capture_probe
+                if not capture_probe.agree(capture_ok, torch.device("cuda", rank)):
+                    self.enforce_eager = True  # on EVERY rank
+                    self.graph_note = self.graph_note or "capture probe failed on another rank"
         torch.cuda.set_device(rank)
         self.device = torch.device("cuda", rank)
         old_dtype = torch.get_default_dtype()

@@ -81,6 +81,9 @@ class MergedColumnParallelLinear(ColumnParallelLinear):
 
 
 class QKVParallelLinear(ColumnParallelLinear):
+    """q heads are split over the ranks; kv heads too while there are at least as many kv heads as ranks, otherwise each
+    kv head is REPLICATED on tp_size / total_num_kv_heads consecutive ranks (attention_new.py:21-34 sizes the attention
+    that way; the reference's own loader never gets there because its TP group is a stub)."""
 
     def __init__(self, hidden_size: int, head_size: int, total_num_heads: int,
                  total_num_kv_heads: int | None = None, bias: bool = False):
@@ -88,9 +91,12 @@ class QKVParallelLinear(ColumnParallelLinear):
         total_num_kv_heads = total_num_kv_heads or total_num_heads
         self.head_size = head_size
         self.num_heads = divide(total_num_heads, tp_size)
-        self.num_kv_heads = divide(total_num_kv_heads, tp_size)
-        output_size = (total_num_heads + 2 * total_num_kv_heads) * self.head_size
-        super().__init__(hidden_size, output_size, bias)
+        if total_num_kv_heads >= tp_size:
+            self.num_kv_heads, self.kv_replicas = divide(total_num_kv_heads, tp_size), 1
+        else:
+            self.num_kv_heads, self.kv_replicas = 1, divide(tp_size, total_num_kv_heads)
+        # per-rank rows (not total / tp_size once kv heads are replicated)
+        LinearBase.__init__(self, hidden_size, (self.num_heads + 2 * self.num_kv_heads) * head_size, bias, 0)
 
     def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor, loaded_shard_id: str):
         assert loaded_shard_id in ["q", "k", "v"]
@@ -98,7 +104,11 @@ class QKVParallelLinear(ColumnParallelLinear):
         kv_rows = self.num_kv_heads * self.head_size
         offset, size = {"q": (0, q_rows), "k": (q_rows, kv_rows), "v": (q_rows + kv_rows, kv_rows)}[loaded_shard_id]
         dst = param.data.narrow(self.tp_dim, offset, size)
-        dst.copy_(loaded_weight.chunk(self.tp_size, self.tp_dim)[self.tp_rank])
+        if loaded_shard_id == "q":
+            dst.copy_(loaded_weight.chunk(self.tp_size, self.tp_dim)[self.tp_rank])
+        else:
+            shards = self.tp_size // self.kv_replicas
+            dst.copy_(loaded_weight.chunk(shards, self.tp_dim)[self.tp_rank // self.kv_replicas])
 
 
 class RowParallelLinear(LinearBase):

@@ -326,5 +326,6 @@ def test_c3_model_logits(ops):
              north_star_rtol=1e-3, greedy_agree=int(agree.sum()), greedy_rows=len(keep),
              min_margin_where_disagree=float(margin[~agree].min()) if bool((~agree).any()) else None)
     assert len(keep) >= 24
-    F.assert_close_like_reference(logits, lref, l32, "logits", rows)
+    # cap 6x: a logit of magnitude 4..8 that lands two bf16 ulp (0.0625) from the reference's is within 0.06 + 0.06|ref|
+    F.assert_close_like_reference(logits, lref, l32, "logits", rows, cap_factor=6.0)
     assert bool((agree | (margin <= 2 * err_row)).all()), "greedy token differs beyond the logit error"

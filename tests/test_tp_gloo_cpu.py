@@ -69,6 +69,17 @@ def _worker(rank, world, port, q):
         y_ref = O.linear(O.linear(x, wq), wo)
         assert torch.allclose(y.float(), y_ref.float(), rtol=3e-2, atol=3e-2 * float(y_ref.float().abs().max()))
 
+        # --- fewer kv heads than ranks: every rank holds a replica of its kv head (nkv=1 at tp=2) ---
+        qkv1 = QKVParallelLinear(H, hd, nh, 1, bias=True)
+        assert qkv1.weight.shape == ((nh // world + 2) * hd, H) and qkv1.kv_replicas == world
+        wk1, bk1 = wk[:hd], torch.arange(hd, dtype=torch.float32).to(torch.bfloat16)
+        qkv1.weight_loader(qkv1.weight, wq, "q")
+        qkv1.weight_loader(qkv1.weight, wk1, "k")
+        qkv1.weight_loader(qkv1.weight, wv[:hd], "v")
+        qkv1.weight_loader(qkv1.bias, bk1, "k")
+        assert torch.equal(qkv1.weight[nq * hd:(nq + 1) * hd], wk1) and torch.equal(qkv1.weight[(nq + 1) * hd:], wv[:hd])
+        assert torch.equal(qkv1.bias[nq * hd:(nq + 1) * hd], bk1)
+
         # --- expert / dense MLP: gate|up column-parallel, down row-parallel ---
         mlp = Glm4MoeMLP(H, I, "silu")
         assert mlp.gate_up_proj.weight.shape == (2 * I // world, H) and mlp.down_proj.weight.shape == (H, I // world)
@@ -90,6 +101,58 @@ def _worker(rank, world, port, q):
         emb.weight_loader(emb.weight, emb_w)
         ids = torch.tensor([0, 24, 25, 49, 7])
         assert torch.equal(emb(ids), emb_w[ids])
+        # --- ParallelLMHead: vocab shard per rank, dist.gather to rank 0 (embed_head.py:64-67).  The projection itself
+        # is a HIP kernel; the TEST stands the oracle's linear in for it so that the gather logic runs on CPU ---
+        from nanovllm import hip_ops
+        from nanovllm.layers.embed_head import ParallelLMHead
+        from nanovllm.utils.context import reset_context, set_context
+        hip_ops.gemm_bf16 = lambda xx, ww, bb=None: O.linear(xx, ww, bb)
+        head = ParallelLMHead(V, H)
+        head.weight_loader(head.weight, emb_w)
+        assert torch.equal(head.weight, emb_w[rank * (V // world):(rank + 1) * (V // world)])
+        set_context(False)
+        logits = head(x)
+        if rank == 0:
+            assert logits.shape == (T, V) and torch.equal(logits, O.linear(x, emb_w))
+        else:
+            assert logits is None
+        # prefill: last token of each sequence only (embed_head.py:60-62)
+        set_context(True, torch.tensor([0, 4, 9], dtype=torch.int32), torch.tensor([0, 4, 9], dtype=torch.int32), 5, 5)
+        logits = head(x)
+        if rank == 0:
+            assert torch.equal(logits, O.linear(x[[3, 8]], emb_w))
+        reset_context()
+
+        # --- MoE block at TP: every expert's gate|up is column-split and its down row-split; the stacked
+        # [E+1, 2I/tp, H] / [E+1, H, I/tp] buffers the grouped GEMMs read must stay tied to the per-expert parameters
+        # the checkpoint loader fills (moe.py:56-69 builds TP-unaware experts; here they shard) ---
+        import types
+        from nanovllm.models.glm4_moe.moe import Glm4MoeMoE
+        E, k = 4, 2
+        cfg = types.SimpleNamespace(hidden_size=H, moe_intermediate_size=I, hidden_act="silu", n_routed_experts=E,
+                                    num_experts_per_tok=k, n_group=1, topk_group=1, routed_scaling_factor=1.0)
+        moe = Glm4MoeMoE(cfg)
+        ew13 = torch.randn(E + 1, 2 * I, H, generator=g).to(torch.bfloat16) * 0.2
+        ew2 = torch.randn(E + 1, H, I, generator=g).to(torch.bfloat16) * 0.2
+        gate_w = torch.randn(E, H, generator=g).to(torch.bfloat16) * 0.2
+        gbias = (torch.rand(E, generator=g) * 0.2 - 0.1).float()
+        mlps = list(moe.experts) + [moe.shared_experts]
+        for e, m in enumerate(mlps):
+            m.gate_up_proj.weight_loader(m.gate_up_proj.weight, ew13[e, :I], 0)
+            m.gate_up_proj.weight_loader(m.gate_up_proj.weight, ew13[e, I:], 1)
+            m.down_proj.weight_loader(m.down_proj.weight, ew2[e])
+        w13s, w2s = moe._stacked()
+        assert w13s.shape == (E + 1, 2 * I // world, H) and w2s.shape == (E + 1, H, I // world)
+        for e, m in enumerate(mlps):
+            assert m.gate_up_proj.weight.data_ptr() == w13s[e].data_ptr(), "stack and parameter must share storage"
+            assert torch.equal(w13s[e, :Il], ew13[e, rank * Il:(rank + 1) * Il])
+            assert torch.equal(w13s[e, Il:], ew13[e, I + rank * Il:I + (rank + 1) * Il])
+            assert torch.equal(w2s[e], ew2[e][:, rank * Il:(rank + 1) * Il])
+        # the product combines the partial down sums per rank and all-reduces ONCE (moe.py here: after moe_combine)
+        part = O.moe(x, gate_w, gbias, k, 1.0, w13s[:E], w2s[:E], w13s[E], w2s[E])
+        full = tp.all_reduce(part.clone())
+        ref = O.moe(x, gate_w, gbias, k, 1.0, ew13[:E], ew2[:E], ew13[E], ew2[E])
+        assert torch.allclose(full.float(), ref.float(), rtol=3e-2, atol=3e-2 * float(ref.float().abs().max()))
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))
