@@ -126,7 +126,24 @@ __device__ __forceinline__ void static_for(F&& f) {
 //   LM_WIDEST 16-byte epilogue stores: the packed results of two neighbouring 16-column tiles are exchanged between
 //             the lane rows (v_permlane16_swap), so a lane stores 8 consecutive columns.
 //   LM_NOSTORE timing study only: the epilogue computes everything and stores nothing.
-constexpr int LM_LEAN = 1, LM_WIDEST = 2, LM_NOSTORE = 4;
+//   LM_DMA2 / LM_DMA4 (with LM_LEAN) 2 / all 4 of a K tile's DMA instructions are issued from the MFMA phase, spread
+//             between the MFMAs, instead of from the (longer) load phase.
+//   LM_LDSEPI (down / plain) the epilogue transposes each 16-row x 64-column block of a wave through a private LDS
+//             patch in the free ring slot, so that a store instruction writes 8 whole 128-byte lines.
+//   LM_DESYNC the workgroups of XCD x start x * GLM_LM_DESYNC_US later: every workgroup runs tiles of the same length, so
+//             without it all 256 CUs reach their epilogues together and the output (1.2 GB for the down projection at
+//             T=16384) leaves in chip-wide bursts that the HBM absorbs at its write rate while every matrix pipe waits.
+//             An XCD stays in step with itself (its co-resident tiles share operand panels through its L2).
+//   LM_NT     non-temporal epilogue stores (the output is not read again by this kernel).
+constexpr int LM_LEAN = 1, LM_WIDEST = 2, LM_NOSTORE = 4, LM_DMA2 = 8, LM_DMA4 = 16, LM_LDSEPI = 32, LM_DESYNC = 64,
+              LM_NT = 128, LM_EPIORD = 256;
+//   LM_EPIORD the epilogue's global LOADS (per-row scales) are issued before the next tile's ring fill, so that waiting
+//             for them does not drain the fill; and the wait that opens a tile leaves the previous tile's stores in
+//             flight (vmcnt counts in issue order and the fill was issued before them) whenever their number is
+//             known exactly — full tiles.
+#ifndef GLM_LM_DESYNC_CYCLES
+#define GLM_LM_DESYNC_CYCLES 5120  // per XCD step, shader clocks (~2.5 us)
+#endif
 // wait for all LDS reads; every fragment register is named so that no consumer moves above it
 __device__ __forceinline__ void lds_wait(u32x4_t (&f)[12]) {
     asm volatile("s_waitcnt lgkmcnt(0)"
@@ -156,6 +173,8 @@ __device__ __forceinline__ void dma_wait_leave(int tiles) {
 template <int MODE, class C, int VAR>
 __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, int n_tiles, int total_tiles) {
     constexpr bool LEAN = (VAR & LM_LEAN) != 0;
+    // DMA instructions of a K tile issued from the MFMA phase (the rest from the load phase)
+    constexpr int S2 = !LEAN ? 0 : (VAR & LM_DMA4) ? C::DPW : (VAR & LM_DMA2) ? C::DPW / 2 : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sh = reinterpret_cast<int*>(smem + C::NSTAGE * C::STAGE);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -259,6 +278,16 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         }
     };
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_lm);
+    // LEAN only: DMA instruction j (0 .. DPW-1; weights first) of K tile kt into ring slot `slot`
+    auto stage_one = [&](int slot, int kt, auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int k0 = kt * C::BK;
+        if constexpr (j < C::W_DMA)
+            blds16(wrs, smem + slot * C::STAGE + wid * C::W_DMA * 1024 + j * 1024, wvo[j], k0 * 2);
+        else
+            blds16(xrs, smem + slot * C::STAGE + C::WT + wid * C::X_DMA * 1024 + (j - C::W_DMA) * 1024,
+                   xvo[j - C::W_DMA], k0 * 2);
+    };
     auto stage = [&](int slot, int kt) {
         char* wdst = smem + slot * C::STAGE + wid * C::W_DMA * 1024;
         char* xdst = smem + slot * C::STAGE + C::WT + wid * C::X_DMA * 1024;
@@ -329,7 +358,14 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         });
     };
 
+    // store instructions per wave of a full tile (16-byte stores: one per pair of output tiles)
+    constexpr int LM_NOUT = MODE == GEMM_GATEUP ? 2 : 4;
+    constexpr int LM_STORES_FULL = C::MT * ((VAR & LM_WIDEST) ? LM_NOUT / 2 : LM_NOUT);
+    int pending_stores = 0;
     if (!find_tile()) return;
+    if constexpr ((VAR & LM_DESYNC) != 0) {
+        for (int i = 0; i < (int)(blockIdx.x & 7) * (GLM_LM_DESYNC_CYCLES / 1024); ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 clocks
+    }
     setup_sources();
     fill_ring();
     for (;;) {
@@ -355,7 +391,13 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         //        B1(kt-1).
         // The ring fill was issued before the previous tile's epilogue stores, and stores retire out of order with
         // loads, so the first wait of a tile is a full drain (the stores are long acknowledged by then).
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr ((VAR & LM_EPIORD) != 0) {
+            // pending_stores = store instructions this wave issued after the ring fill (0 when not known exactly)
+            if (pending_stores == LM_STORES_FULL) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LM_STORES_FULL) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();                 // every share of the first DIST tiles landed
 #if GLM_LM_SCHED == 0
         if (wid >= 4) __builtin_amdgcn_s_barrier();   // the stagger
@@ -369,7 +411,12 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             u32x4_t f[C::NF];
             const int nslot = slot == 0 ? C::NSTAGE - 1 : slot - 1;  // slot of tile kt-1
             LM_T(0);
-            if (GLM_LM_STAGE_POS == 0 && kt + C::DIST < nk) stage(nslot, kt + C::DIST);
+            if (S2 > 0) {
+                if (kt + C::DIST < nk)
+                    static_for<C::DPW - S2>([&](auto jc) { stage_one(nslot, kt + C::DIST, jc); });
+            } else if (GLM_LM_STAGE_POS == 0 && kt + C::DIST < nk) {
+                stage(nslot, kt + C::DIST);
+            }
             LM_T(1);  // 0: DMA issue
             if (LEAN) {
                 read_frags(f, slot * C::STAGE, std::integral_constant<int, 0>{});
@@ -383,7 +430,17 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             if (GLM_LM_STAGE_POS == 2 && kt + C::DIST < nk) stage(nslot, kt + C::DIST);
             LM_T(2);  // 1: LDS read issue
             // this wave's share of tile kt+1: leave only the tiles newer than kt+1 in flight
-            dma_wait_leave<C::DPW>(min(kt + C::DIST, nk - 1) - (kt + 1));
+            if (S2 > 0) {
+                // issued so far beyond tile kt+1: whole tiles up to kt+DIST-1, and the load-phase part of tile kt+DIST
+                const int full = max(0, min(kt + C::DIST - 1, nk - 1) - (kt + 1));
+                const int leave = full * C::DPW + (kt + C::DIST < nk ? C::DPW - S2 : 0);
+                if (leave == 2 * C::DPW - S2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * C::DPW - S2) : "memory");
+                else if (leave == C::DPW) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C::DPW) : "memory");
+                else if (leave == C::DPW - S2 && S2 < C::DPW) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C::DPW - S2) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                dma_wait_leave<C::DPW>(min(kt + C::DIST, nk - 1) - (kt + 1));
+            }
             LM_T(3);  // 2: counted DMA wait
             lds_wait(f);
             LM_T(4);  // 3: LDS wait
@@ -392,15 +449,38 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             LM_T(5);  // 4: barrier 1
             // ---------------- phase 2 ----------------
             __builtin_amdgcn_s_setprio(1);
+            if constexpr (S2 > 0) {
+                // the same MFMAs in the same order, with the remaining S2 DMA instructions of tile kt+DIST spread
+                // between them (pinned: nothing moves across a sched_barrier)
+                constexpr int NM = C::KS * 4 * C::MT;
+                const bool more_dma = kt + C::DIST < nk;
+                static_for<NM>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int ks = i / (4 * C::MT), nt = (i / C::MT) % 4, mt = i % C::MT;
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8_t, f[ks * (4 + C::MT) + nt]),
+                        __builtin_bit_cast(bf16x8_t, f[ks * (4 + C::MT) + 4 + mt]), acc[nt][mt], 0, 0, 0);
+                    // after MFMA number (j+1) * NM / (S2+1), j = 0 .. S2-1
+                    static_for<S2>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        if constexpr (i + 1 == (j + 1) * NM / (S2 + 1)) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (more_dma) stage_one(nslot, kt + C::DIST, std::integral_constant<int, C::DPW - S2 + j>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    });
+                });
+            } else {
 #pragma unroll
-            for (int ks = 0; ks < C::KS; ++ks)
+                for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < C::MT; ++mt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8_t, f[ks * (4 + C::MT) + nt]),
-                            __builtin_bit_cast(bf16x8_t, f[ks * (4 + C::MT) + 4 + mt]), acc[nt][mt], 0, 0, 0);
+                        for (int mt = 0; mt < C::MT; ++mt)
+                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8_t, f[ks * (4 + C::MT) + nt]),
+                                __builtin_bit_cast(bf16x8_t, f[ks * (4 + C::MT) + 4 + mt]), acc[nt][mt], 0, 0, 0);
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             LM_T(6);  // 5: MFMA issue
@@ -461,6 +541,19 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         // waves 4-7 are past every LDS read of this tile here, waves 0-3 finished theirs before the last barrier
 #endif
 
+        // per-row scales of the finished tile: requested before the ring fill (waiting for a load issued after the fill
+        // would drain the fill first)
+        float sc_pre[C::MT];
+        if constexpr ((VAR & LM_EPIORD) != 0 && MODE == GEMM_DOWN) {
+            const bool sc_on = grp_c < p.n_scaled;
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt) {
+                const int row = wm * (C::BM / 2) + 16 * mt + c;
+                sc_pre[mt] = (sc_on && row < mcnt_c) ? bf2f(p.scale[m0_c + row]) : 1.0f;
+            }
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt) asm volatile("" : "+v"(sc_pre[mt]));  // the loads stay above the fill
+        }
         // ---- next tile: every wave is past its last LDS read, so the ring can be refilled right away ----
         pos += pstep;
         const bool more = find_tile();
@@ -479,7 +572,9 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             const int row = wm * (C::BM / 2) + 16 * mt + c;
             const bool row_ok = row < mcnt_c;
             bf16_t* yrow = p.y + (int64_t)(m0_c + (row_ok ? row : 0)) * p.ldy;
-            const float sc = (scaled && row_ok) ? bf2f(p.scale[m0_c + row]) : 1.0f;
+            float sc;
+            if constexpr ((VAR & LM_EPIORD) != 0 && MODE == GEMM_DOWN) sc = sc_pre[mt];
+            else sc = (scaled && row_ok) ? bf2f(p.scale[m0_c + row]) : 1.0f;
             u32x2_t v[NOUT];  // packed columns 4*g4 .. 4*g4+3 of output tile t
 #pragma unroll
             for (int t = 0; t < NOUT; ++t) {
@@ -502,6 +597,29 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                 for (int t = 0; t < NOUT; ++t) asm volatile("" ::"v"(v[t][0]), "v"(v[t][1]));
                 continue;
             }
+            if constexpr ((VAR & LM_LDSEPI) != 0 && NOUT == 4) {
+                // 16 rows x 64 columns of this wave through its private 4 KiB patch in the ring slot that the next
+                // tile's fill does not touch (slot NSTAGE-1; fill_ring uses 0 .. DIST-1): lane (c, g4) writes its four
+                // 8-byte pieces of row c, then 8 lanes read one whole 128-byte row.  Row pitch 144 B (2-way write
+                // conflicts at most).  LDS instructions of one wave execute in order, so neither the read after the
+                // writes nor the next block's writes after these reads need a wait; the stores wait for the reads.
+                const unsigned patch = base + (C::NSTAGE - 1) * C::STAGE + wid * 4096;
+                const unsigned wa = patch + c * 144 + g4 * 8;
+                asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:32\n\t"
+                             "ds_write_b64 %0, %3 offset:64\n\tds_write_b64 %0, %4 offset:96"
+                             :: "v"(wa), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "memory");
+                const unsigned ra = patch + (lane >> 3) * 144 + (lane & 7) * 16;
+                u32x4_t r0, r1;
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1152\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(r0), "=&v"(r1) : "v"(ra) : "memory");
+                const int rrow = wm * (C::BM / 2) + 16 * mt + (lane >> 3);
+                const int n = ncol_w + 8 * (lane & 7);
+                if (n < p.N) {
+                    if (rrow < mcnt_c) *reinterpret_cast<u32x4_t*>(p.y + (int64_t)(m0_c + rrow) * p.ldy + n) = r0;
+                    if (rrow + 8 < mcnt_c) *reinterpret_cast<u32x4_t*>(p.y + (int64_t)(m0_c + rrow + 8) * p.ldy + n) = r1;
+                }
+                continue;
+            }
             if (WIDE) {
                 // tiles (t, t+1): after the swaps lane row g4 holds 8 consecutive columns of tile t + (g4 & 1),
                 // starting at column 8 * (g4 >> 1)
@@ -510,7 +628,11 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                     const u32x2_t a = __builtin_amdgcn_permlane16_swap(v[t][0], v[t + 1][0], false, false);
                     const u32x2_t b = __builtin_amdgcn_permlane16_swap(v[t][1], v[t + 1][1], false, false);
                     const int n = ncol_w + 16 * (t + (g4 & 1)) + 8 * (g4 >> 1);
-                    if (row_ok && n < p.N) *reinterpret_cast<u32x4_t*>(yrow + n) = u32x4_t{a[0], b[0], a[1], b[1]};
+                    if (row_ok && n < p.N) {
+                        const u32x4_t o4 = u32x4_t{a[0], b[0], a[1], b[1]};
+                        if constexpr ((VAR & LM_NT) != 0) __builtin_nontemporal_store(o4, reinterpret_cast<u32x4_t*>(yrow + n));
+                        else *reinterpret_cast<u32x4_t*>(yrow + n) = o4;
+                    }
                 }
             } else {
 #pragma unroll
@@ -519,6 +641,12 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                     if (row_ok && n < p.N) *reinterpret_cast<u32x2_t*>(yrow + n) = v[t];
                 }
             }
+        }
+        if constexpr ((VAR & LM_EPIORD) != 0) {
+            // exact only when every store instruction of the wave ran: all rows and columns of the tile exist
+            const bool full = mcnt_c == C::BM && ncol_w + (MODE == GEMM_GATEUP ? 32 : 64) <= p.N && !NOSTORE &&
+                              !((VAR & LM_LDSEPI) != 0 && NOUT == 4);
+            pending_stores = full ? LM_STORES_FULL : 0;
         }
         if (!more) break;
     }
@@ -594,9 +722,21 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
         GLM_LM_CASE(1);
         GLM_LM_CASE(2);
         GLM_LM_CASE(3);
+        GLM_LM_CASE(11);   // lean + wide + 2 DMA in the MFMA phase
+        GLM_LM_CASE(19);   // lean + wide + 4 DMA in the MFMA phase
+        GLM_LM_CASE(259);  // lean + wide + epilogue ordering
+        GLM_LM_CASE(67);   // lean + wide + XCD desync
+        GLM_LM_CASE(131);  // lean + wide + nt stores
+        GLM_LM_CASE(195);  // lean + wide + desync + nt
+        GLM_LM_CASE(35);   // lean + wide + LDS-transposed epilogue
+        GLM_LM_CASE(43);   // + 2 DMA in the MFMA phase
+        GLM_LM_CASE(51);   // + 4 DMA in the MFMA phase
 #if GLM_LM_STUDY
         GLM_LM_CASE(4);
         GLM_LM_CASE(7);
+        GLM_LM_CASE(263);
+        GLM_LM_CASE(15);
+        GLM_LM_CASE(23);
 #endif
         default:
             GLM_LM_CASE(0);

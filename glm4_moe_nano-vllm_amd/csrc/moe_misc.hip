@@ -9,6 +9,55 @@
 
 namespace {
 
+// Token→expert bucketing: one 1024-thread workgroup (counting sort with LDS atomics).
+constexpr int ALIGN_MAX_G = 1024;
+
+// body shared by moe_align_kernel and the router's last-arriving workgroup; cnt/cur: ALIGN_MAX_G + 1 ints of LDS each
+__device__ __forceinline__ void moe_align_body(const int64_t* topk_idx, const bf16_t* topk_w, int32_t* expert_offsets,
+                                               int32_t* sorted_token, bf16_t* sorted_scale, int32_t* pair_pos,
+                                               int64_t T, int k, int E, int with_shared, int* cnt, int* cur) {
+    const int tid = threadIdx.x;
+    const int64_t P = T * k;
+    for (int e = tid; e <= E; e += 1024) cnt[e] = 0;
+    __syncthreads();
+    for (int64_t p = tid; p < P; p += 1024) {
+        const int64_t e = topk_idx[p];
+        if (e >= 0 && e < E) atomicAdd(&cnt[(int)e], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int e = 0; e < E; ++e) {
+            const int c = cnt[e];
+            cur[e] = run;
+            expert_offsets[e] = run;
+            run += c;
+        }
+        expert_offsets[E] = run;  // == number of valid pairs; start of the shared group
+        cur[E] = run;
+        if (with_shared) expert_offsets[E + 1] = run + (int)T;
+    }
+    __syncthreads();
+    for (int64_t p = tid; p < P; p += 1024) {
+        const int64_t e = topk_idx[p];
+        if (e >= 0 && e < E) {
+            const int pos = atomicAdd(&cur[(int)e], 1);
+            sorted_token[pos] = (int32_t)(p / k);
+            sorted_scale[pos] = topk_w[p];
+            pair_pos[p] = pos;
+        } else {
+            pair_pos[p] = -1;
+        }
+    }
+    if (with_shared) {
+        const int sbase = cur[E];  // unchanged by the loop above (only cur[0..E-1] advance)
+        for (int64_t t = tid; t < T; t += 1024) {
+            sorted_token[sbase + t] = (int32_t)t;
+            sorted_scale[sbase + t] = 0x3F80;  // bf16 1.0
+        }
+    }
+}
+
 constexpr int ROUTER_MAX_E = 256;
 constexpr int ROUTER_EB = 4;  // experts per dot-product pass (x chunk reused 4x)
 constexpr int ROUTER_RU = 4;  // K steps whose gate-row loads are in flight together
@@ -34,6 +83,13 @@ struct RouterPre {
     bf16_t* y;              // [T,H] normalised output
     bf16_t* res_out;        // [T,H]
     float eps;
+    // optional: the LAST workgroup to finish also builds the sorted-row structure of glm_moe_align (one launch less)
+    int32_t* al_offsets;    // nullptr = off
+    int32_t* al_token;
+    bf16_t* al_scale;
+    int32_t* al_pos;
+    int al_with_shared;
+    unsigned* ticket;       // zero before the first launch; the last arriver puts the zero back
 };
 
 template <int PRE>
@@ -170,7 +226,9 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
         }
     }
     __syncthreads();
-    if (wid != 0) return;
+    const bool fuse_align = pre.al_offsets != nullptr;  // uniform (kernel argument)
+    if (wid != 0 && !fuse_align) return;
+    if (wid == 0) {
 
     // wave 0: R2..R7.  lane owns experts lane + 64*i.
     constexpr int EPL = ROUTER_MAX_E / 64;
@@ -260,12 +318,39 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
         }
         base += __popcll(m);
     }
+    }  // wave 0
+    if (!fuse_align) return;
+
+    // ---- last-arriving workgroup: token -> expert bucketing over ALL tokens' routing (glm_moe_align) ----
+    // Hand-off (cdna_hip_programming.md Guideline 16, counter form): wave 0 is the only wave that stored routing data;
+    // it drains its stores, lane 0 releases at agent scope and draws a ticket.  The workgroup that draws T-1 acquires,
+    // waits, and only then — behind the workgroup barrier — do all its waves read the other workgroups' rows.
+    int* flag = reinterpret_cast<int*>(lg);  // lg[] (>= 16 floats) is dead: every logit has been consumed
+    if (wid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned got = __hip_atomic_fetch_add(pre.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = got == (unsigned)gridDim.x - 1u;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(pre.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            }
+            flag[0] = last;
+        }
+    }
+    __syncthreads();
+    if (!flag[0]) return;
+    __syncthreads();  // flag read by everyone before the LDS is reused
+    int* cnt = reinterpret_cast<int*>(smem);  // the x row is dead; 2 * (E + 1) ints fit (host checks)
+    int* cur = cnt + (E + 1);
+    moe_align_body(topk_idx, topk_w, pre.al_offsets, pre.al_token, pre.al_scale, pre.al_pos, (int64_t)gridDim.x, k, E,
+                   pre.al_with_shared, cnt, cur);
 }
 
 // ------------------------------------------------------------------------------------------
-// Token→expert bucketing: one 1024-thread workgroup (counting sort with LDS atomics).
-constexpr int ALIGN_MAX_G = 1024;
-
 __global__ __launch_bounds__(1024) void moe_align_kernel(
     const int64_t* __restrict__ topk_idx, const bf16_t* __restrict__ topk_w,
     int32_t* __restrict__ expert_offsets, int32_t* __restrict__ sorted_token,
@@ -273,46 +358,7 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(
     int with_shared) {
     __shared__ int cnt[ALIGN_MAX_G + 1];
     __shared__ int cur[ALIGN_MAX_G + 1];
-    const int tid = threadIdx.x;
-    const int64_t P = T * k;
-    for (int e = tid; e <= E; e += 1024) cnt[e] = 0;
-    __syncthreads();
-    for (int64_t p = tid; p < P; p += 1024) {
-        const int64_t e = topk_idx[p];
-        if (e >= 0 && e < E) atomicAdd(&cnt[(int)e], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int e = 0; e < E; ++e) {
-            const int c = cnt[e];
-            cur[e] = run;
-            expert_offsets[e] = run;
-            run += c;
-        }
-        expert_offsets[E] = run;  // == number of valid pairs; start of the shared group
-        cur[E] = run;
-        if (with_shared) expert_offsets[E + 1] = run + (int)T;
-    }
-    __syncthreads();
-    for (int64_t p = tid; p < P; p += 1024) {
-        const int64_t e = topk_idx[p];
-        if (e >= 0 && e < E) {
-            const int pos = atomicAdd(&cur[(int)e], 1);
-            sorted_token[pos] = (int32_t)(p / k);
-            sorted_scale[pos] = topk_w[p];
-            pair_pos[p] = pos;
-        } else {
-            pair_pos[p] = -1;
-        }
-    }
-    if (with_shared) {
-        const int sbase = cur[E];  // unchanged by the loop above (only cur[0..E-1] advance)
-        for (int64_t t = tid; t < T; t += 1024) {
-            sorted_token[sbase + t] = (int32_t)t;
-            sorted_scale[sbase + t] = 0x3F80;  // bf16 1.0
-        }
-    }
+    moe_align_body(topk_idx, topk_w, expert_offsets, sorted_token, sorted_scale, pair_pos, T, k, E, with_shared, cnt, cur);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -510,12 +556,51 @@ extern "C" int glm_router_topk(const void* x, const void* gate_w,
     return GLM_OK;
 }
 
+static int add_rmsnorm_router_impl(const void* x, const float* part, int nslices, int64_t slice_stride,
+                                   const void* residual_in, const void* norm_weight, float eps, void* y,
+                                   void* residual_out, const void* gate_w, const float* e_score_correction_bias,
+                                   int64_t* topk_idx, void* topk_w, int64_t T, int H, int E, int k,
+                                   float routed_scaling_factor, int32_t* expert_offsets, int32_t* sorted_token,
+                                   void* sorted_scale, int32_t* pair_pos, int with_shared, uint32_t* ticket,
+                                   glm_stream_t stream);
+
 extern "C" int glm_add_rmsnorm_router_topk(const void* x, const float* part, int nslices, int64_t slice_stride,
                                            const void* residual_in, const void* norm_weight, float eps, void* y,
                                            void* residual_out, const void* gate_w,
                                            const float* e_score_correction_bias, int64_t* topk_idx, void* topk_w,
                                            int64_t T, int H, int E, int k, float routed_scaling_factor,
                                            glm_stream_t stream) {
+    return add_rmsnorm_router_impl(x, part, nslices, slice_stride, residual_in, norm_weight, eps, y, residual_out, gate_w,
+                                   e_score_correction_bias, topk_idx, topk_w, T, H, E, k, routed_scaling_factor, nullptr,
+                                   nullptr, nullptr, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int glm_add_rmsnorm_router_topk_align(const void* x, const float* part, int nslices, int64_t slice_stride,
+                                                 const void* residual_in, const void* norm_weight, float eps, void* y,
+                                                 void* residual_out, const void* gate_w,
+                                                 const float* e_score_correction_bias, int64_t* topk_idx, void* topk_w,
+                                                 int64_t T, int H, int E, int k, float routed_scaling_factor,
+                                                 int32_t* expert_offsets, int32_t* sorted_token, void* sorted_scale,
+                                                 int32_t* pair_pos, int with_shared, uint32_t* ticket,
+                                                 glm_stream_t stream) {
+    GLM_CHECK_ARG(expert_offsets && sorted_token && sorted_scale && pair_pos && ticket, GLM_ERR_INVALID,
+                  "glm_add_rmsnorm_router_topk_align: null pointer");
+    GLM_CHECK_ARG(E < ALIGN_MAX_G && T * (int64_t)(k + 1) < (1ll << 31) && T <= 0x7fffffff &&
+                      (size_t)2 * (E + 1) * 4 <= (size_t)H * 2,
+                  GLM_ERR_UNSUPPORTED, "glm_add_rmsnorm_router_topk_align: needs E<%d, T*(k+1) < 2^31, 4(E+1) <= H",
+                  ALIGN_MAX_G);
+    return add_rmsnorm_router_impl(x, part, nslices, slice_stride, residual_in, norm_weight, eps, y, residual_out, gate_w,
+                                   e_score_correction_bias, topk_idx, topk_w, T, H, E, k, routed_scaling_factor,
+                                   expert_offsets, sorted_token, sorted_scale, pair_pos, with_shared, ticket, stream);
+}
+
+static int add_rmsnorm_router_impl(const void* x, const float* part, int nslices, int64_t slice_stride,
+                                   const void* residual_in, const void* norm_weight, float eps, void* y,
+                                   void* residual_out, const void* gate_w, const float* e_score_correction_bias,
+                                   int64_t* topk_idx, void* topk_w, int64_t T, int H, int E, int k,
+                                   float routed_scaling_factor, int32_t* expert_offsets, int32_t* sorted_token,
+                                   void* sorted_scale, int32_t* pair_pos, int with_shared, uint32_t* ticket,
+                                   glm_stream_t stream) {
     GLM_CHECK_ARG((x != nullptr) != (part != nullptr), GLM_ERR_INVALID,
                   "glm_add_rmsnorm_router_topk: give either x (bf16) or part (fp32 partial sums)");
     GLM_CHECK_ARG(residual_in && norm_weight && y && residual_out && gate_w && e_score_correction_bias && topk_idx &&
@@ -534,6 +619,8 @@ extern "C" int glm_add_rmsnorm_router_topk(const void* x, const float* part, int
     pre.x = (const bf16_t*)x; pre.part = part; pre.nslices = nslices; pre.slice_stride = slice_stride;
     pre.res_in = (const bf16_t*)residual_in; pre.norm_w = (const bf16_t*)norm_weight; pre.y = (bf16_t*)y;
     pre.res_out = (bf16_t*)residual_out; pre.eps = eps;
+    pre.al_offsets = expert_offsets; pre.al_token = sorted_token; pre.al_scale = (bf16_t*)sorted_scale;
+    pre.al_pos = pair_pos; pre.al_with_shared = with_shared; pre.ticket = ticket;
     if (x)
         hipLaunchKernelGGL(router_topk_kernel<1>, dim3((unsigned)T), dim3(ROUTER_NT), shm, glm_s(stream), (const bf16_t*)y,
                            (const bf16_t*)gate_w, e_score_correction_bias, topk_idx, (bf16_t*)topk_w, (bf16_t*)nullptr, H, E,

@@ -22,6 +22,7 @@ _lib = None
 _SIGNATURES = {
     "glm_abi_version": (c_int, []),
     "glm_last_error": (c_char_p, []),
+    "glm_debug_largem_variant": (c_int, [c_int]),
     "glm_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "glm_add_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                 c_float, c_void_p]),
@@ -73,6 +74,10 @@ _SIGNATURES = {
     "glm_add_rmsnorm_router_topk": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_float, c_void_p,
                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                             c_int, c_float, c_void_p]),
+    "glm_add_rmsnorm_router_topk_align": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_float,
+                                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                                  c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                  c_int, c_void_p, c_void_p]),
     "glm_moe_combine_add_rmsnorm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p,
                                             c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "glm_add_rmsnorm_partial": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -369,10 +374,25 @@ def router_topk(x: torch.Tensor, gate_w: torch.Tensor, bias: torch.Tensor, k: in
     return (idx, w, logits) if return_logits else (idx, w)
 
 
+_tickets: dict = {}
+
+
+def _ticket(device) -> torch.Tensor:
+    """The zero-initialised arrival counter of the fused router + align launch (one per device; the kernel restores
+    the zero, and launches on one device are stream-ordered in this engine)."""
+    t = _tickets.get(device)
+    if t is None:
+        t = torch.zeros(4, dtype=torch.int32, device=device)
+        _tickets[device] = t
+    return t
+
+
 def add_rmsnorm_router_topk(x, residual: torch.Tensor, norm_weight: torch.Tensor, eps: float,
-                            gate_w: torch.Tensor, bias: torch.Tensor, k: int, routed_scaling_factor: float):
+                            gate_w: torch.Tensor, bias: torch.Tensor, k: int, routed_scaling_factor: float,
+                            align_with_shared: bool | None = None):
     """Post-attention add-RMSNorm + router in one launch.  x: bf16 [T,H] tensor or PartialSum (o_proj partial sums).
-    Returns (normalised hidden, residual_out, topk_idx, topk_w)."""
+    Returns (normalised hidden, residual_out, topk_idx, topk_w); with align_with_shared = True/False the same launch
+    also builds moe_align's (expert_offsets, sorted_token, sorted_scale, pair_pos), returned as a fifth element."""
     _bf16(residual, "residual"); _bf16(norm_weight, "norm_weight"); _bf16(gate_w, "gate_w")
     assert bias.dtype == torch.float32
     H = residual.shape[-1]
@@ -392,10 +412,24 @@ def add_rmsnorm_router_topk(x, residual: torch.Tensor, norm_weight: torch.Tensor
         x2 = x.reshape(-1, H).contiguous()
         assert x2.shape[0] == T
         xp, pp, ns, stride = _p(x2), None, 0, 0
+    if align_with_shared is not None and 8 * (E + 1) <= 2 * H:
+        ws = bool(align_with_shared)
+        G, R, dev = E + (1 if ws else 0), T * k + (T if ws else 0), r2.device
+        offs = torch.empty(G + 1, dtype=torch.int32, device=dev)
+        tok = torch.empty(R, dtype=torch.int32, device=dev)
+        scale = torch.empty(R, dtype=torch.bfloat16, device=dev)
+        pos = torch.empty(T * k, dtype=torch.int32, device=dev)
+        _check(load_library().glm_add_rmsnorm_router_topk_align(
+            xp, pp, ns, stride, _p(r2), _p(norm_weight), eps, _p(y), _p(ro), _p(gate_w), _p(bias), _p(idx), _p(w), T, H,
+            E, k, routed_scaling_factor, _p(offs), _p(tok), _p(scale), _p(pos), 1 if ws else 0, _p(_ticket(dev)),
+            _stream()), "glm_add_rmsnorm_router_topk_align")
+        return y.view(residual.shape), ro.view(residual.shape), idx, w, (offs, tok, scale, pos)
     _check(load_library().glm_add_rmsnorm_router_topk(xp, pp, ns, stride, _p(r2), _p(norm_weight), eps, _p(y), _p(ro),
                                                       _p(gate_w), _p(bias), _p(idx), _p(w), T, H, E, k,
                                                       routed_scaling_factor, _stream()),
            "glm_add_rmsnorm_router_topk")
+    if align_with_shared is not None:
+        return y.view(residual.shape), ro.view(residual.shape), idx, w, moe_align(idx, w, E, bool(align_with_shared))
     return y.view(residual.shape), ro.view(residual.shape), idx, w
 
 

@@ -58,10 +58,11 @@ class Glm4MoeDecoderLayer(nn.Module):
         if self.fuse_norm_router and gate is not None and residual.shape[-1] <= 8192:
             # post-attention add-RMSNorm and the router of the same token in one launch
             ln = self.post_attention_layernorm
-            hidden_states, residual, idx, w = hip_ops.add_rmsnorm_router_topk(
+            # ... and the token -> expert bucketing (moe_align), done by that launch's last workgroup
+            hidden_states, residual, idx, w, aligned = hip_ops.add_rmsnorm_router_topk(
                 hidden_states, residual, ln.weight.data, ln.eps, gate.weight.data, gate.e_score_correction_bias,
-                gate.top_k, float(gate.routed_scaling_factor))
-            hidden_states = self.mlp(hidden_states, routing=(idx, w), defer_combine=defer_combine)
+                gate.top_k, float(gate.routed_scaling_factor), align_with_shared=True)
+            hidden_states = self.mlp(hidden_states, routing=(idx, w), aligned=aligned, defer_combine=defer_combine)
         else:
             hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
             if gate is not None:

@@ -107,8 +107,9 @@ class Glm4MoeMoE(nn.Module):
         self.shared_experts.load_weights(path, f"{prefix}.shared_experts")
 
     # ---- forward ------------------------------------------------------------------------
-    def forward(self, hidden_states: torch.Tensor, routing=None, defer_combine: bool = False):
+    def forward(self, hidden_states: torch.Tensor, routing=None, defer_combine: bool = False, aligned=None):
         """routing: (topk_idx, topk_w) already computed for these rows (decode_layer's fused norm + router).
+        aligned: hip_ops.moe_align(topk_idx, topk_w, E, True) of that routing, when the same launch produced it.
         defer_combine: the caller hands the result straight to the next layer's RMSNorm.forward(x, residual) and
         accepts a hip_ops.DeferredCombine (TP=1 only)."""
         shape = hidden_states.shape
@@ -117,7 +118,7 @@ class Glm4MoeMoE(nn.Module):
         E, k = self.config.n_routed_experts, self.config.num_experts_per_tok
         w13, w2 = self._stacked()
         topk_idx, topk_w = self.gate(h, precomputed=routing)
-        offs, tok, scale, pos = hip_ops.moe_align(topk_idx, topk_w, E, True)
+        offs, tok, scale, pos = aligned if aligned is not None else hip_ops.moe_align(topk_idx, topk_w, E, True)
         R = T * k + T
         if self.expert_weight_dtype == "fp8_e4m3":
             if self._fp8 is None:

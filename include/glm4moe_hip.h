@@ -221,6 +221,17 @@ int glm_add_rmsnorm_router_topk(const void* x, const float* part, int nslices, i
                                 void* residual_out, const void* gate_w, const float* e_score_correction_bias,
                                 int64_t* topk_idx, void* topk_w, int64_t T, int H, int E, int k,
                                 float routed_scaling_factor, glm_stream_t stream);
+/*     … and glm_moe_align in the same launch: the workgroup that finishes last (agent-scope release / ticket /
+ *     acquire, no co-residency or placement assumption) buckets all T*k pairs.  expert_offsets … pair_pos as
+ *     glm_moe_align.  ticket: one uint32 that is ZERO before the first launch on it (the kernel puts the zero back);
+ *     launches sharing a ticket must be stream-ordered.  Needs 8 (E + 1) <= 2 H bytes of LDS reuse.                */
+int glm_add_rmsnorm_router_topk_align(const void* x, const float* part, int nslices, int64_t slice_stride,
+                                      const void* residual_in, const void* norm_weight, float eps, void* y,
+                                      void* residual_out, const void* gate_w, const float* e_score_correction_bias,
+                                      int64_t* topk_idx, void* topk_w, int64_t T, int H, int E, int k,
+                                      float routed_scaling_factor, int32_t* expert_offsets, int32_t* sorted_token,
+                                      void* sorted_scale, int32_t* pair_pos, int with_shared, uint32_t* ticket,
+                                      glm_stream_t stream);
 
 /* a12+a3 fused: glm_moe_combine of layer i and the input add-RMSNorm of layer i+1 (decode_layer.py:47-49) in one
  *     launch at TP=1: out = normalised rows, residual_out = bf16(combine + residual_in).  H <= 16384.            */
@@ -239,6 +250,11 @@ int glm_paged_attn_decode_qkv(const void* qkv, int64_t qkv_stride, const int64_t
                               int nh, int nkv, int hd, int block_size, int64_t n_blocks, float scale,
                               int num_splits, int max_context_len, void* workspace,
                               size_t workspace_bytes, glm_stream_t stream);
+
+/* Tuning studies only (tools/largem_ab.py): kernel variant of the LDS-tiled large-M GEMM for the next launches of this
+ * process — a bit set of lean load phase (1), 16-byte epilogue stores (2), … (csrc/gemm_largem.hip); < 0 restores the
+ * default.  Every variant that stores results is bit-identical to variant 0.  Returns the previous value.          */
+int glm_debug_largem_variant(int variant);
 
 #ifdef __cplusplus
 }

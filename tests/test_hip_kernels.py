@@ -270,31 +270,37 @@ def test_router_air_shape(ops):
     assert float((logits != rlogits).float().mean()) < 2e-3, "too many logit rounding flips"
 
 
+def _check_align(offs, tok, scale, pos, idx, w, E, shared):
+    """moe_align's contract: groups in ascending expert id, every (token, expert) pair exactly once, pair_pos ↔ rows."""
+    T, k = idx.shape
+    offs, tok, scale, pos = [a.cpu() for a in (offs, tok, scale, pos)]
+    counts = torch.bincount(idx.flatten(), minlength=E)
+    exp_offs = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)])
+    assert torch.equal(offs[: E + 1].long(), exp_offs)
+    for e in range(E):
+        seg = range(int(offs[e]), int(offs[e + 1]))
+        toks = sorted(int(tok[r]) for r in seg)
+        assert toks == sorted(torch.where((idx == e).any(dim=1))[0].tolist())
+    flat_pos = pos.view(T, k)
+    for t in range(T):
+        for j in range(k):
+            r = int(flat_pos[t, j])
+            assert int(offs[int(idx[t, j])]) <= r < int(offs[int(idx[t, j]) + 1])
+            assert int(tok[r]) == t and scale[r] == w[t, j]
+    assert len(set(pos.tolist())) == T * k
+    if shared:
+        assert int(offs[E + 1]) == T * k + T
+        assert tok[T * k:].tolist() == list(range(T))
+        assert bool((scale[T * k:].float() == 1.0).all())
+
+
 def test_moe_align(ops):
     T, k, E = 37, 4, 16
     g = torch.Generator().manual_seed(41)
     idx = torch.stack([torch.randperm(E, generator=g)[:k].sort()[0] for _ in range(T)]).to(torch.int64)
     w = rnd(T, k, seed=42).abs()
     for shared in (True, False):
-        offs, tok, scale, pos = [a.cpu() for a in ops.moe_align(dev(idx), dev(w), E, shared)]
-        counts = torch.bincount(idx.flatten(), minlength=E)
-        exp_offs = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)])
-        assert torch.equal(offs[: E + 1].long(), exp_offs)
-        for e in range(E):
-            seg = range(int(offs[e]), int(offs[e + 1]))
-            toks = sorted(int(tok[r]) for r in seg)
-            assert toks == sorted(torch.where((idx == e).any(dim=1))[0].tolist())
-        flat_pos = pos.view(T, k)
-        for t in range(T):
-            for j in range(k):
-                r = int(flat_pos[t, j])
-                assert int(offs[int(idx[t, j])]) <= r < int(offs[int(idx[t, j]) + 1])
-                assert int(tok[r]) == t and scale[r] == w[t, j]
-        assert len(set(pos.tolist())) == T * k
-        if shared:
-            assert int(offs[E + 1]) == T * k + T
-            assert tok[T * k:].tolist() == list(range(T))
-            assert bool((scale[T * k:].float() == 1.0).all())
+        _check_align(*ops.moe_align(dev(idx), dev(w), E, shared), idx, w, E, shared)
 
 
 def _moe_hip(ops, x, gate_w, bias, k, rsf, w13, w2, sw13, sw2, topk=None):
@@ -452,6 +458,16 @@ def test_fused_add_rmsnorm_router(ops, T, H, E, k, partial):
     y1, r1, i1, w1 = ops.add_rmsnorm_router_topk(x, dev(res), dev(nw), 1e-5, dev(gw), dev(bias), k, 2.5)
     assert torch.equal(y0, y1) and torch.equal(r0, r1)
     assert torch.equal(i0, i1) and torch.equal(w0, w1)
+    # ... and with the token -> expert bucketing done by the launch's last workgroup (agent-scope hand-off): launched
+    # repeatedly on the same ticket, between unrelated launches that keep the other CUs busy
+    for rep in range(4):
+        for shared in (True, False):
+            y2, r2, i2, w2, al = ops.add_rmsnorm_router_topk(x, dev(res), dev(nw), 1e-5, dev(gw), dev(bias), k, 2.5,
+                                                             align_with_shared=shared)
+            ops.rmsnorm(dev(rnd(64, 4096, seed=rep)), dev(rnd(4096, seed=7)), 1e-5)
+            assert torch.equal(y0, y2) and torch.equal(r0, r2) and torch.equal(i0, i2) and torch.equal(w0, w2)
+            _check_align(*al, i2.cpu(), w2.cpu(), E, shared)
+    assert int(ops._ticket(y1.device)[0]) == 0, "the arrival counter must be back at zero"
 
 
 def test_gemm_bf16_strided_input(ops):
