@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--ctx", type=int, default=4096)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c2", action="store_true", help="skip the second measured entry (BASELINE config 2: bs=1 ctx=1024)")
     ap.add_argument("--kernel-iters", type=int, default=20)
     ap.add_argument("--emulate-tp", type=int, default=1,
                     help="kernel-shape study on ONE GPU: run the per-rank shapes of TP=N (heads, kv heads, expert/MLP "
@@ -258,6 +259,12 @@ def main():
     if rank == 0:
         kernels = measure_kernels(model, cfg, hip_ops, B, ctx, world, args.kernel_iters, dev)
 
+    # ---- BASELINE config 2 (greedy bs=1, ctx=1024) on the same model, as a second measured entry ----
+    extra = {}
+    if world == 1 and not args.no_c2 and (B, ctx) != (1, 1024) and args.emulate_tp == 1:
+        extra["c2_bs1_ctx1024"] = measure_c2(model, cfg, kv, dev, L, bs, args.fp8_experts)
+        set_context(False, slot_mapping=slot_mapping, context_lens=context_lens, block_tables=block_tables)
+
     cpu_base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_base = cpu_baseline(model, cfg, kv, block_tables, context_lens, positions, slot_mapping, B, L)
@@ -279,6 +286,7 @@ def main():
                        "ms_per_layer": round(ms_per_step / L, 4), "model_build_s": round(t_build, 1)},
             "roofline": dom,
             "kernels": kernels,
+            "extra": extra,
             "cpu_baseline": cpu_base,
         }
         print(json.dumps(line))
@@ -287,21 +295,98 @@ def main():
         dist.destroy_process_group()
 
 
+def _kernel_source_digest() -> str:
+    """sha256 over the kernel sources and this file: what a PMC summary must have been taken with to describe this run."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "glm4_moe_nano-vllm_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _git(*args) -> str | None:
+    import subprocess
+    try:
+        r = subprocess.run(["git", *args], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=10)
+        return r.stdout.decode().strip() or None if r.returncode == 0 else None
+    except Exception:  # noqa: BLE001 - no git on the box is not an error
+        return None
+
+
+def measure_c2(model, cfg, kv, dev, L, bs, fp8, steps=30, warmup=5):
+    """BASELINE config 2 — random-init bf16, TP=1, greedy decode of ONE sequence at context 1024 — on the model the
+    headline run built: whole step in one HIP graph, tokens/s, and the layer's algorithmic HBM bytes over its time."""
+    import torch
+    from nanovllm.utils.context import set_context
+    B, ctx = 1, 1024
+    per = (ctx + bs - 1) // bs
+    bt = torch.arange(3, 3 + per, dtype=torch.int32, device=dev).view(1, per)
+    cl = torch.full((B,), ctx, dtype=torch.int32, device=dev)
+    pos = torch.full((B,), ctx - 1, dtype=torch.int64, device=dev)
+    slots = (bt[:, (ctx - 1) // bs].to(torch.int64) * bs + (ctx - 1) % bs).to(torch.int32)
+    ids = torch.randint(0, cfg.vocab_size, (B,), generator=torch.Generator().manual_seed(11)).to(dev)
+    tok = torch.zeros(B, dtype=torch.int64, device=dev)
+    set_context(False, slot_mapping=slots, context_lens=cl, block_tables=bt)
+
+    @torch.inference_mode()
+    def step():
+        logits = model.compute_logits(model(ids, pos))
+        tok.copy_(torch.argmax(logits, dim=-1))
+
+    step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    for _ in range(warmup):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    H, I, E, k = cfg.hidden_size, cfg.moe_intermediate_size, cfg.n_routed_experts, cfg.num_experts_per_tok
+    nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    wb = 1 if fp8 else 2
+    layer_bytes = ((nh + 2 * nkv) * hd * H * 2 + H * nh * hd * 2 + E * H * 2 + (k + 1) * 3 * I * H * wb
+                   + B * ctx * nkv * hd * 2 * 2)
+    return {"workload": "greedy decode bs=1 ctx=1024, same model", "tokens_per_s": round(B / dt, 2),
+            "ms_per_step": round(dt * 1e3, 4), "ms_per_layer": round(dt * 1e3 / L, 4), "steps": steps, "hip_graph": True,
+            "layer_algorithmic_bytes": int(layer_bytes),
+            "layer_hbm_frac": round(layer_bytes / (dt / L) / 1e9 / HBM_PEAK_GBS, 4),
+            "bytes_model": "QKV + O + router + (k+1) experts x 3*I*H + KV read, per MoE layer (BASELINE.md §3 at bs=1)"}
+
+
 def attach_pmc_traffic(kernels: dict) -> None:
-    """`traffic` = HBM bytes per launch from the PMC counters.  The counters need their own
-    `rocprofv3 --pmc` passes (FETCH_SIZE and WRITE_SIZE cannot share a pass), so they are taken
-    from the newest committed summary under profiles/ (same workload, TP=1) rather than re-measured
-    inside this run; null when no summary covers the kernel."""
+    """`traffic` = HBM bytes per launch from the PMC counters.  The counters need their own `rocprofv3 --pmc` passes
+    (FETCH_SIZE and WRITE_SIZE cannot share a pass, and a profiled run is not a timed run), so they come from the
+    newest committed summary under profiles/ (tools/pmc_traffic.sh, same workload, TP=1).  The summary records the
+    digest of the kernel sources it was taken with; it is attached only when that digest equals the digest of the
+    sources of THIS run, together with the file's git blob id and the commit that last touched it — otherwise
+    `traffic` stays null and `traffic_note` says why."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
     if not files:
         return
     with open(files[-1]) as f:
         pmc = json.load(f)
+    meta = pmc.get("_meta", {})
+    rel = os.path.relpath(files[-1], ROOT)
+    now = _kernel_source_digest()
+    fresh = meta.get("kernel_source_digest") == now
+    src = {"file": rel, "git_blob": _git("hash-object", files[-1]), "git_commit": _git("log", "-1", "--format=%h", "--", rel),
+           "kernel_source_digest": meta.get("kernel_source_digest"), "this_run_digest": now}
     for name, rec in kernels.items():
-        if name in pmc and rec.get("bound") == "hbm":
-            rec["traffic"] = pmc[name]["hbm_bytes_corrected"]
-            rec["traffic_source"] = os.path.relpath(files[-1], ROOT)
+        if name in pmc and (rec.get("bound") == "hbm" or "hbm_bytes_corrected" in pmc[name]):
+            if fresh:
+                rec["traffic"] = pmc[name]["hbm_bytes_corrected"]
+                rec["traffic_source"] = src
+            else:
+                rec["traffic_note"] = f"{rel} was taken with other kernel sources ({src['kernel_source_digest']} != {now})"
 
 
 def measure_kernels(model, cfg, ops, B, ctx, world, iters, dev):
@@ -455,6 +540,14 @@ def measure_prefill_gemm(layer, cfg, ops, world, dev, T=16384, iters=10, warm=5)
         out[name] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel_us_mean": round(us, 1),
                      "algorithmic_flops": flops, "flops_model": f"2*R*N*K with R={R} rows (T={T}, k={k}, +shared)"}
+    # the grouped expert GEMM as ONE figure: both launches' FLOPs over both launches' time
+    a, b = out["grouped_gemm_gateup_silu@prefill16k"], out["grouped_gemm_down@prefill16k"]
+    fl, us = a["algorithmic_flops"] + b["algorithmic_flops"], a["kernel_us_mean"] + b["kernel_us_mean"]
+    tf = fl / (us * 1e-6) / 1e12
+    out["grouped_gemm@prefill16k"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                      "kernel_us_mean": round(us, 1), "algorithmic_flops": fl,
+                                      "flops_model": "gate|up + down launches together"}
     return out
 
 
@@ -463,9 +556,11 @@ def cpu_baseline(model, cfg, kv, block_tables, context_lens, positions, slot_map
     shapes, timed on the host cores; tokens/s is extrapolated to L layers."""
     import torch
     from oracle import glm4_moe_oracle as O
-    # a 1-GPU box owns a 16-core share of the host; more threads than that oversubscribe it
-    # (measured: 256 threads run the same GEMMs 100-300x slower than 16)
-    ncores = min(16, os.cpu_count() or 1)
+    # BASELINE.md §4 asks for os.cpu_count() threads.  A 1-GPU box owns a 16-core SHARE of a host that reports 256:
+    # 256 threads oversubscribe that share and run the same GEMMs 100-300x slower (r01 probe, tools/cpu_probe.py), so
+    # the thread count is capped at the share; both numbers are reported.
+    host_cpus = os.cpu_count() or 1
+    ncores = min(16, host_cpus)
     torch.set_num_threads(ncores)
     layer = next(l for l in model.model.layers if hasattr(l.mlp, "gate"))
     li = list(model.model.layers).index(layer)
@@ -488,15 +583,16 @@ def cpu_baseline(model, cfg, kv, block_tables, context_lens, positions, slot_map
     pos = cpu(positions)
     times = []
     with torch.inference_mode():
-        for it in range(3):  # 1 warm-up + 2 timed
+        for it in range(4):  # 1 warm-up + 3 timed, ~3 s each
             t0 = time.perf_counter()
             O.decoder_layer(pos, h, r, lw, c, cs, kc, vc, meta)
             times.append(time.perf_counter() - t0)
-            if sum(times) > 40:
+            if sum(times) > 60:
                 break
     timed = times[1:] if len(times) > 1 else times
     t_layer = sorted(timed)[len(timed) // 2]
-    return {"value": round(B / (L * t_layer), 3), "unit": "tokens/s", "cores": ncores, "kind": "port",
+    return {"value": round(B / (L * t_layer), 3), "unit": "tokens/s", "cores": ncores, "host_cpu_count": host_cpus,
+            "kind": "port",
             "sample": f"one MoE decoder layer, decode step B={B} ctx={int(context_lens[0])}, torch CPU bf16, "
                       f"{len(timed)} timed run(s) after 1 warm-up, median {t_layer * 1e3:.0f} ms/layer-step; "
                       f"tokens/s = B / (L={L} x t_layer)",

@@ -136,7 +136,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 //             An XCD stays in step with itself (its co-resident tiles share operand panels through its L2).
 //   LM_NT     non-temporal epilogue stores (the output is not read again by this kernel).
 constexpr int LM_LEAN = 1, LM_WIDEST = 2, LM_NOSTORE = 4, LM_DMA2 = 8, LM_DMA4 = 16, LM_LDSEPI = 32, LM_DESYNC = 64,
-              LM_NT = 128, LM_EPIORD = 256;
+              LM_NT = 128, LM_EPIORD = 256, LM_NOPRIO = 512, LM_LOADPRIO = 1024;  // issue-priority studies
 //   LM_EPIORD the epilogue's global LOADS (per-row scales) are issued before the next tile's ring fill, so that waiting
 //             for them does not drain the fill; and the wait that opens a tile leaves the previous tile's stores in
 //             flight (vmcnt counts in issue order and the fill was issued before them) whenever their number is
@@ -411,6 +411,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             u32x4_t f[C::NF];
             const int nslot = slot == 0 ? C::NSTAGE - 1 : slot - 1;  // slot of tile kt-1
             LM_T(0);
+            if constexpr ((VAR & LM_LOADPRIO) != 0) __builtin_amdgcn_s_setprio(1);
             if (S2 > 0) {
                 if (kt + C::DIST < nk)
                     static_for<C::DPW - S2>([&](auto jc) { stage_one(nslot, kt + C::DIST, jc); });
@@ -445,10 +446,11 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             lds_wait(f);
             LM_T(4);  // 3: LDS wait
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((VAR & LM_LOADPRIO) != 0) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();  // B1
             LM_T(5);  // 4: barrier 1
             // ---------------- phase 2 ----------------
-            __builtin_amdgcn_s_setprio(1);
+            if constexpr ((VAR & (LM_NOPRIO | LM_LOADPRIO)) == 0) __builtin_amdgcn_s_setprio(1);
             if constexpr (S2 > 0) {
                 // the same MFMAs in the same order, with the remaining S2 DMA instructions of tile kt+DIST spread
                 // between them (pinned: nothing moves across a sched_barrier)
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                                 __builtin_bit_cast(bf16x8_t, f[ks * (4 + C::MT) + nt]),
                                 __builtin_bit_cast(bf16x8_t, f[ks * (4 + C::MT) + 4 + mt]), acc[nt][mt], 0, 0, 0);
             }
-            __builtin_amdgcn_s_setprio(0);
+            if constexpr ((VAR & (LM_NOPRIO | LM_LOADPRIO)) == 0) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             LM_T(6);  // 5: MFMA issue
             __builtin_amdgcn_s_barrier();  // B2
@@ -725,6 +727,8 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
         GLM_LM_CASE(11);   // lean + wide + 2 DMA in the MFMA phase
         GLM_LM_CASE(19);   // lean + wide + 4 DMA in the MFMA phase
         GLM_LM_CASE(259);  // lean + wide + epilogue ordering
+        GLM_LM_CASE(771);  // ... without the MFMA-phase priority
+        GLM_LM_CASE(1283); // ... with the LOAD phase at priority 1
         GLM_LM_CASE(67);   // lean + wide + XCD desync
         GLM_LM_CASE(131);  // lean + wide + nt stores
         GLM_LM_CASE(195);  // lean + wide + desync + nt

@@ -745,8 +745,11 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
 #if !defined(GLM_SM_NO_DMA) && !defined(GLM_SM_DMA_MID)
 #define GLM_SM_DMA_MID 2, 1, 2, 2  // 23.7 us (4,2,2,2: 25.6; 1,1,2,2: 24.4; 4,1,2,2: 39.8)
 #endif
+#ifndef GLM_SM_DMA_MIN_ROWS
+#define GLM_SM_DMA_MIN_ROWS 17  // total rows from which the grouped projections take the LDS-DMA body
+#endif
 #ifdef GLM_SM_DMA_GATEUP
-    if (mode == GEMM_GATEUP && p.R > 16) return launch_cfg_dma<GEMM_GATEUP, GLM_SM_DMA_GATEUP>(p, st);
+    if (mode == GEMM_GATEUP && p.R >= GLM_SM_DMA_MIN_ROWS) return launch_cfg_dma<GEMM_GATEUP, GLM_SM_DMA_GATEUP>(p, st);
 #endif
 #if !defined(GLM_SM_NO_DMA) && !defined(GLM_SM_DMA_DOWN)
 #define GLM_SM_DMA_DOWN 1, 1, 2, 2  // one-wave workgroups (32 KiB of LDS each): 122 -> 115 us; 4,1,2,2 and 2,1,2,2: 116-117
@@ -758,12 +761,19 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
 #ifndef GLM_SM_DMA_DOWN_DENSE
 #define GLM_SM_DMA_DOWN_DENSE 4, 4, 1, 2
 #endif
-    if (mode == GEMM_DOWN && p.G == 1 && p.R > 16 && p.K >= 4096) return launch_cfg_dma<GEMM_DOWN, GLM_SM_DMA_DOWN_DENSE>(p, st);
+    if (mode == GEMM_DOWN && p.G == 1 && p.R >= GLM_SM_DMA_MIN_ROWS && p.K >= 4096) return launch_cfg_dma<GEMM_DOWN, GLM_SM_DMA_DOWN_DENSE>(p, st);
 #endif
     // a K of one or two chunks (TP=8 shard: 176) leaves the ring nothing to overlap: 37 vs 31 us for the VGPR body
-    if (mode == GEMM_DOWN && p.R > 16 && p.K >= 512) return launch_cfg_dma<GEMM_DOWN, GLM_SM_DMA_DOWN>(p, st);
+    if (mode == GEMM_DOWN && p.R >= GLM_SM_DMA_MIN_ROWS && p.K >= 512) return launch_cfg_dma<GEMM_DOWN, GLM_SM_DMA_DOWN>(p, st);
 #endif
-    if (mode == GEMM_GATEUP && p.R <= 16) return launch_cfg<GEMM_GATEUP, 4, 1, 2, 2>(p, st);
+#ifndef GLM_SM_CFG_GATEUP_R16
+#define GLM_SM_CFG_GATEUP_R16 4, 1, 2, 2
+#endif
+#ifndef GLM_SM_CFG_DOWN_R16
+#define GLM_SM_CFG_DOWN_R16 2, 1, 2, 2  // single sequence (9 groups): 25.7 us (4,2,1,2: 27.8; 4,1,1,2: 25.9; 8,1,1,2: 30.3; r02 sweep)
+#endif
+    if (mode == GEMM_GATEUP && p.R <= 16) return launch_cfg<GEMM_GATEUP, GLM_SM_CFG_GATEUP_R16>(p, st);
+    if (mode == GEMM_DOWN && p.R <= 16) return launch_cfg<GEMM_DOWN, GLM_SM_CFG_DOWN_R16>(p, st);
     if (mode == GEMM_GATEUP) return launch_cfg<GEMM_GATEUP, GLM_SM_CFG_GATEUP>(p, st);
     if (mode == GEMM_DOWN) return launch_cfg<GEMM_DOWN, GLM_SM_CFG_DOWN>(p, st);
     // dense projection: choose the K-split so that the grid covers the chip
@@ -809,7 +819,7 @@ int glm_launch_gemm_smallm_partial(const GemmParams& p, hipStream_t st) {
 #define GLM_SM_CFG_PARTIAL 4, 1, 1, 2
 #endif
 #if !defined(GLM_SM_NO_DMA) && !defined(GLM_SM_DMA_PARTIAL)
-#define GLM_SM_DMA_PARTIAL 4, 1, 2, 2
+#define GLM_SM_DMA_PARTIAL 2, 1, 4, 2  // o_proj slices at M=32: 19.0 us (4,1,2,2: 20.1; 1,1,4,2: 21.8; 2,1,2,2: 21.2; r02 sweep)
 #endif
 #ifdef GLM_SM_DMA_PARTIAL
     return launch_cfg_dma<GEMM_PLAIN, GLM_SM_DMA_PARTIAL>(p, st);

@@ -63,6 +63,14 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(uintptr_t)(const lds_void*)p;
 }
 
+// write-through (sc1) stores for data another workgroup reads in the same launch (the kv-split partials): with every
+// byte stored this way and drained before the ticket, the producer needs no agent-scope release fence, which costs
+// 2-6 us behind freshly written lines (MI355X_MICROARCH.md, visibility table; Guideline 16 R1)
+__device__ __forceinline__ void store16_sc1(float* base, int64_t elem_off, f32x4_t v) {
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, (int)(elem_off * 4), 0, 16);
+}
+
 // issue the 16 LDS-DMA instructions of one 32-key group into `stage` (wave-private)
 __device__ __forceinline__ void issue_group(const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
                                             char* stage, int64_t phys_block, int in_block_off,
@@ -117,8 +125,8 @@ template <int FUSED>
 __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
     const int32_t* __restrict__ context_lens, const int32_t* __restrict__ block_tables,
-    int64_t bt_stride, bf16_t* __restrict__ out, float* __restrict__ part_o,
-    float* __restrict__ part_ml, int nh, int nkv, int block_size, float scale_log2e,
+    int64_t bt_stride, bf16_t* __restrict__ out, float* part_o,
+    float* part_ml, unsigned* tickets, int nh, int nkv, int block_size, float scale_log2e,
     int num_splits, const PaFuse fu) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int split = blockIdx.x, kvh = blockIdx.y;
@@ -351,15 +359,78 @@ __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
                 for (int i = 0; i < 4; ++i) ov[i] = pack2bf(o[2 * i] * inv, o[2 * i + 1] * inv);
                 *reinterpret_cast<u32x4_t*>(out + (b * nh + head) * PA_HD + d0) = ov;
             } else {
-                float* po = part_o + ((b * nh + head) * num_splits + split) * PA_HD + d0;
+                const int64_t prow = (b * nh + head) * num_splits + split;
+                if (tickets != nullptr) {  // read by the last-arriving split of this launch: write-through stores
+                    store16_sc1(part_o, prow * PA_HD + d0, f32x4_t{o[0], o[1], o[2], o[3]});
+                    store16_sc1(part_o, prow * PA_HD + d0 + 4, f32x4_t{o[4], o[5], o[6], o[7]});
+                    if ((tid & 15) == 0) {
+                        const unsigned long long ml = (unsigned long long)__float_as_uint(M) |
+                                                      ((unsigned long long)__float_as_uint(L) << 32);
+                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(part_ml + prow * 2), ml,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else {
+                    float* po = part_o + prow * PA_HD + d0;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) po[i] = o[i];
-                if ((tid & 15) == 0) {
-                    float* pm = part_ml + ((b * nh + head) * num_splits + split) * 2;
-                    pm[0] = M;
-                    pm[1] = L;
+                    for (int i = 0; i < 8; ++i) po[i] = o[i];
+                    if ((tid & 15) == 0) {
+                        part_ml[prow * 2] = M;
+                        part_ml[prow * 2 + 1] = L;
+                    }
                 }
             }
+        }
+    }
+    if (num_splits == 1 || tickets == nullptr) return;
+
+    // ---- merge of the kv-splits by the LAST workgroup of this (sequence, kv-head) to finish (no second launch) ----
+    // Hand-off (cdna_hip_programming.md Guideline 16 R1, counter form): the partials were stored write-through (sc1);
+    // every wave drains its stores, the workgroup meets, one lane draws a ticket; the drawer of num_splits-1 acquires
+    // at agent scope, waits and puts the counter back to zero; only behind the next workgroup barrier do its waves
+    // read the other splits' partials.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem + PA_WAVES * PA_RING);  // the block-table slice is dead
+    if (tid == 0) {
+        unsigned* tk = tickets + b * nkv + kvh;
+        const unsigned got = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = got == (unsigned)num_splits - 1u;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        flag[0] = last;
+    }
+    __syncthreads();
+    if (!flag[0]) return;
+    {
+        // same arithmetic and summation order as paged_attn_reduce_kernel: thread (head h, 8 dims at d0)
+        const int h = tid >> 4, d0 = (tid & 15) * 8;
+        if (h < gq) {
+            const int64_t bh = b * nh + (int64_t)kvh * gq + h;
+            float M = -INFINITY;
+            for (int sp = 0; sp < num_splits; ++sp) M = fmaxf(M, part_ml[(bh * num_splits + sp) * 2]);
+            float L = 0.f, o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = 0.f;
+            for (int sp = 0; sp < num_splits; ++sp) {
+                const float m = part_ml[(bh * num_splits + sp) * 2];
+                const float f = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - M);
+                L += f * part_ml[(bh * num_splits + sp) * 2 + 1];
+                const float* po = part_o + (bh * num_splits + sp) * PA_HD + d0;
+                const f32x4_t a = *reinterpret_cast<const f32x4_t*>(po), c4 = *reinterpret_cast<const f32x4_t*>(po + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    o[i] += f * a[i];
+                    o[4 + i] += f * c4[i];
+                }
+            }
+            u32x4_t ov;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                ov[i] = pack2bf(L > 0.f ? o[2 * i] / L : 0.f, L > 0.f ? o[2 * i + 1] / L : 0.f);
+            *reinterpret_cast<u32x4_t*>(out + bh * PA_HD + d0) = ov;
         }
     }
 }
@@ -383,11 +454,16 @@ __global__ __launch_bounds__(128) void paged_attn_reduce_kernel(const float* __r
     out[bh * PA_HD + d] = f2bf(L > 0.f ? o / L : 0.f);
 }
 
+// the first PA_TICKET_BYTES of the workspace are arrival counters, one per (sequence, kv-head): zero before the first
+// launch on a workspace, put back to zero by the kernel
+constexpr size_t PA_TICKET_BYTES = 65536;
+
 int choose_splits(int64_t B, int nkv, int max_ctx) {
-    // aim for >= 256 workgroups (one per CU) without making a split shorter than 4 wave-steps
+    // aim for >= 256 workgroups (one per CU) without making a split shorter than one wave-step per wave (128 keys):
+    // at single-sequence decode the kernel is latency-bound, and ctx = 1024 over 2 splits kept 240 CUs idle (20.5 us)
     const int64_t base = B * nkv;
     int s = (int)((256 + base - 1) / base);
-    const int max_by_len = max_ctx > 0 ? (max_ctx + 4 * PA_GK * PA_WAVES - 1) / (4 * PA_GK * PA_WAVES) : 1;
+    const int max_by_len = max_ctx > 0 ? (max_ctx + PA_GK * PA_WAVES - 1) / (PA_GK * PA_WAVES) : 1;
     if (s > max_by_len) s = max_by_len;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
@@ -412,7 +488,7 @@ extern "C" int glm_paged_attn_decode_splits(int64_t B, int nkv, int block_size, 
 extern "C" size_t glm_paged_attn_decode_workspace_bytes(int64_t B, int nh, int hd, int num_splits) {
     const int s = num_splits <= 0 ? 64 : num_splits;
     if (s == 1) return 0;
-    return (size_t)B * nh * s * (hd + 2) * sizeof(float);
+    return PA_TICKET_BYTES + (size_t)B * nh * s * (hd + 2) * sizeof(float);
 }
 
 static int pa_launch(const void* q, const void* k_cache, const void* v_cache, const int32_t* context_lens,
@@ -431,12 +507,15 @@ static int pa_launch(const void* q, const void* k_cache, const void* v_cache, co
     const int splits = pa_effective_splits(B, nkv, block_size, bt_stride, num_splits, max_context_len);
     float* part_o = nullptr;
     float* part_ml = nullptr;
+    unsigned* tickets = nullptr;
     if (splits > 1) {
-        const size_t need = (size_t)B * nh * splits * (PA_HD + 2) * sizeof(float);
-        GLM_CHECK_ARG(workspace != nullptr && workspace_bytes >= need, GLM_ERR_WORKSPACE,
-                      "%s: workspace %zu < %zu bytes", name, workspace_bytes, need);
-        part_o = (float*)workspace;
+        const size_t need = PA_TICKET_BYTES + (size_t)B * nh * splits * (PA_HD + 2) * sizeof(float);
+        GLM_CHECK_ARG(workspace != nullptr && workspace_bytes >= need && glm_aligned16(workspace), GLM_ERR_WORKSPACE,
+                      "%s: workspace %zu < %zu bytes (or not 16-byte aligned)", name, workspace_bytes, need);
+        part_o = (float*)((char*)workspace + PA_TICKET_BYTES);
         part_ml = part_o + (size_t)B * nh * splits * PA_HD;
+        // in-kernel merge by the last-arriving split when the counters fit; else the separate reduce launch
+        if ((size_t)B * nkv * sizeof(unsigned) <= PA_TICKET_BYTES) tickets = (unsigned*)workspace;
     }
     static bool attr_set[2] = {false, false};
     const int fz = fuse != nullptr;
@@ -458,14 +537,14 @@ static int pa_launch(const void* q, const void* k_cache, const void* v_cache, co
         fu = *fuse;
         hipLaunchKernelGGL((paged_attn_decode_kernel<1>), grid, dim3(256), PA_LDS, st, (const bf16_t*)nullptr,
                            (const bf16_t*)k_cache, (const bf16_t*)v_cache, context_lens, block_tables, bt_stride,
-                           (bf16_t*)out, part_o, part_ml, nh, nkv, block_size, scale_log2e, splits, fu);
+                           (bf16_t*)out, part_o, part_ml, tickets, nh, nkv, block_size, scale_log2e, splits, fu);
     } else {
         hipLaunchKernelGGL((paged_attn_decode_kernel<0>), grid, dim3(256), PA_LDS, st, (const bf16_t*)q,
                            (const bf16_t*)k_cache, (const bf16_t*)v_cache, context_lens, block_tables, bt_stride,
-                           (bf16_t*)out, part_o, part_ml, nh, nkv, block_size, scale_log2e, splits, fu);
+                           (bf16_t*)out, part_o, part_ml, tickets, nh, nkv, block_size, scale_log2e, splits, fu);
     }
     GLM_CHECK_LAUNCH(name);
-    if (splits > 1) {
+    if (splits > 1 && tickets == nullptr) {
         hipLaunchKernelGGL(paged_attn_reduce_kernel, dim3((unsigned)(B * nh)), dim3(128), 0, st, part_o,
                            part_ml, (bf16_t*)out, splits);
         GLM_CHECK_LAUNCH(name);

@@ -273,7 +273,7 @@ def _attn_workspace(device, need: int) -> torch.Tensor | None:
     if ws is None or ws.numel() < need:
         if ws is not None:
             _attn_ws_retired.append(ws)
-        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        ws = torch.zeros(need, dtype=torch.uint8, device=device)  # zeros: the head of it holds arrival counters
         _attn_ws[key] = ws
     return ws
 

@@ -98,7 +98,9 @@ int glm_silu_and_mul(const void* x, void* y, int64_t T, int I, glm_stream_t stre
  *     sequence over a paged KV cache.
  *     q: [B,nh,hd] contiguous; caches: [n_blocks, block_size, nkv, hd]; context_lens int32[B]
  *     (0 ⇒ zero output row); block_tables int32 [B, bt_stride] (-1 padded); out [B,nh,hd].
- *     workspace: glm_paged_attn_decode_workspace_bytes() bytes (may be NULL when that is 0).
+ *     workspace: glm_paged_attn_decode_workspace_bytes() bytes (may be NULL when that is 0), 16-byte aligned.  Its
+ *     first 64 KiB are the arrival counters of the split merge (done by the last split to finish, in the same
+ *     launch): they must be ZERO before the first launch on a workspace; the kernel puts the zeros back.
  *     num_splits: 0 = choose; ≥1 = forced number of KV splits per (sequence, kv-head).
  *     glm_paged_attn_decode_splits() = the split count a launch with these arguments uses (1 ⇒ no workspace is
  *     read); size the workspace with THAT count — workspace_bytes(…, 0) is the worst case (64 splits).        */

@@ -46,7 +46,8 @@ def test_host_only_entry_points(lib_path):
     from nanovllm import hip_ops
     lib = hip_ops.load_library(lib_path)
     assert lib.glm_paged_attn_decode_workspace_bytes(32, 96, 128, 1) == 0
-    assert lib.glm_paged_attn_decode_workspace_bytes(2, 8, 128, 4) == 2 * 8 * 4 * 130 * 4
+    assert lib.glm_paged_attn_decode_workspace_bytes(2, 8, 128, 4) == 65536 + 2 * 8 * 4 * 130 * 4
+    assert lib.glm_paged_attn_decode_splits(32, 8, 256, 16, 0, 4096) == 1 and lib.glm_paged_attn_decode_splits(1, 8, 256, 4, 0, 1024) == 8
     # argument validation happens before any launch: usable without a GPU
     rc = lib.glm_rmsnorm(None, None, None, 4, 128, 1e-5, None)
     assert rc == -1 and b"null pointer" in lib.glm_last_error()

@@ -17,7 +17,7 @@ names = {  # kernel-name pattern -> bench.py kernel key
     r"gemm_smallm_dma_kernel<1,": "grouped_gemm_gateup_silu",
     r"gemm_smallm_dma_kernel<2,": "grouped_gemm_down",
     r"gemm_smallm_dma_kernel<0, 2, 1, 2, 2": "gemm_qkv",  # lm_head shares the config; the median over launches is QKV
-    r"gemm_smallm_dma_kernel<0, 4, 1, 2, 2": "gemm_o",
+    r"gemm_smallm_dma_kernel<0, 2, 1, 4, 2": "gemm_o",
     r"paged_attn_decode_kernel": "paged_attn_decode",
     r"gemm_largem_kernel<1,": "grouped_gemm_gateup_silu@prefill16k",
     r"gemm_largem_kernel<2,": "grouped_gemm_down@prefill16k",
@@ -37,7 +37,13 @@ for key, d in vals.items():
                 "hbm_bytes_corrected": int((2 * fk + wk) * 1024),
                 "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16 B/lane streaming reads -> x2 "
                               "(MI355X_MICROARCH.md HBM); WRITE_SIZE exact; KB*1024"}
+import sys
+sys.path.insert(0, "$R")
+import bench
+out["_meta"] = {"kernel_source_digest": bench._kernel_source_digest(), "git_head": bench._git("rev-parse", "--short", "HEAD"),
+                "command": "bench.py --layers 3 --steps 2 --warmup 1 --no-graph --no-cpu-baseline --kernel-iters 12",
+                "passes": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace", "rocprofv3 --pmc WRITE_SIZE --kernel-trace"]}
 json.dump(out, open("$R/gpurun_out/pmc_traffic.json", "w"), indent=1)
 for k, v in out.items():
-    print(f"{k:40s} {v['hbm_bytes_corrected']/1e6:10.1f} MB  ({v['launches']} launches)")
+    if k != "_meta": print(f"{k:40s} {v['hbm_bytes_corrected']/1e6:10.1f} MB  ({v['launches']} launches)")
 PY
