@@ -366,10 +366,15 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(
 // p0 < p1 < ... = the token's routed rows in ascending expert id (sorted rows ascend with id).
 constexpr int COMBINE_MAX_K = 64;
 
+// row_scale != nullptr (expert-parallel combine): the rows are the experts' UNSCALED bf16 outputs as they came back
+// from their owners, and the routing weight is applied here with the down projection's own rounding,
+// bf16(bf16(acc) * w) (moe.py:149); shared != nullptr: the shared expert's rows live in their own [T, H] buffer.
 __global__ __launch_bounds__(256) void moe_combine_kernel(const bf16_t* __restrict__ y, int64_t ldy,
                                                           const int32_t* __restrict__ pair_pos,
                                                           bf16_t* __restrict__ out, int k, int H,
-                                                          int64_t shared_base, int vec_ok) {
+                                                          int64_t shared_base, int vec_ok,
+                                                          const bf16_t* __restrict__ row_scale,
+                                                          const bf16_t* __restrict__ shared, int64_t ld_shared) {
     // grid = (token, column slab): a token's row is split over gridDim.y workgroups so that a
     // decode batch (32 tokens) still spreads over the chip; every workgroup re-derives the sorted
     // row list (k <= 64 integers) on its own.
@@ -400,14 +405,24 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const bf16_t* __restri
             for (int i = 0; i < 8; ++i) acc[i] = 0.f;
             for (int j = 0; j < n; ++j) {
                 const u32x4_t v = reinterpret_cast<const u32x4_t*>(y + (int64_t)pos[j] * ldy)[c];
+                if (row_scale) {
+                    const float sc = bf2f(row_scale[pos[j]]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[2 * q] = rbf(acc[2 * q] + rbf(bflo(v[q]) * sc));
+                        acc[2 * q + 1] = rbf(acc[2 * q + 1] + rbf(bfhi(v[q]) * sc));
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     acc[2 * q] = rbf(acc[2 * q] + bflo(v[q]));
                     acc[2 * q + 1] = rbf(acc[2 * q + 1] + bfhi(v[q]));
                 }
             }
-            if (shared_base >= 0) {
-                const u32x4_t v = reinterpret_cast<const u32x4_t*>(y + (shared_base + t) * ldy)[c];
+            if (shared_base >= 0 || shared) {
+                const u32x4_t v = shared ? reinterpret_cast<const u32x4_t*>(shared + t * ld_shared)[c]
+                                         : reinterpret_cast<const u32x4_t*>(y + (shared_base + t) * ldy)[c];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     acc[2 * q] = acc[2 * q] + bflo(v[q]);
@@ -422,8 +437,13 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const bf16_t* __restri
     } else {
         for (int c = blockIdx.y * 256 + threadIdx.x; c < H; c += gridDim.y * 256) {
             float acc = 0.f;
-            for (int j = 0; j < n; ++j) acc = rbf(acc + bf2f(y[(int64_t)pos[j] * ldy + c]));
-            if (shared_base >= 0) acc = acc + bf2f(y[(shared_base + t) * ldy + c]);
+            for (int j = 0; j < n; ++j) {
+                float v = bf2f(y[(int64_t)pos[j] * ldy + c]);
+                if (row_scale) v = rbf(v * bf2f(row_scale[pos[j]]));
+                acc = rbf(acc + v);
+            }
+            if (shared) acc = acc + bf2f(shared[t * ld_shared + c]);
+            else if (shared_base >= 0) acc = acc + bf2f(y[(shared_base + t) * ldy + c]);
             out[t * H + c] = f2bf(acc);
         }
     }
@@ -660,9 +680,78 @@ extern "C" int glm_moe_combine(const void* y, int64_t ldy, const int32_t* pair_p
     while (slabs > 1 && (int64_t)T * slabs > 2048) slabs = (slabs + 1) / 2;  // enough WGs already
     GLM_CHECK_ARG(T <= 0x7fffffff, GLM_ERR_UNSUPPORTED, "glm_moe_combine: T too large");
     hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned)T, (unsigned)slabs), dim3(256), 0, glm_s(stream),
-                       (const bf16_t*)y, ldy, pair_pos, (bf16_t*)out, k, H, shared_base, vec_ok);
+                       (const bf16_t*)y, ldy, pair_pos, (bf16_t*)out, k, H, shared_base, vec_ok, (const bf16_t*)nullptr,
+                       (const bf16_t*)nullptr, (int64_t)0);
     GLM_CHECK_LAUNCH("glm_moe_combine");
     return GLM_OK;
+}
+
+extern "C" int glm_moe_combine_scaled(const void* y, int64_t ldy, const int32_t* pair_pos, const void* row_scale,
+                                      const void* shared_rows, int64_t ld_shared, void* out, int64_t T, int k, int H,
+                                      glm_stream_t stream) {
+    GLM_CHECK_ARG(y && pair_pos && row_scale && out, GLM_ERR_INVALID, "glm_moe_combine_scaled: null pointer");
+    GLM_CHECK_ARG(T >= 0 && k > 0 && H > 0 && ldy >= H && (shared_rows == nullptr || ld_shared >= H), GLM_ERR_INVALID,
+                  "glm_moe_combine_scaled: bad shape");
+    GLM_CHECK_ARG(k <= COMBINE_MAX_K && T <= 0x7fffffff, GLM_ERR_UNSUPPORTED, "glm_moe_combine_scaled: k > %d", COMBINE_MAX_K);
+    if (T == 0) return GLM_OK;
+    const int vec_ok = H % 8 == 0 && ldy % 8 == 0 && glm_aligned16(y) && glm_aligned16(out) &&
+                       (shared_rows == nullptr || (ld_shared % 8 == 0 && glm_aligned16(shared_rows)));
+    const int work = vec_ok ? H / 8 : H;
+    int slabs = (work + 255) / 256;
+    while (slabs > 1 && (int64_t)T * slabs > 2048) slabs = (slabs + 1) / 2;
+    hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned)T, (unsigned)slabs), dim3(256), 0, glm_s(stream),
+                       (const bf16_t*)y, ldy, pair_pos, (bf16_t*)out, k, H, (int64_t)-1, vec_ok, (const bf16_t*)row_scale,
+                       (const bf16_t*)shared_rows, ld_shared);
+    GLM_CHECK_LAUNCH("glm_moe_combine_scaled");
+    return GLM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Row pack / unpack of the expert-parallel dispatch: dst[i] = src[idx[i]] (gather) or dst[idx[i]] = src[i] (scatter),
+// rows of `cols` bf16 (16-byte vectors when everything is aligned); idx < 0 skips the row.
+namespace {
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void permute_rows_kernel(const bf16_t* __restrict__ src, int64_t ld_src,
+                                                           bf16_t* __restrict__ dst, int64_t ld_dst,
+                                                           const int32_t* __restrict__ idx, int cols, int vec_ok) {
+    const int64_t i = blockIdx.x;
+    const int64_t j = idx[i];
+    if (j < 0) return;
+    const bf16_t* s = src + (SCATTER ? i : j) * ld_src;
+    bf16_t* d = dst + (SCATTER ? j : i) * ld_dst;
+    if (vec_ok) {
+        for (int c = threadIdx.x; c < (cols >> 3); c += 256)
+            reinterpret_cast<u32x4_t*>(d)[c] = reinterpret_cast<const u32x4_t*>(s)[c];
+    } else {
+        for (int c = threadIdx.x; c < cols; c += 256) d[c] = s[c];
+    }
+}
+}  // namespace
+
+static int permute_rows(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, const int32_t* idx, int64_t n,
+                        int cols, bool scatter, glm_stream_t stream, const char* name) {
+    GLM_CHECK_ARG(src && dst && idx, GLM_ERR_INVALID, "%s: null pointer", name);
+    GLM_CHECK_ARG(n >= 0 && cols > 0 && ld_src >= cols && ld_dst >= cols && n <= 0x7fffffff, GLM_ERR_INVALID,
+                  "%s: bad shape", name);
+    if (n == 0) return GLM_OK;
+    const int vec_ok = cols % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && glm_aligned16(src) && glm_aligned16(dst);
+    if (scatter)
+        hipLaunchKernelGGL(permute_rows_kernel<true>, dim3((unsigned)n), dim3(256), 0, glm_s(stream), (const bf16_t*)src,
+                           ld_src, (bf16_t*)dst, ld_dst, idx, cols, vec_ok);
+    else
+        hipLaunchKernelGGL(permute_rows_kernel<false>, dim3((unsigned)n), dim3(256), 0, glm_s(stream), (const bf16_t*)src,
+                           ld_src, (bf16_t*)dst, ld_dst, idx, cols, vec_ok);
+    GLM_CHECK_LAUNCH(name);
+    return GLM_OK;
+}
+
+extern "C" int glm_gather_rows(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, const int32_t* idx, int64_t n,
+                               int cols, glm_stream_t stream) {
+    return permute_rows(src, ld_src, dst, ld_dst, idx, n, cols, false, stream, "glm_gather_rows");
+}
+extern "C" int glm_scatter_rows(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, const int32_t* idx, int64_t n,
+                                int cols, glm_stream_t stream) {
+    return permute_rows(src, ld_src, dst, ld_dst, idx, n, cols, true, stream, "glm_scatter_rows");
 }
 
 extern "C" int glm_moe_combine_add_rmsnorm(const void* y, int64_t ldy, const int32_t* pair_pos, int64_t T, int k, int H,

@@ -1,0 +1,169 @@
+"""Expert parallelism for the GLM-4-MoE block (BASELINE config 4: TP=8 over xGMI with expert-parallel all-to-all).
+
+No reference counterpart runs: the reference has no all-to-all call site, only dead `dispatch` / `combine` stubs
+(distributed/parallel_state_ref.py:792-810).  Parity is therefore defined as "EP = k output == TP = 1 output"
+(SURVEY.md §8e): the routing, every expert row and the combine order (ascending expert id, one bf16 rounding per add,
+moe.py:133-171) are the ones of the single-GPU path; only WHERE a row is computed changes.
+
+Layout, ep ranks (= the TP group):
+  * rank r owns the routed experts [r*E/ep, (r+1)*E/ep) with their FULL intermediate size (not TP-sharded) and a replica
+    of the shared expert;
+  * the hidden states are replicated after the attention's all-reduce; rank r takes the token slice
+    [r*ceil(T/ep), ...), and for its tokens
+      1. buckets its (token, expert) pairs by expert (glm_moe_align — expert order is also destination-rank order) and
+         packs the rows (glm_gather_rows);
+      2. all-gathers the per-expert pair counts (E int32 per rank), all-to-all-v's the rows to the experts' owners;
+      3. the owner runs its experts over the rows it received, grouped by expert through a gather index
+         (glm_grouped_gemm_gateup_silu / glm_grouped_gemm_down, unscaled), un-permutes them (glm_scatter_rows) and
+         all-to-all-v's them back;
+      4. the source applies the routing weights and combines in ascending expert id (glm_moe_combine_scaled) and adds
+         its shared-expert rows; the slices are all-gathered so that every rank has [T, H] again for the next
+         (tensor-parallel) attention.
+  xGMI is point-to-point: at B=256, k=8 a rank sends 256 pairs x 8 KiB = 2 MiB spread over 7 peers — one hop, all links.
+
+The forward is written as a GENERATOR that yields at every collective.  `run` drives it with torch.distributed (RCCL,
+or gloo in the CPU tests); `run_emulated` drives the generators of several logical ranks in lockstep inside one process
+(the one-GPU rehearsal and the "EP=2 == TP=1" test).  The split sizes of the all-to-all-v are host integers, so this
+path syncs once per MoE block and runs eagerly; a graph-capturable fixed-capacity variant is future work.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def token_slice(T: int, ep: int, rank: int) -> tuple[int, int]:
+    per = (T + ep - 1) // ep
+    lo = min(T, rank * per)
+    return lo, min(T, lo + per)
+
+
+class EPExperts:
+    """One rank's side of the expert-parallel MoE block.  `ops` is nanovllm.hip_ops (the CPU tests inject a stand-in
+    with the reference arithmetic on CPU tensors); `w13`, `w2` are this rank's [E/ep, 2I, H] / [E/ep, H, I] stacks, `shared` a callable
+    for the (replicated) shared expert."""
+
+    def __init__(self, ops, ep_size: int, rank: int, n_experts: int, top_k: int, w13, w2, shared):
+        assert n_experts % ep_size == 0, "experts must divide over the expert-parallel ranks"
+        self.ops, self.ep, self.rank, self.E, self.k = ops, ep_size, rank, n_experts, top_k
+        self.El = n_experts // ep_size
+        self.w13, self.w2, self.shared = w13, w2, shared
+
+    def forward(self, h: torch.Tensor, topk_idx: torch.Tensor, topk_w: torch.Tensor):
+        """Generator.  h [T, H] (replicated), routing of ALL T tokens (replicated, identical on every rank).
+        Yields (op, payload...) tuples at the collectives, finally returns the full [T, H] output."""
+        ops, ep, E, El, k = self.ops, self.ep, self.E, self.El, self.k
+        T, H = h.shape
+        lo, hi = token_slice(T, ep, self.rank)
+        Tl = hi - lo
+        hl, idx, w = h[lo:hi], topk_idx[lo:hi].contiguous(), topk_w[lo:hi].contiguous()
+        # 1. bucket + pack this rank's pairs (rows sorted by expert id == sorted by destination rank)
+        if Tl > 0:
+            offs, tok, scale, pos = ops.moe_align(idx, w, E, False)
+            send = ops.gather_rows(hl, tok)
+            counts = (offs[1:E + 1] - offs[:E]).to(torch.int32)
+        else:
+            offs = tok = scale = pos = None
+            send = h.new_zeros((0, H))
+            counts = torch.zeros(E, dtype=torch.int32, device=h.device)
+        # 2. who sends how many rows to which expert: [ep, E] on every rank (one small all-gather, then ONE host read)
+        all_counts = (yield ("all_gather", counts)).view(ep, E).cpu()
+        mine = all_counts[:, self.rank * El:(self.rank + 1) * El]            # [src, local expert]
+        in_splits = all_counts[self.rank].view(ep, El).sum(1).tolist()       # rows I send to each rank
+        out_splits = mine.sum(1).tolist()                                    # rows I receive from each rank
+        recv = yield ("all_to_all", send, in_splits, out_splits)
+        # 3. my experts over the received rows.  They arrive grouped by source, each block sorted by local expert:
+        #    row index of (src, e) blocks -> gather list in expert order
+        n_recv = int(sum(out_splits))
+        if n_recv > 0:
+            src_base = torch.tensor([0] + out_splits[:-1]).cumsum(0)          # first row of each source block
+            within = torch.cat([torch.zeros(ep, 1, dtype=torch.long), mine.long().cumsum(1)[:, :-1]], dim=1)
+            order = [torch.arange(int(mine[s, e])) + int(src_base[s]) + int(within[s, e])
+                     for e in range(El) for s in range(ep)]
+            gidx = torch.cat(order).to(torch.int32).to(h.device)
+            loffs = torch.cat([torch.zeros(1, dtype=torch.long), mine.long().sum(0).cumsum(0)]).to(torch.int32).to(h.device)
+            act = ops.grouped_gemm_gateup_silu(recv, self.w13, loffs, gidx, n_recv)
+            y = ops.grouped_gemm_down(act, self.w2, loffs, None, 0)           # unscaled: the weight is applied at home
+            back = ops.scatter_rows(y, gidx, n_recv)                          # expert order -> arrival order
+        else:
+            back = h.new_zeros((0, H))
+        ret = yield ("all_to_all", back, out_splits, in_splits)
+        # 4. routing weights, ascending-expert combine, shared expert; then everyone gets every slice
+        if Tl > 0:
+            out_l = ops.moe_combine_scaled(ret, pos, scale, self.shared(hl), Tl, k)
+        else:
+            out_l = h.new_zeros((0, H))
+        sizes = [token_slice(T, ep, r)[1] - token_slice(T, ep, r)[0] for r in range(ep)]
+        out = yield ("all_gather_rows", out_l, sizes)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def run(gen, group=None):
+    """Drive one rank's generator with torch.distributed collectives."""
+    try:
+        req = next(gen)
+        while True:
+            op = req[0]
+            if op == "all_gather":
+                t = req[1]
+                outl = torch.empty(dist.get_world_size(group) * t.numel(), dtype=t.dtype, device=t.device)
+                dist.all_gather_into_tensor(outl, t.contiguous(), group=group)
+                res = outl
+            elif op == "all_to_all":
+                _, t, in_splits, out_splits = req
+                res = torch.empty((int(sum(out_splits)), t.shape[1]), dtype=t.dtype, device=t.device)
+                dist.all_to_all_single(res, t.contiguous(), out_splits, in_splits, group=group)
+            elif op == "all_gather_rows":
+                _, t, sizes = req
+                per, world = max(sizes), len(sizes)  # slices are equal except the last: pad to one fixed-size gather
+                padded = t if t.shape[0] == per else torch.cat([t, t.new_zeros((per - t.shape[0], t.shape[1]))])
+                buf = torch.empty((world * per, t.shape[1]), dtype=t.dtype, device=t.device)
+                dist.all_gather_into_tensor(buf, padded.contiguous(), group=group)
+                res = torch.cat([buf[r * per:r * per + n] for r, n in enumerate(sizes)], dim=0)
+            else:  # pragma: no cover
+                raise RuntimeError(f"unknown collective {op}")
+            req = gen.send(res)
+    except StopIteration as e:
+        return e.value
+
+
+def run_emulated(gens: list):
+    """Drive the generators of all logical ranks in lockstep inside ONE process (same collectives, done by copies)."""
+    n = len(gens)
+    reqs = [next(g) for g in gens]
+    results = [None] * n
+    done = 0
+    while done < n:
+        op = reqs[0][0]
+        assert all(r[0] == op for r in reqs), "ranks diverged"
+        if op == "all_gather":
+            cat = torch.cat([r[1].reshape(-1) for r in reqs])
+            res = [cat.clone() for _ in range(n)]
+        elif op == "all_to_all":
+            res = []
+            for dst in range(n):
+                pieces = []
+                for src in range(n):
+                    t, in_splits = reqs[src][1], reqs[src][2]
+                    start = sum(in_splits[:dst])
+                    pieces.append(t[start:start + in_splits[dst]])
+                    assert in_splits[dst] == reqs[dst][3][src], "split bookkeeping disagrees between ranks"
+                res.append(torch.cat(pieces, dim=0))
+        elif op == "all_gather_rows":
+            cat = torch.cat([r[1] for r in reqs], dim=0)
+            res = [cat.clone() for _ in range(n)]
+        else:  # pragma: no cover
+            raise RuntimeError(f"unknown collective {op}")
+        nxt = []
+        for i, g in enumerate(gens):
+            try:
+                nxt.append(g.send(res[i]))
+            except StopIteration as e:
+                results[i] = e.value
+                done += 1
+                nxt.append(None)
+        reqs = nxt
+        if done and done < n:
+            raise RuntimeError("ranks finished at different collectives")
+    return results

@@ -43,5 +43,28 @@ def set_tp_group(group) -> None:
     _TP_GROUP = TPGroup(group)
 
 
+class _SingleRank:
+    """What the reference's stub always answers (parallel_state.py:1-9): used while building modules that must NOT be
+    tensor-parallel although the process group is (the experts of an expert-parallel MoE block)."""
+    world_size, rank = 1, 0
+
+    def all_reduce(self, t):
+        return t
+
+
+class unsharded:
+    """Context manager: modules constructed inside see a single-rank TP group (their linears keep full shapes)."""
+
+    def __enter__(self):
+        global _TP_GROUP
+        self._saved = _TP_GROUP
+        _TP_GROUP = _SingleRank()
+
+    def __exit__(self, *exc):
+        global _TP_GROUP
+        _TP_GROUP = self._saved
+        return False
+
+
 def tensor_model_parallel_all_reduce(t: torch.Tensor) -> torch.Tensor:
     return get_tp_group().all_reduce(t)

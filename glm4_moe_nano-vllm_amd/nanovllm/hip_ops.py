@@ -78,6 +78,10 @@ _SIGNATURES = {
                                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                                   c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                                   c_int, c_void_p, c_void_p]),
+    "glm_gather_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
+    "glm_scatter_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
+    "glm_moe_combine_scaled": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,
+                                       c_int, c_void_p]),
     "glm_moe_combine_add_rmsnorm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p,
                                             c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "glm_add_rmsnorm_partial": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -525,6 +529,39 @@ def moe_combine(y, pair_pos, T: int, k: int, shared_base: int) -> torch.Tensor:
     out = torch.empty((T, H), dtype=y.dtype, device=y.device)
     _check(load_library().glm_moe_combine(_p(y), y.stride(0), _p(pair_pos), _p(out), T, k, H,
                                           shared_base, _stream()), "glm_moe_combine")
+    return out
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """dst[i] = src[idx[i]] (rows of bf16; idx int32)."""
+    _bf16(src, "src")
+    assert src.dim() == 2 and idx.dtype == torch.int32 and idx.is_contiguous()
+    dst = torch.empty((idx.numel(), src.shape[1]), dtype=src.dtype, device=src.device)
+    _check(load_library().glm_gather_rows(_p(src), src.stride(0), _p(dst), dst.stride(0), _p(idx), idx.numel(),
+                                          src.shape[1], _stream()), "glm_gather_rows")
+    return dst
+
+
+def scatter_rows(src: torch.Tensor, idx: torch.Tensor, n_rows: int | None = None) -> torch.Tensor:
+    """dst[idx[i]] = src[i]; rows of dst no index points at stay zero."""
+    _bf16(src, "src")
+    assert src.dim() == 2 and idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == src.shape[0]
+    dst = torch.zeros((n_rows if n_rows is not None else src.shape[0], src.shape[1]), dtype=src.dtype, device=src.device)
+    _check(load_library().glm_scatter_rows(_p(src), src.stride(0), _p(dst), dst.stride(0), _p(idx), idx.numel(),
+                                           src.shape[1], _stream()), "glm_scatter_rows")
+    return dst
+
+
+def moe_combine_scaled(y, pair_pos, row_scale, shared_rows, T: int, k: int) -> torch.Tensor:
+    """Expert-parallel combine: routing weight applied here to the unscaled rows, ascending-expert bf16 adds, + shared."""
+    _bf16(y, "y"); _bf16(row_scale, "row_scale")
+    H = y.shape[1]
+    out = torch.empty((T, H), dtype=y.dtype, device=y.device)
+    if shared_rows is not None:
+        _bf16(shared_rows, "shared_rows")
+    _check(load_library().glm_moe_combine_scaled(_p(y), y.stride(0), _p(pair_pos), _p(row_scale), _p(shared_rows),
+                                                 shared_rows.stride(0) if shared_rows is not None else 0, _p(out), T, k,
+                                                 H, _stream()), "glm_moe_combine_scaled")
     return out
 
 

@@ -14,7 +14,8 @@ import torch
 import torch.nn as nn
 
 from nanovllm import hip_ops
-from nanovllm.distributed.parallel_state import get_tp_group
+from nanovllm.distributed import expert_parallel as EP
+from nanovllm.distributed.parallel_state import get_tp_group, unsharded
 from nanovllm.utils.loader import load_prefixed
 from .mlp import Glm4MoeMLP
 
@@ -51,9 +52,24 @@ class Glm4MoeMoE(nn.Module):
         mk = lambda: Glm4MoeMLP(hidden_size=config.hidden_size,
                                 intermediate_size=config.moe_intermediate_size,
                                 hidden_act=config.hidden_act, reduce_results=False)
-        self.experts = nn.ModuleList([mk() for _ in range(config.n_routed_experts)])
+        # N3 expert parallelism (`config.expert_parallel_size` = TP world size, BASELINE config 4): this rank builds
+        # only ITS experts, with their full intermediate size, plus a replica of the shared expert; `experts[i]` is
+        # then the expert with global id expert_ids[i] (distributed/expert_parallel.py)
+        self.ep_size = int(getattr(config, "expert_parallel_size", 1) or 1)
+        E = config.n_routed_experts
+        if self.ep_size > 1:
+            tp = get_tp_group()
+            assert self.ep_size == tp.world_size, "expert_parallel_size must equal the tensor-parallel world size"
+            assert E % self.ep_size == 0, "n_routed_experts must divide over the expert-parallel ranks"
+            self.expert_ids = list(range(tp.rank * (E // self.ep_size), (tp.rank + 1) * (E // self.ep_size)))
+            with unsharded():
+                self.experts = nn.ModuleList([mk() for _ in self.expert_ids])
+                self.shared_experts = mk()
+        else:
+            self.expert_ids = list(range(E))
+            self.experts = nn.ModuleList([mk() for _ in range(E)])
+            self.shared_experts = mk()
         self.gate = GlmMoeSelectTopk(config)
-        self.shared_experts = mk()
         self._w13 = None
         self._w2 = None
         self._stack(copy=False)
@@ -102,9 +118,16 @@ class Glm4MoeMoE(nn.Module):
         if f"{prefix}.gate.e_score_correction_bias" in sd:
             self.gate.e_score_correction_bias.copy_(sd[f"{prefix}.gate.e_score_correction_bias"])
         self._stacked()
-        for i, expert in enumerate(self.experts):
-            expert.load_weights(path, f"{prefix}.experts.{i}")
+        for expert, gid in zip(self.experts, self.expert_ids):
+            expert.load_weights(path, f"{prefix}.experts.{gid}")
         self.shared_experts.load_weights(path, f"{prefix}.shared_experts")
+
+    def _ep_experts(self, ops=hip_ops, rank: int | None = None):
+        w13, w2 = self._stacked()
+        El = len(self.experts)
+        return EP.EPExperts(ops, self.ep_size, get_tp_group().rank if rank is None else rank,
+                            self.config.n_routed_experts, self.config.num_experts_per_tok, w13[:El], w2[:El],
+                            self.shared_experts)
 
     # ---- forward ------------------------------------------------------------------------
     def forward(self, hidden_states: torch.Tensor, routing=None, defer_combine: bool = False, aligned=None):
@@ -118,6 +141,8 @@ class Glm4MoeMoE(nn.Module):
         E, k = self.config.n_routed_experts, self.config.num_experts_per_tok
         w13, w2 = self._stacked()
         topk_idx, topk_w = self.gate(h, precomputed=routing)
+        if self.ep_size > 1:
+            return EP.run(self._ep_experts().forward(h, topk_idx, topk_w)).view(shape)
         offs, tok, scale, pos = aligned if aligned is not None else hip_ops.moe_align(topk_idx, topk_w, E, True)
         R = T * k + T
         if self.expert_weight_dtype == "fp8_e4m3":

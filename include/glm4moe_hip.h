@@ -253,6 +253,20 @@ int glm_paged_attn_decode_qkv(const void* qkv, int64_t qkv_stride, const int64_t
                               int num_splits, int max_context_len, void* workspace,
                               size_t workspace_bytes, glm_stream_t stream);
 
+/* N3  expert-parallel dispatch / combine (BASELINE config 4; no reference counterpart: parallel_state_ref.py:792-810
+ *     only has dead dispatch/combine stubs).  Row pack / unpack around the all-to-all: gather dst[i] = src[idx[i]],
+ *     scatter dst[idx[i]] = src[i] (rows of `cols` bf16; idx < 0 skips).  glm_moe_combine_scaled = glm_moe_combine on
+ *     the UNSCALED expert rows that came back from their owners: out[t] = sum over the token's rows in ascending
+ *     expert id of bf16(y[row] * row_scale[row]) (one bf16 rounding per add, moe.py:149-151), then + shared_rows[t]
+ *     (moe.py:171) when given.                                                                                      */
+int glm_gather_rows(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, const int32_t* idx, int64_t n, int cols,
+                    glm_stream_t stream);
+int glm_scatter_rows(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, const int32_t* idx, int64_t n, int cols,
+                     glm_stream_t stream);
+int glm_moe_combine_scaled(const void* y, int64_t ldy, const int32_t* pair_pos, const void* row_scale,
+                           const void* shared_rows, int64_t ld_shared, void* out, int64_t T, int k, int H,
+                           glm_stream_t stream);
+
 /* Tuning studies only (tools/largem_ab.py): kernel variant of the LDS-tiled large-M GEMM for the next launches of this
  * process — a bit set of lean load phase (1), 16-byte epilogue stores (2), … (csrc/gemm_largem.hip); < 0 restores the
  * default.  Every variant that stores results is bit-identical to variant 0.  Returns the previous value.          */

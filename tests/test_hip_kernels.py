@@ -620,3 +620,64 @@ def test_moe_block_fp8_weights(ops, T, E, k, H, I):
     ref_bf16 = O.moe(x, None, None, k, 1.0, w13[:E], w2[:E], w13[E], w2[E], topk=(idx, w))
     rel = float((ref.float() - ref_bf16.float()).norm() / ref_bf16.float().norm())
     assert rel < 0.08, f"fp8 quantisation error {rel:.3f}"
+
+
+# ------------------------------------------------------------------------------------------
+# N3: expert-parallel dispatch / combine pieces
+def test_row_gather_scatter(ops):
+    for n_src, cols in ((37, 4096), (5, 100), (64, 1408)):
+        src = rnd(n_src, cols, seed=n_src)
+        g = torch.Generator().manual_seed(cols)
+        idx = torch.randint(0, n_src, (91,), generator=g).to(torch.int32)
+        assert torch.equal(ops.gather_rows(dev(src), dev(idx)).cpu(), src[idx.long()])
+        perm = torch.randperm(n_src, generator=g).to(torch.int32)
+        out = ops.scatter_rows(dev(src), dev(perm)).cpu()
+        exp = torch.zeros_like(src)
+        exp[perm.long()] = src
+        assert torch.equal(out, exp)
+    idx = torch.tensor([3, -1, 0], dtype=torch.int32)  # -1 skips
+    out = ops.scatter_rows(dev(rnd(3, 64, seed=1)), dev(idx), 5).cpu()
+    assert float(out[1].float().abs().max()) == 0 and float(out[2].float().abs().max()) == 0
+
+
+@pytest.mark.parametrize("T,k,H", [(9, 4, 256), (32, 8, 4096), (3, 2, 100)])
+def test_moe_combine_scaled_equals_scaled_rows_combine(ops, T, k, H):
+    """Routing weight applied at combine time (expert-parallel path) == weight applied by the down projection's
+    epilogue followed by the plain combine, bit for bit; shared rows from their own buffer."""
+    P = T * k
+    y = rnd(P, H, seed=201, scale=2.0)
+    sc = (torch.rand(P, generator=torch.Generator().manual_seed(202)) + 0.1).to(BF)
+    sh = rnd(T, H, seed=203)
+    pos = torch.randperm(P, generator=torch.Generator().manual_seed(204)).view(T, k).to(torch.int32)
+    got = ops.moe_combine_scaled(dev(y), dev(pos.flatten().contiguous()), dev(sc), dev(sh), T, k).cpu()
+    ys = torch.cat([y * sc.unsqueeze(-1), sh])  # bf16 multiply = bf16(bf16(acc) * w)
+    exp = ops.moe_combine(dev(ys), dev(pos.flatten().contiguous()), T, k, P).cpu()
+    assert torch.equal(got, exp)
+
+
+@pytest.mark.parametrize("ep,T,E,k,H,I", [(2, 32, 8, 2, 512, 128), (4, 37, 16, 4, 256, 192), (8, 5, 64, 8, 4096, 1408),
+                                          (2, 1, 4, 2, 256, 64)])
+def test_expert_parallel_emulated_equals_single_gpu(ops, ep, T, E, k, H, I):
+    """EP = ep logical ranks on ONE device (same code, collectives done by copies) == the TP = 1 kernels' result bit for
+    bit: a row's value does not depend on which rank's grouped GEMM computed it nor on its position in the group."""
+    from nanovllm.distributed import expert_parallel as EP
+    x = rnd(T, H, seed=301)
+    w13, w2 = rnd(E + 1, 2 * I, H, seed=302, scale=H ** -0.5), rnd(E + 1, H, I, seed=303, scale=I ** -0.5)
+    g = torch.Generator().manual_seed(304)
+    idx = torch.stack([torch.randperm(E, generator=g)[:k].sort()[0] for _ in range(T)]).to(torch.int64)
+    w = (torch.rand(T, k, generator=g) + 0.1).to(BF)
+    ref_dev, _ = _moe_hip(ops, x, None, None, k, 1.0, w13[:E], w2[:E], w13[E], w2[E], topk=(idx, w))
+    W13, W2, xd = dev(w13), dev(w2), dev(x)
+    El = E // ep
+
+    def shared(hh):
+        a = ops.grouped_gemm_gateup_silu(hh, W13[E:E + 1], None, None, hh.shape[0])
+        return ops.grouped_gemm_down(a, W2[E:E + 1], None, None, 0)
+    gens = [EP.EPExperts(ops, ep, r, E, k, W13[r * El:(r + 1) * El], W2[r * El:(r + 1) * El], shared)
+            .forward(xd, dev(idx), dev(w)) for r in range(ep)]
+    outs = EP.run_emulated(gens)
+    for o in outs:
+        assert torch.equal(o, outs[0])
+    assert torch.equal(outs[0], ref_dev), "expert-parallel result differs from the single-GPU kernels"
+    ref = O.moe(x, None, None, k, 1.0, w13[:E], w2[:E], w13[E], w2[E], topk=(idx, w))
+    assert_mixed(outs[0], ref, 2 ** -6, 2 ** -6 * float(ref.float().abs().max()), "expert-parallel vs oracle")
