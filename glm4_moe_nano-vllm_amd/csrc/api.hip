@@ -19,6 +19,23 @@ namespace {
 // rows per group above which the MFMA-bound tiled kernel is used instead of weight streaming
 constexpr int64_t LARGEM_MIN_AVG_ROWS = 96;
 
+// Many rows per group with fp8 weights (prefill): the GEMM is MFMA-bound, weight bytes do not matter, so the stack is
+// expanded (exactly) to bf16 in caller-provided scratch by one streaming pass and the tiled bf16 kernel runs on the copy,
+// with the per-row dequantisation scale applied to its fp32 accumulators — the arithmetic of the streaming fp8 kernel.
+int fp8w_large(int mode, GemmParams p, int rows, int cols, void* scratch, size_t scratch_bytes, hipStream_t st) {
+    const int64_t pitch = glm_expand_pitch(cols);
+    const size_t need = (size_t)p.G * rows * pitch * sizeof(bf16_t);
+    GLM_CHECK_ARG(scratch_bytes >= need && glm_aligned16(scratch), GLM_ERR_WORKSPACE,
+                  "fp8 expert GEMM: expansion scratch %zu < %zu bytes", scratch_bytes, need);
+    // fp8 strides are in elements = bytes
+    const int rc = glm_launch_fp8_expand(p.w, p.ldw, p.w_gstride, scratch, pitch, (int64_t)rows * pitch, p.G, rows, cols, st);
+    if (rc != GLM_OK) return rc;
+    p.w = (const bf16_t*)scratch;
+    p.ldw = pitch;
+    p.w_gstride = (int64_t)rows * pitch;
+    return glm_launch_gemm_largem(mode, p, st);  // p.wscale stays set
+}
+
 int dispatch(int mode, const GemmParams& p, hipStream_t st) {
     if (p.R <= 0) return GLM_OK;
     const int64_t avg = p.R / (p.G > 0 ? p.G : 1);
@@ -108,6 +125,7 @@ extern "C" int glm_grouped_gemm_gateup_silu_fp8w(const void* x, int64_t ldx, con
                                                  const float* w13_scale, int64_t w13_scale_group_stride,
                                                  const int32_t* expert_offsets, const int32_t* sorted_token,
                                                  void* act, int64_t R, int H, int I, int G,
+                                                 void* expand_scratch, size_t expand_scratch_bytes,
                                                  glm_stream_t stream) {
     GLM_CHECK_ARG(x && w13_q && w13_scale && act, GLM_ERR_INVALID, "glm_grouped_gemm_gateup_silu_fp8w: null pointer");
     GLM_CHECK_ARG(R >= 0 && H > 0 && I > 0 && G >= 1 && ldx >= H && w13_row_stride >= H &&
@@ -124,6 +142,8 @@ extern "C" int glm_grouped_gemm_gateup_silu_fp8w(const void* x, int64_t ldx, con
     p.offs = expert_offsets; p.src = sorted_token;
     p.y = (bf16_t*)act; p.ldy = I;
     p.R = R; p.N = I; p.K = H; p.G = G;
+    if (R / G >= LARGEM_MIN_AVG_ROWS && expand_scratch != nullptr)
+        return fp8w_large(GEMM_GATEUP, p, 2 * I, H, expand_scratch, expand_scratch_bytes, glm_s(stream));
     return glm_launch_gemm_smallm_fp8w(GEMM_GATEUP, p, glm_s(stream));
 }
 
@@ -131,7 +151,8 @@ extern "C" int glm_grouped_gemm_down_fp8w(const void* act, const void* w2_q, int
                                           int64_t w2_row_stride, const float* w2_scale,
                                           int64_t w2_scale_group_stride, const int32_t* expert_offsets,
                                           const void* sorted_scale, int n_scaled_groups, void* y,
-                                          int64_t ldy, int64_t R, int H, int I, int G, glm_stream_t stream) {
+                                          int64_t ldy, int64_t R, int H, int I, int G, void* expand_scratch,
+                                          size_t expand_scratch_bytes, glm_stream_t stream) {
     GLM_CHECK_ARG(act && w2_q && w2_scale && y, GLM_ERR_INVALID, "glm_grouped_gemm_down_fp8w: null pointer");
     GLM_CHECK_ARG(R >= 0 && H > 0 && I > 0 && G >= 1 && ldy >= H && w2_row_stride >= I &&
                       (G == 1 || (w2_group_stride >= (int64_t)H * w2_row_stride && w2_scale_group_stride >= H)) &&
@@ -147,5 +168,11 @@ extern "C" int glm_grouped_gemm_down_fp8w(const void* act, const void* w2_q, int
     p.scale = (const bf16_t*)sorted_scale; p.n_scaled = n_scaled_groups;
     p.y = (bf16_t*)y; p.ldy = ldy;
     p.R = R; p.N = H; p.K = I; p.G = G;
+    if (R / G >= LARGEM_MIN_AVG_ROWS && expand_scratch != nullptr)
+        return fp8w_large(GEMM_DOWN, p, H, I, expand_scratch, expand_scratch_bytes, glm_s(stream));
     return glm_launch_gemm_smallm_fp8w(GEMM_DOWN, p, glm_s(stream));
+}
+
+extern "C" size_t glm_fp8w_expand_scratch_bytes(int G, int rows, int cols) {
+    return (size_t)G * rows * glm_expand_pitch(cols) * sizeof(bf16_t);
 }

@@ -705,3 +705,45 @@ extern "C" int glm_silu_and_mul(const void* x, void* y, int64_t T, int I, glm_st
     GLM_CHECK_LAUNCH("glm_silu_and_mul");
     return GLM_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// N4: exact expansion of OCP fp8 e4m3 weights to bf16 (every e4m3 value is representable in bf16), one 16-element
+// vector per thread.  Prefill runs the MFMA-bound tiled GEMM on the expanded copy (weight bytes do not matter there) and
+// applies the per-row dequantisation scale to the fp32 accumulator, exactly as the streaming decode kernel does.
+namespace {
+__global__ __launch_bounds__(256) void fp8_expand_kernel(const unsigned char* __restrict__ q, int64_t ld_q,
+                                                         int64_t gs_q, bf16_t* __restrict__ out, int64_t ld_out,
+                                                         int64_t gs_out, int rows, int cols) {
+    const int vpr = cols >> 4;  // 16-element vectors per row
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= (int64_t)rows * vpr) return;
+    const int64_t g = blockIdx.y;
+    const int64_t r = v / vpr;
+    const int c = (int)(v % vpr) * 16;
+    const u32x4_t w = *reinterpret_cast<const u32x4_t*>(q + g * gs_q + r * ld_q + c);
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    u32x4_t o[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], false), b = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], true);
+        o[i >> 1][2 * (i & 1)] = pack2bf(a[0], a[1]);
+        o[i >> 1][2 * (i & 1) + 1] = pack2bf(b[0], b[1]);
+    }
+    u32x4_t* dst = reinterpret_cast<u32x4_t*>(out + g * gs_out + r * ld_out + c);
+    dst[0] = o[0];
+    dst[1] = o[1];
+}
+}  // namespace
+
+int glm_launch_fp8_expand(const void* q, int64_t ld_q, int64_t gs_q, void* out, int64_t ld_out, int64_t gs_out, int G,
+                          int rows, int cols, hipStream_t st) {
+    GLM_CHECK_ARG(cols % 16 == 0 && ld_q % 16 == 0 && gs_q % 16 == 0 && ld_out % 8 == 0 && gs_out % 8 == 0 &&
+                      glm_aligned16(q) && glm_aligned16(out),
+                  GLM_ERR_UNSUPPORTED, "fp8 expand: needs cols%%16==0 and 16-byte aligned rows");
+    const int64_t n = (int64_t)rows * (cols / 16);
+    hipLaunchKernelGGL(fp8_expand_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)G), dim3(256), 0, st,
+                       (const unsigned char*)q, ld_q, gs_q, (bf16_t*)out, ld_out, gs_out, rows, cols);
+    GLM_CHECK_LAUNCH("fp8 expand");
+    return GLM_OK;
+}
+

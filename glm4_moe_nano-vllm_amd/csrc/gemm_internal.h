@@ -38,8 +38,14 @@ int glm_launch_gemm_smallm_partial(const GemmParams& p, hipStream_t st);
 int glm_smallm_partial_slices(int K, int want);  // slices actually used for a requested count (whole 128-wide chunks)
 // same, weights stored as OCP fp8 e4m3 (1 byte/element, ldw/w_gstride in elements) + per-row scale
 int glm_launch_gemm_smallm_fp8w(int mode, const GemmParams& p, hipStream_t st);
-// LDS-tiled MFMA kernels for many rows per group (prefill)
+// LDS-tiled MFMA kernels for many rows per group (prefill); p.wscale != nullptr: per-weight-row fp32 scale applied to
+// the accumulator before the bf16 roundings (weights expanded from fp8, elementwise.hip)
 int glm_launch_gemm_largem(int mode, const GemmParams& p, hipStream_t st);
+// exact fp8 e4m3 -> bf16 expansion of a weight stack [G, rows, cols] (element strides)
+int glm_launch_fp8_expand(const void* q, int64_t ld_q, int64_t gs_q, void* out, int64_t ld_out, int64_t gs_out, int G,
+                          int rows, int cols, hipStream_t st);
+// row pitch (elements) of the expanded copy: padded like hip_ops.padded_weight (no 4 KiB multiples)
+static inline int64_t glm_expand_pitch(int cols) { return cols + (((int64_t)cols * 2) % 4096 == 0 ? 64 : 0); }
 
 // SiLU for the GEMM epilogues: g * rcp(1 + 2^(-g*log2 e)) on the hardware exp2/rcp units
 // (each within 1 ulp fp32).  The result is rounded to bf16 right away, so against the precise

@@ -584,9 +584,17 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (MODE == GEMM_GATEUP) {
-                        o[r] = rbf(glm_silu(rbf(acc[t][mt][r]))) * rbf(acc[t + 2][mt][r]);
+                        float ga = acc[t][mt][r], ua = acc[t + 2][mt][r];
+                        if (p.wscale) {  // weights expanded from fp8: per-row scale on the fp32 accumulators (uniform branch)
+                            const float* ws = p.wscale + (int64_t)grp_c * p.wscale_gstride;
+                            const int n1 = min(ncol_w + 16 * t + 4 * g4 + r, p.N - 1);
+                            ga *= ws[n1];
+                            ua *= ws[p.N + n1];
+                        }
+                        o[r] = rbf(glm_silu(rbf(ga))) * rbf(ua);
                     } else {
                         float a = acc[t][mt][r];
+                        if (p.wscale) a *= p.wscale[(int64_t)grp_c * p.wscale_gstride + min(ncol_w + 16 * t + 4 * g4 + r, p.N - 1)];
                         if (MODE == GEMM_PLAIN && p.bias) a += bf2f(p.bias[min(ncol_w + 16 * t + 4 * g4 + r, p.N - 1)]);
                         if (scaled) a = rbf(a) * sc;
                         o[r] = a;

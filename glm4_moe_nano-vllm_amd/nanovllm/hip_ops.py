@@ -58,12 +58,13 @@ _SIGNATURES = {
                                              c_void_p]),
     "glm_grouped_gemm_down": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int,
                                       c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "glm_fp8w_expand_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "glm_grouped_gemm_gateup_silu_fp8w": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                                   c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int,
-                                                  c_int, c_int, c_void_p]),
+                                                  c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "glm_grouped_gemm_down_fp8w": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p,
                                            c_void_p, c_int, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
-                                           c_void_p]),
+                                           c_void_p, c_size_t, c_void_p]),
     "glm_moe_combine": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
                                 c_int64, c_void_p]),
     "glm_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
@@ -497,6 +498,23 @@ def quantize_fp8_rowwise(w: torch.Tensor):
     return view, s.contiguous()
 
 
+_FP8_LARGE_MIN_AVG_ROWS = 96  # api.hip LARGEM_MIN_AVG_ROWS
+_fp8_scratch: dict = {}
+
+
+def _fp8_expand_scratch(device, G: int, rows: int, cols: int, R: int):
+    """Scratch for the prefill-regime fp8 expert GEMM (bf16 copy of ONE weight stack, reused by every layer and both
+    projections); None at decode row counts, where the streaming fp8 kernel runs."""
+    if R // max(G, 1) < _FP8_LARGE_MIN_AVG_ROWS:
+        return None, 0
+    need = load_library().glm_fp8w_expand_scratch_bytes(G, rows, cols)
+    buf = _fp8_scratch.get(device)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(need, dtype=torch.uint8, device=device)
+        _fp8_scratch[device] = buf
+    return buf, buf.numel()
+
+
 def grouped_gemm_gateup_silu_fp8w(x, w13_q, w13_s, expert_offsets, sorted_token, R: int) -> torch.Tensor:
     """x [T,H] bf16; w13_q [G,2I,H] uint8 (fp8 e4m3); w13_s [G,2I] fp32 -> act [R,I]."""
     _bf16(x, "x")
@@ -505,9 +523,10 @@ def grouped_gemm_gateup_silu_fp8w(x, w13_q, w13_s, expert_offsets, sorted_token,
     assert w13_q.dtype == torch.uint8 and w13_q.stride(2) == 1 and w13_s.dtype == torch.float32
     assert w13_s.stride(1) == 1
     act = torch.empty((R, I), dtype=x.dtype, device=x.device)
+    scr, scr_n = _fp8_expand_scratch(x.device, G, I2, H, R)
     _check(load_library().glm_grouped_gemm_gateup_silu_fp8w(
         _p(x), x.stride(0), _p(w13_q), w13_q.stride(0), w13_q.stride(1), _p(w13_s), w13_s.stride(0),
-        _p(expert_offsets), _p(sorted_token), _p(act), R, H, I, G, _stream()),
+        _p(expert_offsets), _p(sorted_token), _p(act), R, H, I, G, _p(scr), scr_n, _stream()),
         "glm_grouped_gemm_gateup_silu_fp8w")
     return act
 
@@ -518,9 +537,11 @@ def grouped_gemm_down_fp8w(act, w2_q, w2_s, expert_offsets, sorted_scale, n_scal
     R = act.shape[0]
     assert w2_q.dtype == torch.uint8 and w2_q.stride(2) == 1 and w2_s.dtype == torch.float32 and act.is_contiguous()
     y = torch.empty((R, H), dtype=act.dtype, device=act.device)
+    scr, scr_n = _fp8_expand_scratch(act.device, G, H, I, R)
     _check(load_library().glm_grouped_gemm_down_fp8w(
         _p(act), _p(w2_q), w2_q.stride(0), w2_q.stride(1), _p(w2_s), w2_s.stride(0), _p(expert_offsets),
-        _p(sorted_scale), n_scaled_groups, _p(y), H, R, H, I, G, _stream()), "glm_grouped_gemm_down_fp8w")
+        _p(sorted_scale), n_scaled_groups, _p(y), H, R, H, I, G, _p(scr), scr_n, _stream()),
+        "glm_grouped_gemm_down_fp8w")
     return y
 
 

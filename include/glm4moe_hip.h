@@ -175,19 +175,25 @@ int glm_grouped_gemm_down(const void* act, const void* w2,
  *     fp8 values are converted exactly to bf16 in registers, accumulated in fp32 on the bf16 MFMA,
  *     and the row scale is applied to the fp32 accumulator before the bf16 roundings of a13.
  *     w13_q: [G, 2I, H] uint8 with element strides (group, row, 1); w13_scale: f32 [G, 2I]
- *     (row stride 1, group stride w13_scale_group_stride); likewise w2_q [G, H, I], w2_scale [G, H]. */
+ *     (row stride 1, group stride w13_scale_group_stride); likewise w2_q [G, H, I], w2_scale [G, H].
+ *     Few rows per group (decode): the weights are streamed as fp8 (HBM-bound, half the bytes).  Many rows per group
+ *     (prefill, MFMA-bound) and expand_scratch != NULL (glm_fp8w_expand_scratch_bytes(G, weight rows, K) bytes,
+ *     16-byte aligned, contents scratch): the stack is expanded exactly to bf16 by one streaming pass and the tiled
+ *     bf16 MFMA kernel runs on the copy with the same accumulator scaling; with NULL the streaming kernel is used.  */
+size_t glm_fp8w_expand_scratch_bytes(int G, int rows, int cols);
 int glm_grouped_gemm_gateup_silu_fp8w(const void* x, int64_t ldx, const void* w13_q,
                                       int64_t w13_group_stride, int64_t w13_row_stride,
                                       const float* w13_scale, int64_t w13_scale_group_stride,
                                       const int32_t* expert_offsets, const int32_t* sorted_token,
                                       void* act, int64_t R, int H, int I, int G,
-                                      glm_stream_t stream);
+                                      void* expand_scratch, size_t expand_scratch_bytes, glm_stream_t stream);
 int glm_grouped_gemm_down_fp8w(const void* act, const void* w2_q,
                                int64_t w2_group_stride, int64_t w2_row_stride,
                                const float* w2_scale, int64_t w2_scale_group_stride,
                                const int32_t* expert_offsets, const void* sorted_scale,
                                int n_scaled_groups, void* y, int64_t ldy,
-                               int64_t R, int H, int I, int G, glm_stream_t stream);
+                               int64_t R, int H, int I, int G,
+                               void* expand_scratch, size_t expand_scratch_bytes, glm_stream_t stream);
 
 /* a12 models/glm4_moe/moe.py:133,151,171: out[t] = bf16-accumulate of the token's k routed
  *     rows in ascending expert order (one bf16 rounding per add, starting from 0), then

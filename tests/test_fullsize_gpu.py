@@ -230,6 +230,47 @@ def test_c3_grouped_gemms_prefill_shape(ops):
     assert torch.equal(out2, out[perm]), "MoE block is not permutation-equivariant at T=16384"
 
 
+@pytest.mark.parametrize("T", [64, 4096])
+def test_c5_fp8_expert_gemms_full_size(ops, T):
+    """N4 / BASELINE config 5 flavour at Air dims (H=4096, I=1408, G=65): fp8 e4m3 weight-only experts.  T=64 (the
+    config's batch) runs the streaming fp8 kernel, T=4096 the prefill path (exact fp8->bf16 expansion + tiled MFMA
+    kernel with the row scale on the accumulator).  Oracle = the reference's expert arithmetic on the dequantised
+    weights with the SAME bytes and scales (oracle.linear_fp8w): sampled rows of sampled groups."""
+    cfg = F.air_cfg()
+    H, E, k, I = cfg.hidden_size, cfg.n_routed_experts, cfg.num_experts_per_tok, cfg.moe_intermediate_size
+    x, idx, w, offs, tok, scale, pos = _bench_routing(ops, cfg, T, seed=401)
+    g = torch.Generator(device="cuda").manual_seed(8)
+    w13 = torch.empty(E + 1, 2 * I, H, device="cuda", dtype=BF).normal_(0.0, 0.02, generator=g)
+    w2 = torch.empty(E + 1, H, I, device="cuda", dtype=BF).normal_(0.0, 0.02, generator=g)
+    q13, s13 = ops.quantize_fp8_rowwise(w13)
+    q2, s2 = ops.quantize_fp8_rowwise(w2)
+    del w13, w2
+    R = T * k + T
+    act = ops.grouped_gemm_gateup_silu_fp8w(x, q13, s13, offs, tok, R)
+    y = ops.grouped_gemm_down_fp8w(act, q2, s2, offs, scale, E)
+    torch.cuda.synchronize()
+    offs_c, tok_c, scale_c = offs.cpu(), tok.cpu(), scale.cpu()
+    worst = {}
+    for e in (0, 31, 63, 64):
+        lo, hi = int(offs_c[e]), int(offs_c[e + 1])
+        n = hi - lo
+        if n == 0:
+            continue
+        rr = (torch.cat([torch.arange(0, min(256, n)), torch.arange(max(0, n - 150), n)]).unique() + lo)
+        rg = rr.cuda()
+        qe13 = q13[e].cpu().contiguous().view(torch.float8_e4m3fn)
+        qe2 = q2[e].cpu().contiguous().view(torch.float8_e4m3fn)
+        a_ref = O.silu_and_mul(O.linear_fp8w(x[tok[rg].long()].cpu(), qe13, s13[e].cpu()))
+        a_got = act[rg].cpu()
+        assert_close_bf16(a_got, a_ref, 3, 0.06, atol=2 ** -7, what=f"fp8 T={T} act group {e}")
+        y_ref = O.linear_fp8w(a_got, qe2, s2[e].cpu())
+        if e < E:
+            y_ref = y_ref * scale_c[rr].unsqueeze(-1)
+        assert_close_bf16(y[rg].cpu(), y_ref, 1, 0.05, atol=2 ** -9, what=f"fp8 T={T} y group {e}")
+        worst[f"group{e}"] = {"act": F.err_stats(a_got, a_ref), "y": F.err_stats(y[rg].cpu(), y_ref)}
+    F.report(f"C5.fp8_expert_gemms_T{T}", rows=R, worst=worst)
+
+
 def test_c3_paged_attention_full_size(ops):
     """(iv) paged decode attention at B=32, nh=96, nkv=8, ctx=4096 (the no-split instantiation bench.py times) and at
     B=1 ctx=1024 (split + reduce), stand-alone and fused-from-QKV."""

@@ -580,7 +580,9 @@ def test_padded_weight_pitch(ops):
 
 # ------------------------------------------------------------------------------------------
 # N4: fp8 (OCP e4m3) weight-only quantised experts
-@pytest.mark.parametrize("T,E,k,H,I", [(32, 8, 2, 512, 128), (5, 4, 2, 4096, 192), (70, 4, 2, 256, 352)])
+@pytest.mark.parametrize("T,E,k,H,I", [(32, 8, 2, 512, 128), (5, 4, 2, 4096, 192), (70, 4, 2, 256, 352),
+                                       # many rows per group: exact fp8 -> bf16 expansion + the tiled MFMA kernel
+                                       (600, 4, 2, 256, 128), (1024, 2, 1, 512, 352)])
 def test_moe_block_fp8_weights(ops, T, E, k, H, I):
     x = rnd(T, H, seed=111)
     w13, w2 = rnd(E + 1, 2 * I, H, seed=112, scale=H ** -0.5), rnd(E + 1, H, I, seed=113, scale=I ** -0.5)
@@ -658,8 +660,11 @@ def test_moe_combine_scaled_equals_scaled_rows_combine(ops, T, k, H):
 @pytest.mark.parametrize("ep,T,E,k,H,I", [(2, 32, 8, 2, 512, 128), (4, 37, 16, 4, 256, 192), (8, 5, 64, 8, 4096, 1408),
                                           (2, 1, 4, 2, 256, 64)])
 def test_expert_parallel_emulated_equals_single_gpu(ops, ep, T, E, k, H, I):
-    """EP = ep logical ranks on ONE device (same code, collectives done by copies) == the TP = 1 kernels' result bit for
-    bit: a row's value does not depend on which rank's grouped GEMM computed it nor on its position in the group."""
+    """EP = ep logical ranks on ONE device (same code, collectives done by copies) == the TP = 1 kernels' result: a
+    row's value does not depend on which rank's grouped GEMM computed it nor on its position in the group — bit for
+    bit whenever both sides run the same kernel instantiation; a rank that holds few rows may get another K-split
+    configuration of the streaming GEMM (gemm_smallm.hip dispatches on the total row count), i.e. another fp32
+    summation order: then single bf16 ulps."""
     from nanovllm.distributed import expert_parallel as EP
     x = rnd(T, H, seed=301)
     w13, w2 = rnd(E + 1, 2 * I, H, seed=302, scale=H ** -0.5), rnd(E + 1, H, I, seed=303, scale=I ** -0.5)
@@ -678,6 +683,7 @@ def test_expert_parallel_emulated_equals_single_gpu(ops, ep, T, E, k, H, I):
     outs = EP.run_emulated(gens)
     for o in outs:
         assert torch.equal(o, outs[0])
-    assert torch.equal(outs[0], ref_dev), "expert-parallel result differs from the single-GPU kernels"
+    if not torch.equal(outs[0], ref_dev):
+        assert_close_bf16(outs[0], ref_dev, 2, 0.05, atol=2 ** -8, what="expert-parallel vs single-GPU kernels")
     ref = O.moe(x, None, None, k, 1.0, w13[:E], w2[:E], w13[E], w2[E], topk=(idx, w))
     assert_mixed(outs[0], ref, 2 ** -6, 2 ** -6 * float(ref.float().abs().max()), "expert-parallel vs oracle")
