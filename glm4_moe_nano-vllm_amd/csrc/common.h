@@ -61,5 +61,23 @@ void glm_set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel instantiation, device): the attribute belongs to the
+// device the call is made on, so a process that drives several GPUs must set it on each of them
+#define GLM_MAX_DEVICES 16
+#define GLM_SET_MAX_LDS(kern, bytes, name)                                                                   \
+    do {                                                                                                     \
+        static bool lds_set__[GLM_MAX_DEVICES] = {};                                                         \
+        int dev__ = -1;                                                                                      \
+        if (hipGetDevice(&dev__) != hipSuccess) dev__ = -1;                                                  \
+        if (dev__ < 0 || dev__ >= GLM_MAX_DEVICES || !lds_set__[dev__]) {                                    \
+            hipError_t e__ = hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); \
+            if (e__ != hipSuccess) {                                                                         \
+                glm_set_error("%s: hipFuncSetAttribute(%d B LDS): %s", name, (int)(bytes), hipGetErrorString(e__)); \
+                return GLM_ERR_LAUNCH;                                                                       \
+            }                                                                                                \
+            if (dev__ >= 0 && dev__ < GLM_MAX_DEVICES) lds_set__[dev__] = true;                              \
+        }                                                                                                    \
+    } while (0)
+
 static inline bool glm_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static inline hipStream_t glm_s(glm_stream_t s) { return (hipStream_t)s; }

@@ -673,15 +673,7 @@ int launch_largem_cfg(const GemmParams& p, hipStream_t st) {
     if (total <= 0) return GLM_OK;
     GLM_CHECK_ARG(total < (1ll << 31), GLM_ERR_UNSUPPORTED, "gemm_largem: grid too large");
     auto kern = gemm_largem_kernel<MODE, C, VAR>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-        if (e != hipSuccess) {
-            glm_set_error("gemm_largem: hipFuncSetAttribute(%d): %s", C::LDS, hipGetErrorString(e));
-            return GLM_ERR_LAUNCH;
-        }
-        attr_set = true;
-    }
+    GLM_SET_MAX_LDS(kern, C::LDS, "gemm_largem");
     // one workgroup per CU (the ring takes most of the LDS), a multiple of 8 so that every XCD gets the same count
     static int n_cu = 0;
     if (n_cu == 0) {

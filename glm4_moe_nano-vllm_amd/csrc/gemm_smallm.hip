@@ -646,6 +646,225 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_smallm_dma_kernel(const Gemm
     else smallm_body_dma<MODE, NWAVES, WS, RT, (MTMAX < 2 ? MTMAX : 2), TPW>(p, smem, grp, m0, mcnt);
 }
 
+// ==========================================================================================
+// Shared-activation LDS-DMA body ("sx"): the NW waves of a workgroup own different weight rows of one column tile and
+// SHARE one activation tile per K chunk.  With private rings (smallm_body_dma) a wave moves as many activation bytes
+// L2 -> LDS as weight bytes whenever a row block holds as many rows as the wave has weight rows — with 1-byte weights
+// twice as many, which is what capped the fp8 DMA variant of r01 (239 / 111 us).  Here the activation rows of a chunk
+// are fetched once per workgroup (each wave DMAs 1/NW of them), i.e. 12-25 % on top of the weight stream.
+//   * 3-stage ring shared by the workgroup, stage = [wave 0 rows | ... | wave NW-1 rows | activation rows]; one chunk =
+//     256 B per weight row: 128 k of bf16 or 256 k of fp8 (activation rows then 512 B).
+//   * ONE workgroup barrier per chunk: a wave waits for its own DMA of chunk `it` (counted vmcnt, chunk it+1 stays in
+//     flight), then the barrier makes every wave's share of the activation tile visible AND proves that everyone is done
+//     reading chunk it-1, whose stage is refilled with chunk it+2 right after the fragment reads.
+//   * fp8 weights are converted to bf16 fragments in registers exactly as in smallm_body (one 16-byte LDS read = two
+//     k-steps of a lane), the row scale multiplies the fp32 accumulator.
+template <int MODE, int NW, int RT, int MT, bool W8>
+__device__ __forceinline__ void smallm_body_sx(const GemmParams& p, char* smem, int grp, int m0, int mcnt) {
+    static_assert((RT == 1 || RT == 2 || RT == 4) && MT <= 2, "1/2/4 row tiles, at most 2 token tiles");
+    constexpr int KC = W8 ? 256 : 128;            // k per chunk: 256 B per weight row
+    constexpr int NKS = KC / 32;                  // MFMA k-steps per chunk
+    constexpr int XROWB = KC * 2;                 // activation row bytes per chunk
+    constexpr int WROWS = 16 * RT, XROWS = 16 * MT;
+    constexpr int WWAVE = WROWS * 256;            // one wave's weight bytes per stage
+    constexpr int XT = XROWS * XROWB;             // shared activation bytes per stage
+    constexpr int STAGE = NW * WWAVE + XT;
+    constexpr int NW_DMA = WROWS / 4;             // weight DMA instructions per wave per chunk (4 rows x 256 B each)
+    constexpr int NX_ALL = XT / 1024, NX_DMA = NX_ALL / NW;  // activation DMA instructions: all, per wave
+    static_assert(NX_ALL % NW == 0, "activation tile must split evenly over the waves");
+    constexpr int NDMA = NW_DMA + NX_DMA;
+    constexpr int XRPI = 1024 / XROWB;            // activation rows per DMA instruction (4 or 2)
+    constexpr int XCPR = XROWB / 16;              // 16-B chunks per activation row (16 or 32)
+    constexpr int CPW = MODE == GEMM_GATEUP ? 8 * RT : 16 * RT;  // output columns per wave
+    constexpr int WB = W8 ? 1 : 2;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g4 = lane >> 4;
+    const int K = p.K;
+    const int nchunks = (K + KC - 1) / KC;
+    const int ncol0 = (blockIdx.x * NW + wid) * CPW;
+
+    // ---- DMA sources ----
+    const int r4 = lane >> 4, pch = lane & 15;
+    const char* wg = reinterpret_cast<const char*>(p.w) + (int64_t)grp * p.w_gstride * WB;
+    const char* wsrc[NW_DMA];
+    int wk[NW_DMA];  // byte offset of this lane's 16-B piece inside a chunk row
+#pragma unroll
+    for (int i = 0; i < NW_DMA; ++i) {
+        const int row = 4 * i + r4;
+        int wi;
+        if (MODE == GEMM_GATEUP) wi = (row < WROWS / 2 ? 0 : p.N) + min(ncol0 + row % (WROWS / 2), p.N - 1);
+        else wi = min(ncol0 + row, p.N - 1);
+        wsrc[i] = wg + (int64_t)wi * p.ldw * WB;
+        wk[i] = (pch ^ (row & 15)) << 4;
+    }
+    const char* xsrc[NX_DMA];
+    int xk[NX_DMA];
+#pragma unroll
+    for (int i = 0; i < NX_DMA; ++i) {
+        const int inst = wid * NX_DMA + i;                 // this wave's share of the activation tile
+        const int row = inst * XRPI + lane / XCPR;         // 0 .. XROWS-1
+        const int pos = lane % XCPR;
+        const int rr = row < mcnt ? row : 0;               // padding rows re-read row 0 (never stored)
+        const int64_t srow = p.src ? (int64_t)p.src[m0 + rr] : (int64_t)(m0 + rr);
+        xsrc[i] = reinterpret_cast<const char*>(p.x + srow * p.ldx);
+        xk[i] = (pos ^ (row & 15)) << 4;                   // XOR of the low 4 bits: stays inside the row
+    }
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+    auto issue = [&](int ci) {
+        char* st = smem + (ci % 3) * STAGE;
+        const int k0 = ci * KC;
+#pragma unroll
+        for (int i = 0; i < NW_DMA; ++i) {
+            const int kb = k0 * WB + wk[i];  // byte offset in the weight row; 16 bytes = 16 / WB elements
+            sm_glds16<2>(kb / WB < K ? wsrc[i] + kb : zero, st + wid * WWAVE + i * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < NX_DMA; ++i) {
+            const int kb = k0 * 2 + xk[i];
+            sm_glds16<0>(kb / 2 < K ? xsrc[i] + kb : zero, st + NW * WWAVE + (wid * NX_DMA + i) * 1024);
+        }
+    };
+
+    f32x4_t acc[RT][MT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[rt][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets relative to the stage base.  weights: lane (c, g4) reads row 16 rt + c, 16-B piece
+    // (4 q + g4) ^ c for q = 0..3 (bf16: k-step q; fp8: k-steps 2q, 2q+1).  activations: row 16 mt + c, piece xp ^ c.
+    unsigned wrel[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wrel[q] = wid * WWAVE + c * 256 + (((4 * q + g4) ^ c) << 4);
+    unsigned xrel[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int xp = W8 ? 8 * (ks >> 1) + 2 * g4 + (ks & 1) : 4 * ks + g4;
+        xrel[ks] = NW * WWAVE + c * XROWB + ((xp ^ c) << 4);
+    }
+    const unsigned rbase = (unsigned)(uintptr_t)(const sm_lds_void*)smem;
+
+    if (nchunks > 0) issue(0);
+    if (nchunks > 1) issue(1);
+    for (int it = 0; it < nchunks; ++it) {
+        if (it + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned sb = rbase + (it % 3) * STAGE;
+        u32x4_t af[RT][4], bfr[MT][NKS];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sm_lds_read_b128<0>(af[0][q], sb + wrel[q]);
+            if (RT > 1) sm_lds_read_b128<4096>(af[1 % RT][q], sb + wrel[q]);
+            if (RT > 2) {
+                sm_lds_read_b128<8192>(af[2 % RT][q], sb + wrel[q]);
+                sm_lds_read_b128<12288>(af[3 % RT][q], sb + wrel[q]);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            sm_lds_read_b128<0>(bfr[0][ks], sb + xrel[ks]);
+            if (MT > 1) sm_lds_read_b128<16 * XROWB>(bfr[MT - 1][ks], sb + xrel[ks]);
+        }
+        // wait for every LDS read: all destinations named so that no consumer moves above the wait
+        if constexpr (RT == 2 && MT == 1 && NKS == 8)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]), "+v"(af[1][0]),
+                         "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][3]), "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(bfr[0][2]),
+                         "+v"(bfr[0][3]), "+v"(bfr[0][4]), "+v"(bfr[0][5]), "+v"(bfr[0][6]), "+v"(bfr[0][7])::"memory");
+        else if constexpr (RT == 2 && MT == 2 && NKS == 8)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]), "+v"(af[1][0]),
+                         "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][3]), "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(bfr[0][2]),
+                         "+v"(bfr[0][3]), "+v"(bfr[0][4]), "+v"(bfr[0][5]), "+v"(bfr[0][6]), "+v"(bfr[0][7]), "+v"(bfr[1][0]),
+                         "+v"(bfr[1][1]), "+v"(bfr[1][2]), "+v"(bfr[1][3]), "+v"(bfr[1][4]), "+v"(bfr[1][5]), "+v"(bfr[1][6]),
+                         "+v"(bfr[1][7])::"memory");
+        else if constexpr (RT == 2 && MT == 1 && NKS == 4)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]), "+v"(af[1][0]),
+                         "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][3]), "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(bfr[0][2]),
+                         "+v"(bfr[0][3])::"memory");
+        else {
+            static_assert(RT == 2 && MT == 2 && NKS == 4, "fragment sets covered: 2 row tiles x 1/2 token tiles, bf16 or fp8");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]), "+v"(af[1][0]),
+                         "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][3]), "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(bfr[0][2]),
+                         "+v"(bfr[0][3]), "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(bfr[1][2]), "+v"(bfr[1][3])::"memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 2 < nchunks) issue(it + 2);  // stage (it+2)%3 == (it-1)%3: everyone is past it (barrier above)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                bf16x8_t a;
+                if (!W8) {
+                    a = __builtin_bit_cast(bf16x8_t, af[rt][ks]);
+                } else {  // bytes [8 (ks & 1), +8) of piece ks >> 1: exact fp8 -> bf16
+                    const u32x4_t w = af[rt][ks >> 1];
+                    const unsigned d0 = w[2 * (ks & 1)], d1 = w[2 * (ks & 1) + 1];
+                    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+                    const f32x2_t e0 = __builtin_amdgcn_cvt_pk_f32_fp8(d0, false), e1 = __builtin_amdgcn_cvt_pk_f32_fp8(d0, true);
+                    const f32x2_t e2 = __builtin_amdgcn_cvt_pk_f32_fp8(d1, false), e3 = __builtin_amdgcn_cvt_pk_f32_fp8(d1, true);
+                    const u32x4_t o = {pack2bf(e0[0], e0[1]), pack2bf(e1[0], e1[1]), pack2bf(e2[0], e2[1]), pack2bf(e3[0], e3[1])};
+                    a = __builtin_bit_cast(bf16x8_t, o);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[rt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8_t, bfr[mt][ks]),
+                                                                         acc[rt][mt], 0, 0, 0);
+            }
+    }
+    if (W8) {
+        const float* ws = p.wscale + (int64_t)grp * p.wscale_gstride;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int rb = (MODE == GEMM_GATEUP ? (rt < RT / 2 ? ncol0 + 16 * rt : p.N + ncol0 + 16 * (rt - RT / 2)) : ncol0 + 16 * rt) + 4 * g4;
+            const int rmax = MODE == GEMM_GATEUP ? 2 * p.N - 1 : p.N - 1;
+            float sc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[r] = ws[min(rb + r, rmax)];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[rt][mt][r] *= sc[r];
+        }
+    }
+    smallm_epilogue<MODE, RT, MT>(p, acc, grp, m0, mcnt, ncol0, c, g4);
+}
+
+template <int MODE, int NW, int RT, int MTMAX, bool W8>
+__global__ __launch_bounds__(NW * 64) void gemm_smallm_sx_kernel(const GemmParams p) {
+    constexpr int MB = 16 * MTMAX;
+    constexpr int RING = 3 * (NW * 16 * RT * 256 + 16 * MTMAX * (W8 ? 512 : 256));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* sh = reinterpret_cast<int*>(smem + RING);
+    glm_locate_block(p.offs, p.G, p.R, MB, blockIdx.y, sh);
+    __syncthreads();
+    const int grp = sh[0];
+    if (grp < 0) return;
+    const int m0 = sh[1], mcnt = sh[2];
+    if (mcnt <= 16) smallm_body_sx<MODE, NW, RT, 1, W8>(p, smem, grp, m0, mcnt);
+    else smallm_body_sx<MODE, NW, RT, (MTMAX < 2 ? MTMAX : 2), W8>(p, smem, grp, m0, mcnt);
+}
+
+template <int MODE, int NW, int RT, int MTMAX, bool W8>
+int launch_cfg_sx(const GemmParams& p, hipStream_t st) {
+    static_assert(MTMAX <= 2, "the shared-activation body stages at most 32 token rows");
+    constexpr int MB = 16 * MTMAX;
+    constexpr int RING = 3 * (NW * 16 * RT * 256 + 16 * MTMAX * (W8 ? 512 : 256));
+    static_assert(RING + 16 <= 160 * 1024, "the ring must fit the CU's 160 KiB of LDS");
+    constexpr int LDS = RING + 16;
+    const int cols_per_wg = MODE == GEMM_GATEUP ? NW * 8 * RT : NW * RT * 16;
+    const unsigned gx = (unsigned)((p.N + cols_per_wg - 1) / cols_per_wg);
+    const int64_t combos = p.offs ? (p.R / MB + p.G) : (p.R + MB - 1) / MB;
+    if (combos <= 0 || gx == 0) return GLM_OK;
+    GLM_CHECK_ARG(combos <= 65535, GLM_ERR_UNSUPPORTED, "gemm_smallm(sx): too many row blocks (%ld)", (long)combos);
+    auto kern = gemm_smallm_sx_kernel<MODE, NW, RT, MTMAX, W8>;
+    GLM_SET_MAX_LDS(kern, LDS, "gemm_smallm(sx)");
+    hipLaunchKernelGGL(kern, dim3(gx, (unsigned)combos, 1), dim3(NW * 64), LDS, st, p);
+    GLM_CHECK_LAUNCH("gemm_smallm(sx)");
+    return GLM_OK;
+}
+
 template <int MODE, int NWAVES, int WS, int RT, int MTMAX, int TPW = 1>
 int launch_cfg_dma(const GemmParams& p, hipStream_t st) {
     static_assert(MTMAX <= 2, "the DMA variant stages at most 32 token rows");
@@ -666,17 +885,7 @@ int launch_cfg_dma(const GemmParams& p, hipStream_t st) {
     if (combos <= 0 || gx == 0) return GLM_OK;
     GLM_CHECK_ARG(combos <= 65535, GLM_ERR_UNSUPPORTED, "gemm_smallm: too many row blocks (%ld)", (long)combos);
     auto kern = gemm_smallm_dma_kernel<MODE, NWAVES, WS, RT, MTMAX, TPW>;
-    if (LDS > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            if (e != hipSuccess) {
-                glm_set_error("gemm_smallm(dma): hipFuncSetAttribute(%d): %s", LDS, hipGetErrorString(e));
-                return GLM_ERR_LAUNCH;
-            }
-            attr_set = true;
-        }
-    }
+    if (LDS > 64 * 1024) GLM_SET_MAX_LDS(kern, LDS, "gemm_smallm(dma)");
     hipLaunchKernelGGL(kern, dim3(gx, (unsigned)combos, (unsigned)(p.ksplit > 1 ? p.ksplit : 1)), dim3(NWAVES * 64),
                        LDS, st, p);
     GLM_CHECK_LAUNCH("gemm_smallm(dma)");
@@ -697,17 +906,7 @@ int launch_cfg(const GemmParams& p, hipStream_t st) {
     if (combos <= 0 || gx == 0) return GLM_OK;
     GLM_CHECK_ARG(combos <= 65535, GLM_ERR_UNSUPPORTED, "gemm_smallm: too many row blocks (%ld)", (long)combos);
     auto kern = gemm_smallm_kernel<MODE, NWAVES, WS, RT, MTMAX, W8>;
-    if (LDS > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            if (e != hipSuccess) {
-                glm_set_error("gemm_smallm: hipFuncSetAttribute(%d): %s", LDS, hipGetErrorString(e));
-                return GLM_ERR_LAUNCH;
-            }
-            attr_set = true;
-        }
-    }
+    if (LDS > 64 * 1024) GLM_SET_MAX_LDS(kern, LDS, "gemm_smallm");
     hipLaunchKernelGGL(kern, dim3(gx, (unsigned)combos, (unsigned)(p.ksplit > 1 ? p.ksplit : 1)), dim3(NWAVES * 64),
                        LDS, st, p);
     GLM_CHECK_LAUNCH("gemm_smallm");
@@ -841,6 +1040,12 @@ int glm_launch_gemm_smallm_fp8w(int mode, const GemmParams& p, hipStream_t st) {
 #endif
 #ifndef GLM_SM_CFG_DOWN_W8
 #define GLM_SM_CFG_DOWN_W8 8, 1, 1, 2
+#endif
+    // shared-activation LDS-DMA body (4 waves, 64 act / 128 down columns per workgroup) from two sequences on;
+    // a single sequence (k + 1 rows in as many groups) keeps the VGPR body.  -DGLM_SM_FP8_NO_SX: VGPR body everywhere.
+#ifndef GLM_SM_FP8_NO_SX
+    if (p.R > 16 && mode == GEMM_GATEUP) return launch_cfg_sx<GEMM_GATEUP, 4, 2, 2, true>(p, st);
+    if (p.R > 16 && mode == GEMM_DOWN) return launch_cfg_sx<GEMM_DOWN, 4, 2, 2, true>(p, st);
 #endif
     if (mode == GEMM_GATEUP) return launch_cfg<GEMM_GATEUP, GLM_SM_CFG_GATEUP_W8, true>(p, st);
     if (mode == GEMM_DOWN) return launch_cfg<GEMM_DOWN, GLM_SM_CFG_DOWN_W8, true>(p, st);

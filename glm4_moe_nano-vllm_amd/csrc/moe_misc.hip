@@ -90,6 +90,10 @@ struct RouterPre {
     int32_t* al_pos;
     int al_with_shared;
     unsigned* ticket;       // zero before the first launch; the last arriver puts the zero back
+    // optional: the experts of a token split over gridDim.y workgroups (each pulls E / gridDim.y gate rows); the one
+    // that finishes last (per-token ticket) gathers the logits and selects
+    unsigned* tok_ticket;   // [T], zero before the first launch, restored by the kernel
+    float* lg_global;       // [T, E] logits (already rounded to bf16 precision)
 };
 
 template <int PRE>
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
                 s8[2 * j + 1] = xv[2 * j + 1] + bfhi(rv[j]);
                 ov[j] = pack2bf(s8[2 * j], s8[2 * j + 1]);
             }
-            reinterpret_cast<u32x4_t*>(pre.res_out + t * H)[tid] = ov;
+            if (blockIdx.y == 0) reinterpret_cast<u32x4_t*>(pre.res_out + t * H)[tid] = ov;
 #pragma unroll
             for (int j = 0; j < 8; ++j) ss += s8[j] * s8[j];
         }
@@ -176,14 +180,69 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
                 const float b = rbf(s8[2 * i + 1] * rstd) * bfhi(wv[i]);
                 o[i] = pack2bf(a, b);
             }
-            reinterpret_cast<u32x4_t*>(pre.y + t * H)[tid] = o;
+            if (blockIdx.y == 0) reinterpret_cast<u32x4_t*>(pre.y + t * H)[tid] = o;
             reinterpret_cast<u32x4_t*>(xs)[tid] = o;
         }
     }
     __syncthreads();
 
     // R1: logits = bf16( fp32 dot )
-    const int nblk = (E + ROUTER_EB - 1) / ROUTER_EB;
+    const int G = gridDim.y;
+    if (G > 1) {
+        // this workgroup's experts, one per wave at a time, every K step's gate-row load in flight at once.  Per expert
+        // the FMA chain runs over the lane's chunks lane, lane+64, ... in ascending order and ends in the same
+        // wave_sum as the blocked loop below: the logits are bit-identical however the experts are distributed.
+        const int Eg = (E + G - 1) / G;
+        const int e_lo = blockIdx.y * Eg, e_hi = min(E, e_lo + Eg);
+        constexpr int MAXSTEP = 8 * ROUTER_NT / 8 / 64;  // H <= 8 * ROUTER_NT (host check) -> at most 16 steps
+        for (int e = e_lo + wid; e < e_hi; e += ROUTER_NT / 64) {
+            const u32x4_t* grow = reinterpret_cast<const u32x4_t*>(gw + (int64_t)e * H);
+            u32x4_t wv[MAXSTEP];
+#pragma unroll
+            for (int u = 0; u < MAXSTEP; ++u) {
+                wv[u] = u32x4_t{0, 0, 0, 0};
+                if (64 * u < nvec) wv[u] = grow[lane + 64 * u < nvec ? lane + 64 * u : lane];  // uniform guard
+            }
+            float acc = 0.f;
+#pragma unroll
+            for (int u = 0; u < MAXSTEP; ++u) {
+                const int c = lane + 64 * u;
+                if (c < nvec) {
+                    const u32x4_t xv = reinterpret_cast<const u32x4_t*>(xs)[c];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc = fmaf(bflo(xv[q]), bflo(wv[u][q]), acc);
+                        acc = fmaf(bfhi(xv[q]), bfhi(wv[u][q]), acc);
+                    }
+                }
+            }
+            const float sdot = wave_sum(acc);
+            if (lane == 0)  // write-through: another workgroup of this launch reads it (Guideline 16 R1)
+                __hip_atomic_store(reinterpret_cast<unsigned*>(pre.lg_global + t * E + e), __float_as_uint(rbf(sdot)),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // per-token hand-off: every wave drains its stores, the workgroup meets, one lane draws the token's ticket; the
+        // workgroup that draws G-1 acquires and gathers all E logits into LDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* tflag = reinterpret_cast<int*>(lg);
+        if (tid == 0) {
+            unsigned* tk = pre.tok_ticket + t;
+            const unsigned got = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = got == (unsigned)G - 1u;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            tflag[0] = last;
+        }
+        __syncthreads();
+        if (!tflag[0]) return;
+        __syncthreads();
+        for (int e = tid; e < E; e += ROUTER_NT) lg[e] = pre.lg_global[t * E + e];
+    }
+    const int nblk = G > 1 ? 0 : (E + ROUTER_EB - 1) / ROUTER_EB;
     for (int b = wid; b < nblk; b += ROUTER_NT / 64) {
         const int e0 = b * ROUTER_EB;
         float acc[ROUTER_EB];
@@ -332,7 +391,7 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned got = __hip_atomic_fetch_add(pre.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = got == (unsigned)gridDim.x - 1u;
+            const int last = got == (unsigned)gridDim.x - 1u;  // one drawer per token (the token's selecting workgroup)
             if (last) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -581,8 +640,15 @@ static int add_rmsnorm_router_impl(const void* x, const float* part, int nslices
                                    void* residual_out, const void* gate_w, const float* e_score_correction_bias,
                                    int64_t* topk_idx, void* topk_w, int64_t T, int H, int E, int k,
                                    float routed_scaling_factor, int32_t* expert_offsets, int32_t* sorted_token,
-                                   void* sorted_scale, int32_t* pair_pos, int with_shared, uint32_t* ticket,
-                                   glm_stream_t stream);
+                                   void* sorted_scale, int32_t* pair_pos, int with_shared, uint32_t* workspace,
+                                   size_t workspace_bytes, glm_stream_t stream);
+
+// workspace of the fused router + align launch: [global ticket | 65536 per-token tickets | T x E logits (fp32)]
+constexpr size_t ROUTER_WS_TICKETS = 65536;
+constexpr size_t ROUTER_WS_HEAD = 64 + ROUTER_WS_TICKETS * 4;
+extern "C" size_t glm_router_workspace_bytes(int64_t T, int E) {
+    return ROUTER_WS_HEAD + (size_t)(T > 0 ? T : 0) * (size_t)(E > 0 ? E : 0) * sizeof(float);
+}
 
 extern "C" int glm_add_rmsnorm_router_topk(const void* x, const float* part, int nslices, int64_t slice_stride,
                                            const void* residual_in, const void* norm_weight, float eps, void* y,
@@ -592,7 +658,7 @@ extern "C" int glm_add_rmsnorm_router_topk(const void* x, const float* part, int
                                            glm_stream_t stream) {
     return add_rmsnorm_router_impl(x, part, nslices, slice_stride, residual_in, norm_weight, eps, y, residual_out, gate_w,
                                    e_score_correction_bias, topk_idx, topk_w, T, H, E, k, routed_scaling_factor, nullptr,
-                                   nullptr, nullptr, nullptr, 0, nullptr, stream);
+                                   nullptr, nullptr, nullptr, 0, nullptr, 0, stream);
 }
 
 extern "C" int glm_add_rmsnorm_router_topk_align(const void* x, const float* part, int nslices, int64_t slice_stride,
@@ -601,17 +667,20 @@ extern "C" int glm_add_rmsnorm_router_topk_align(const void* x, const float* par
                                                  const float* e_score_correction_bias, int64_t* topk_idx, void* topk_w,
                                                  int64_t T, int H, int E, int k, float routed_scaling_factor,
                                                  int32_t* expert_offsets, int32_t* sorted_token, void* sorted_scale,
-                                                 int32_t* pair_pos, int with_shared, uint32_t* ticket,
-                                                 glm_stream_t stream) {
-    GLM_CHECK_ARG(expert_offsets && sorted_token && sorted_scale && pair_pos && ticket, GLM_ERR_INVALID,
+                                                 int32_t* pair_pos, int with_shared, uint32_t* workspace,
+                                                 size_t workspace_bytes, glm_stream_t stream) {
+    GLM_CHECK_ARG(expert_offsets && sorted_token && sorted_scale && pair_pos && workspace, GLM_ERR_INVALID,
                   "glm_add_rmsnorm_router_topk_align: null pointer");
+    GLM_CHECK_ARG(workspace_bytes >= ROUTER_WS_HEAD && glm_aligned16(workspace), GLM_ERR_WORKSPACE,
+                  "glm_add_rmsnorm_router_topk_align: workspace %zu < %zu bytes", workspace_bytes, ROUTER_WS_HEAD);
     GLM_CHECK_ARG(E < ALIGN_MAX_G && T * (int64_t)(k + 1) < (1ll << 31) && T <= 0x7fffffff &&
                       (size_t)2 * (E + 1) * 4 <= (size_t)H * 2,
                   GLM_ERR_UNSUPPORTED, "glm_add_rmsnorm_router_topk_align: needs E<%d, T*(k+1) < 2^31, 4(E+1) <= H",
                   ALIGN_MAX_G);
     return add_rmsnorm_router_impl(x, part, nslices, slice_stride, residual_in, norm_weight, eps, y, residual_out, gate_w,
                                    e_score_correction_bias, topk_idx, topk_w, T, H, E, k, routed_scaling_factor,
-                                   expert_offsets, sorted_token, sorted_scale, pair_pos, with_shared, ticket, stream);
+                                   expert_offsets, sorted_token, sorted_scale, pair_pos, with_shared, workspace,
+                                   workspace_bytes, stream);
 }
 
 static int add_rmsnorm_router_impl(const void* x, const float* part, int nslices, int64_t slice_stride,
@@ -619,8 +688,8 @@ static int add_rmsnorm_router_impl(const void* x, const float* part, int nslices
                                    void* residual_out, const void* gate_w, const float* e_score_correction_bias,
                                    int64_t* topk_idx, void* topk_w, int64_t T, int H, int E, int k,
                                    float routed_scaling_factor, int32_t* expert_offsets, int32_t* sorted_token,
-                                   void* sorted_scale, int32_t* pair_pos, int with_shared, uint32_t* ticket,
-                                   glm_stream_t stream) {
+                                   void* sorted_scale, int32_t* pair_pos, int with_shared, uint32_t* workspace,
+                                   size_t workspace_bytes, glm_stream_t stream) {
     GLM_CHECK_ARG((x != nullptr) != (part != nullptr), GLM_ERR_INVALID,
                   "glm_add_rmsnorm_router_topk: give either x (bf16) or part (fp32 partial sums)");
     GLM_CHECK_ARG(residual_in && norm_weight && y && residual_out && gate_w && e_score_correction_bias && topk_idx &&
@@ -640,13 +709,23 @@ static int add_rmsnorm_router_impl(const void* x, const float* part, int nslices
     pre.res_in = (const bf16_t*)residual_in; pre.norm_w = (const bf16_t*)norm_weight; pre.y = (bf16_t*)y;
     pre.res_out = (bf16_t*)residual_out; pre.eps = eps;
     pre.al_offsets = expert_offsets; pre.al_token = sorted_token; pre.al_scale = (bf16_t*)sorted_scale;
-    pre.al_pos = pair_pos; pre.al_with_shared = with_shared; pre.ticket = ticket;
+    pre.al_pos = pair_pos; pre.al_with_shared = with_shared; pre.ticket = workspace;
+    pre.tok_ticket = nullptr; pre.lg_global = nullptr;
+    // experts of a token over several workgroups (16 gate rows each) when the workspace holds the logits and the tickets
+    unsigned G = 1;
+    if (workspace != nullptr && E >= 32 && T <= (int64_t)ROUTER_WS_TICKETS &&
+        workspace_bytes >= ROUTER_WS_HEAD + (size_t)T * E * sizeof(float)) {
+        G = (unsigned)((E + 15) / 16);
+        pre.tok_ticket = workspace + 16;
+        pre.lg_global = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ROUTER_WS_HEAD);
+    }
+    const dim3 grid((unsigned)T, G);
     if (x)
-        hipLaunchKernelGGL(router_topk_kernel<1>, dim3((unsigned)T), dim3(ROUTER_NT), shm, glm_s(stream), (const bf16_t*)y,
+        hipLaunchKernelGGL(router_topk_kernel<1>, grid, dim3(ROUTER_NT), shm, glm_s(stream), (const bf16_t*)y,
                            (const bf16_t*)gate_w, e_score_correction_bias, topk_idx, (bf16_t*)topk_w, (bf16_t*)nullptr, H, E,
                            k, routed_scaling_factor, pre);
     else
-        hipLaunchKernelGGL(router_topk_kernel<2>, dim3((unsigned)T), dim3(ROUTER_NT), shm, glm_s(stream), (const bf16_t*)y,
+        hipLaunchKernelGGL(router_topk_kernel<2>, grid, dim3(ROUTER_NT), shm, glm_s(stream), (const bf16_t*)y,
                            (const bf16_t*)gate_w, e_score_correction_bias, topk_idx, (bf16_t*)topk_w, (bf16_t*)nullptr, H, E,
                            k, routed_scaling_factor, pre);
     GLM_CHECK_LAUNCH("glm_add_rmsnorm_router_topk");

@@ -517,17 +517,9 @@ static int pa_launch(const void* q, const void* k_cache, const void* v_cache, co
         // in-kernel merge by the last-arriving split when the counters fit; else the separate reduce launch
         if ((size_t)B * nkv * sizeof(unsigned) <= PA_TICKET_BYTES) tickets = (unsigned*)workspace;
     }
-    static bool attr_set[2] = {false, false};
     const int fz = fuse != nullptr;
-    if (!attr_set[fz]) {
-        const void* fn = fz ? (const void*)paged_attn_decode_kernel<1> : (const void*)paged_attn_decode_kernel<0>;
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PA_LDS);
-        if (e != hipSuccess) {
-            glm_set_error("%s: hipFuncSetAttribute(%d B LDS): %s", name, PA_LDS, hipGetErrorString(e));
-            return GLM_ERR_LAUNCH;
-        }
-        attr_set[fz] = true;
-    }
+    if (fz) GLM_SET_MAX_LDS(paged_attn_decode_kernel<1>, PA_LDS, name);
+    else GLM_SET_MAX_LDS(paged_attn_decode_kernel<0>, PA_LDS, name);
     hipStream_t st = glm_s(stream);
     const float scale_log2e = scale * 1.4426950408889634f;
     const dim3 grid((unsigned)splits, (unsigned)nkv, (unsigned)B);

@@ -519,17 +519,9 @@ extern "C" int glm_varlen_attn_prefill(const void* q, const void* k, const void*
     GLM_CHECK_ARG(glm_aligned16(q) && glm_aligned16(k) && glm_aligned16(v) && glm_aligned16(out),
                   GLM_ERR_INVALID, "glm_varlen_attn_prefill: pointers must be 16-byte aligned");
     if (B == 0 || max_seqlen_q == 0) return GLM_OK;
-    static bool attr_set[2] = {false, false};
     const int paged = block_tables != nullptr;
-    if (!attr_set[paged]) {
-        const void* fn = paged ? (const void*)prefill_attn_kernel<true> : (const void*)prefill_attn_kernel<false>;
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FA_STAGE + FA_MAX_BT * 4);
-        if (e != hipSuccess) {
-            glm_set_error("glm_varlen_attn_prefill: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return GLM_ERR_LAUNCH;
-        }
-        attr_set[paged] = true;
-    }
+    if (paged) GLM_SET_MAX_LDS(prefill_attn_kernel<true>, 2 * FA_STAGE + FA_MAX_BT * 4, "glm_varlen_attn_prefill");
+    else GLM_SET_MAX_LDS(prefill_attn_kernel<false>, 2 * FA_STAGE + FA_MAX_BT * 4, "glm_varlen_attn_prefill");
     const int nqblk = (max_seqlen_q + FA_BQ - 1) / FA_BQ;
     const int64_t total = (int64_t)nqblk * nh * B;
     GLM_CHECK_ARG(total < (int64_t)1 << 31, GLM_ERR_UNSUPPORTED, "glm_varlen_attn_prefill: grid too large");

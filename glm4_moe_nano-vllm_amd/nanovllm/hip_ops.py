@@ -78,7 +78,8 @@ _SIGNATURES = {
     "glm_add_rmsnorm_router_topk_align": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_float,
                                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                                   c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
-                                                  c_int, c_void_p, c_void_p]),
+                                                  c_int, c_void_p, c_size_t, c_void_p]),
+    "glm_router_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "glm_gather_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "glm_scatter_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "glm_moe_combine_scaled": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,
@@ -379,17 +380,23 @@ def router_topk(x: torch.Tensor, gate_w: torch.Tensor, bias: torch.Tensor, k: in
     return (idx, w, logits) if return_logits else (idx, w)
 
 
-_tickets: dict = {}
+_router_ws: dict = {}
+_router_ws_retired: list = []
 
 
-def _ticket(device) -> torch.Tensor:
-    """The zero-initialised arrival counter of the fused router + align launch (one per device; the kernel restores
-    the zero, and launches on one device are stream-ordered in this engine)."""
-    t = _tickets.get(device)
-    if t is None:
-        t = torch.zeros(4, dtype=torch.int32, device=device)
-        _tickets[device] = t
-    return t
+def _router_workspace(device, T: int, E: int) -> torch.Tensor:
+    """Workspace of the fused router + align launch (arrival counters, zero-initialised and restored by the kernel, then
+    the T x E logits scratch): one grow-only buffer per (device, stream); a replaced buffer stays referenced because
+    HIP graphs captured earlier hold its address."""
+    need = load_library().glm_router_workspace_bytes(T, E)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _router_ws.get(key)
+    if ws is None or ws.numel() < need:
+        if ws is not None:
+            _router_ws_retired.append(ws)
+        ws = torch.zeros(need, dtype=torch.uint8, device=device)
+        _router_ws[key] = ws
+    return ws
 
 
 def add_rmsnorm_router_topk(x, residual: torch.Tensor, norm_weight: torch.Tensor, eps: float,
@@ -424,9 +431,10 @@ def add_rmsnorm_router_topk(x, residual: torch.Tensor, norm_weight: torch.Tensor
         tok = torch.empty(R, dtype=torch.int32, device=dev)
         scale = torch.empty(R, dtype=torch.bfloat16, device=dev)
         pos = torch.empty(T * k, dtype=torch.int32, device=dev)
+        rws = _router_workspace(dev, T, E)
         _check(load_library().glm_add_rmsnorm_router_topk_align(
             xp, pp, ns, stride, _p(r2), _p(norm_weight), eps, _p(y), _p(ro), _p(gate_w), _p(bias), _p(idx), _p(w), T, H,
-            E, k, routed_scaling_factor, _p(offs), _p(tok), _p(scale), _p(pos), 1 if ws else 0, _p(_ticket(dev)),
+            E, k, routed_scaling_factor, _p(offs), _p(tok), _p(scale), _p(pos), 1 if ws else 0, _p(rws), rws.numel(),
             _stream()), "glm_add_rmsnorm_router_topk_align")
         return y.view(residual.shape), ro.view(residual.shape), idx, w, (offs, tok, scale, pos)
     _check(load_library().glm_add_rmsnorm_router_topk(xp, pp, ns, stride, _p(r2), _p(norm_weight), eps, _p(y), _p(ro),

@@ -231,15 +231,19 @@ int glm_add_rmsnorm_router_topk(const void* x, const float* part, int nslices, i
                                 float routed_scaling_factor, glm_stream_t stream);
 /*     … and glm_moe_align in the same launch: the workgroup that finishes last (agent-scope release / ticket /
  *     acquire, no co-residency or placement assumption) buckets all T*k pairs.  expert_offsets … pair_pos as
- *     glm_moe_align.  ticket: one uint32 that is ZERO before the first launch on it (the kernel puts the zero back);
- *     launches sharing a ticket must be stream-ordered.  Needs 8 (E + 1) <= 2 H bytes of LDS reuse.                */
+ *     glm_moe_align.  With E >= 32 the experts of a token are also split over ceil(E / 16) workgroups (a CU pulls
+ *     1/4 of the gate matrix at E = 64 instead of all of it); the last of them to finish gathers the token's logits
+ *     and selects.  workspace: glm_router_workspace_bytes(T, E) bytes, 16-byte aligned; its first 262208 bytes
+ *     (arrival counters) must be ZERO before the first launch on it — the kernel puts the zeros back; launches
+ *     sharing a workspace must be stream-ordered.  Needs 8 (E + 1) <= 2 H bytes of LDS reuse.                    */
+size_t glm_router_workspace_bytes(int64_t T, int E);
 int glm_add_rmsnorm_router_topk_align(const void* x, const float* part, int nslices, int64_t slice_stride,
                                       const void* residual_in, const void* norm_weight, float eps, void* y,
                                       void* residual_out, const void* gate_w, const float* e_score_correction_bias,
                                       int64_t* topk_idx, void* topk_w, int64_t T, int H, int E, int k,
                                       float routed_scaling_factor, int32_t* expert_offsets, int32_t* sorted_token,
-                                      void* sorted_scale, int32_t* pair_pos, int with_shared, uint32_t* ticket,
-                                      glm_stream_t stream);
+                                      void* sorted_scale, int32_t* pair_pos, int with_shared, uint32_t* workspace,
+                                      size_t workspace_bytes, glm_stream_t stream);
 
 /* a12+a3 fused: glm_moe_combine of layer i and the input add-RMSNorm of layer i+1 (decode_layer.py:47-49) in one
  *     launch at TP=1: out = normalised rows, residual_out = bf16(combine + residual_in).  H <= 16384.            */
