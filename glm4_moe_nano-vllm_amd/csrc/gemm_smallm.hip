@@ -659,7 +659,9 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_smallm_dma_kernel(const Gemm
 //     reading chunk it-1, whose stage is refilled with chunk it+2 right after the fragment reads.
 //   * fp8 weights are converted to bf16 fragments in registers exactly as in smallm_body (one 16-byte LDS read = two
 //     k-steps of a lane), the row scale multiplies the fp32 accumulator.
-template <int MODE, int NW, int RT, int MT, bool W8>
+//   * NST = 2 (GLM_SM_SX_STAGES): two stages and a SECOND barrier per chunk (after the fragment reads, before the
+//     refill of the stage just read): 80 KiB per workgroup, i.e. two workgroups = 8 waves per CU instead of 4.
+template <int MODE, int NW, int RT, int MT, bool W8, int NST>
 __device__ __forceinline__ void smallm_body_sx(const GemmParams& p, char* smem, int grp, int m0, int mcnt) {
     static_assert((RT == 1 || RT == 2 || RT == 4) && MT <= 2, "1/2/4 row tiles, at most 2 token tiles");
     constexpr int KC = W8 ? 256 : 128;            // k per chunk: 256 B per weight row
@@ -713,7 +715,7 @@ __device__ __forceinline__ void smallm_body_sx(const GemmParams& p, char* smem, 
     }
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
     auto issue = [&](int ci) {
-        char* st = smem + (ci % 3) * STAGE;
+        char* st = smem + (ci % NST) * STAGE;
         const int k0 = ci * KC;
 #pragma unroll
         for (int i = 0; i < NW_DMA; ++i) {
@@ -752,7 +754,7 @@ __device__ __forceinline__ void smallm_body_sx(const GemmParams& p, char* smem, 
         if (it + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const unsigned sb = rbase + (it % 3) * STAGE;
+        const unsigned sb = rbase + (it % NST) * STAGE;
         u32x4_t af[RT][4], bfr[MT][NKS];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -790,7 +792,9 @@ __device__ __forceinline__ void smallm_body_sx(const GemmParams& p, char* smem, 
                          "+v"(bfr[0][3]), "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(bfr[1][2]), "+v"(bfr[1][3])::"memory");
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (it + 2 < nchunks) issue(it + 2);  // stage (it+2)%3 == (it-1)%3: everyone is past it (barrier above)
+        if (NST == 2) __builtin_amdgcn_s_barrier();  // every wave holds its fragments of this stage: it may be refilled
+        // NST 3: stage (it+2)%3 == (it-1)%3, everyone is past it (barrier at the top); NST 2: the stage just read
+        if (it + 2 < nchunks) issue(it + 2);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
@@ -831,28 +835,32 @@ __device__ __forceinline__ void smallm_body_sx(const GemmParams& p, char* smem, 
     smallm_epilogue<MODE, RT, MT>(p, acc, grp, m0, mcnt, ncol0, c, g4);
 }
 
+#ifndef GLM_SM_SX_STAGES
+#define GLM_SM_SX_STAGES 2
+#endif
 template <int MODE, int NW, int RT, int MTMAX, bool W8>
 __global__ __launch_bounds__(NW * 64) void gemm_smallm_sx_kernel(const GemmParams p) {
     constexpr int MB = 16 * MTMAX;
-    constexpr int RING = 3 * (NW * 16 * RT * 256 + 16 * MTMAX * (W8 ? 512 : 256));
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* sh = reinterpret_cast<int*>(smem + RING);
+    // the block search borrows the start of the ring (80 KiB x 2 workgroups leaves the CU no byte to spare)
+    int* sh = reinterpret_cast<int*>(smem);
     glm_locate_block(p.offs, p.G, p.R, MB, blockIdx.y, sh);
     __syncthreads();
     const int grp = sh[0];
-    if (grp < 0) return;
     const int m0 = sh[1], mcnt = sh[2];
-    if (mcnt <= 16) smallm_body_sx<MODE, NW, RT, 1, W8>(p, smem, grp, m0, mcnt);
-    else smallm_body_sx<MODE, NW, RT, (MTMAX < 2 ? MTMAX : 2), W8>(p, smem, grp, m0, mcnt);
+    __syncthreads();  // everyone has read sh before the first DMA lands on it
+    if (grp < 0) return;
+    if (mcnt <= 16) smallm_body_sx<MODE, NW, RT, 1, W8, GLM_SM_SX_STAGES>(p, smem, grp, m0, mcnt);
+    else smallm_body_sx<MODE, NW, RT, (MTMAX < 2 ? MTMAX : 2), W8, GLM_SM_SX_STAGES>(p, smem, grp, m0, mcnt);
 }
 
 template <int MODE, int NW, int RT, int MTMAX, bool W8>
 int launch_cfg_sx(const GemmParams& p, hipStream_t st) {
     static_assert(MTMAX <= 2, "the shared-activation body stages at most 32 token rows");
     constexpr int MB = 16 * MTMAX;
-    constexpr int RING = 3 * (NW * 16 * RT * 256 + 16 * MTMAX * (W8 ? 512 : 256));
-    static_assert(RING + 16 <= 160 * 1024, "the ring must fit the CU's 160 KiB of LDS");
-    constexpr int LDS = RING + 16;
+    constexpr int RING = GLM_SM_SX_STAGES * (NW * 16 * RT * 256 + 16 * MTMAX * (W8 ? 512 : 256));
+    static_assert(RING <= 160 * 1024, "the ring must fit the CU's 160 KiB of LDS");
+    constexpr int LDS = RING;
     const int cols_per_wg = MODE == GEMM_GATEUP ? NW * 8 * RT : NW * RT * 16;
     const unsigned gx = (unsigned)((p.N + cols_per_wg - 1) / cols_per_wg);
     const int64_t combos = p.offs ? (p.R / MB + p.G) : (p.R + MB - 1) / MB;
@@ -1044,8 +1052,14 @@ int glm_launch_gemm_smallm_fp8w(int mode, const GemmParams& p, hipStream_t st) {
     // shared-activation LDS-DMA body (4 waves, 64 act / 128 down columns per workgroup) from two sequences on;
     // a single sequence (k + 1 rows in as many groups) keeps the VGPR body.  -DGLM_SM_FP8_NO_SX: VGPR body everywhere.
 #ifndef GLM_SM_FP8_NO_SX
-    if (p.R > 16 && mode == GEMM_GATEUP) return launch_cfg_sx<GEMM_GATEUP, 4, 2, 2, true>(p, st);
-    if (p.R > 16 && mode == GEMM_DOWN) return launch_cfg_sx<GEMM_DOWN, 4, 2, 2, true>(p, st);
+    // 16-row blocks (a 32-row group such as the shared expert at bs=32 re-reads its weights once): 80 KiB per workgroup
+    // r02, 12 layers at bs=32 (same box): gate|up 144.7 us (best 135.0) vs 149.0 (142.0) for the VGPR body; down 74.2 vs
+    // 71.3 -> the shared-activation body for gate|up only (-DGLM_SM_FP8_SX_DOWN adds down); 3 stages at one
+    // workgroup per CU measured 165.7 / 91.1
+    if (p.R > 16 && mode == GEMM_GATEUP) return launch_cfg_sx<GEMM_GATEUP, 4, 2, 1, true>(p, st);
+#ifdef GLM_SM_FP8_SX_DOWN
+    if (p.R > 16 && mode == GEMM_DOWN) return launch_cfg_sx<GEMM_DOWN, 4, 2, 1, true>(p, st);
+#endif
 #endif
     if (mode == GEMM_GATEUP) return launch_cfg<GEMM_GATEUP, GLM_SM_CFG_GATEUP_W8, true>(p, st);
     if (mode == GEMM_DOWN) return launch_cfg<GEMM_DOWN, GLM_SM_CFG_DOWN_W8, true>(p, st);
