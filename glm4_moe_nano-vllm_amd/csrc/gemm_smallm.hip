@@ -418,6 +418,21 @@ __device__ __forceinline__ void sm_lds_wait(u32x4_t (&a)[NA][4], u32x4_t (&b)[NB
     }
 }
 
+// counted wait with a run-time count (wave-uniform): leave the newest `n` vector-memory operations in flight
+template <int LO, int HI>
+__device__ __forceinline__ void sm_wait_leave(int n) {
+    if constexpr (LO >= HI) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LO) : "memory");
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (n <= MID) sm_wait_leave<LO, MID>(n);
+        else sm_wait_leave<MID + 1, HI>(n);
+    }
+}
+#ifndef GLM_SM_XSKIP
+#define GLM_SM_XSKIP 1  // do not fetch activation rows beyond the block's row count (their outputs are never stored)
+#endif
+
 // TPW > 1 (grouped modes, WS == 1): a wave walks TPW consecutive column tiles as ONE stream — the ring keeps
 // prefetching across tile boundaries, so the start-up and drain bubbles of a short K (down: 11 chunks) are paid once
 // per TPW tiles; results are stored at each tile's last chunk.
@@ -480,6 +495,10 @@ __device__ __forceinline__ void smallm_body_dma(const GemmParams& p, char* smem,
         }
     }
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+    // activation DMA instructions that carry at least one real row (4 rows each); the rest of the tile keeps whatever
+    // the LDS held: those token columns of the MFMAs are garbage that the epilogue never stores
+    const int nx_eff = GLM_SM_XSKIP ? min(NX_DMA, (mcnt + 3) >> 2) : NX_DMA;
+    const int ndma_eff = NW_DMA + nx_eff;
     // number of column tiles of this wave that exist
     int ntv = 1;
     if (TPW > 1) {
@@ -498,7 +517,7 @@ __device__ __forceinline__ void smallm_body_dma(const GemmParams& p, char* smem,
             sm_glds16<2>(k0 + wk[i] < K ? wsrc[i] + wo + k0 + wk[i] : zero, st + i * 1024);
 #pragma unroll
         for (int i = 0; i < NX_DMA; ++i)
-            sm_glds16<0>(k0 + xk[i] < K ? xsrc[i] + k0 + xk[i] : zero, st + WT + i * 1024);
+            if (i < nx_eff) sm_glds16<0>(k0 + xk[i] < K ? xsrc[i] + k0 + xk[i] : zero, st + WT + i * 1024);
         if (++is_c == nmine) {
             is_c = 0;
             ++is_t;
@@ -521,7 +540,7 @@ __device__ __forceinline__ void smallm_body_dma(const GemmParams& p, char* smem,
     const unsigned rbase = (unsigned)(uintptr_t)(const sm_lds_void*)ring;
     int cs_t = 0, cs_c = 0;  // (tile, chunk) being consumed
     for (int it = 0; it < total; ++it) {
-        if (it + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NDMA) : "memory");
+        if (it + 1 < total) sm_wait_leave<NW_DMA + 1, NDMA>(ndma_eff);
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned sb = rbase + (it & 1) * STAGE;
         u32x4_t af[RT][4], bfr[MT][4];

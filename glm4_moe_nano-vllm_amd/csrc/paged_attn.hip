@@ -100,7 +100,8 @@ struct PaFuse {
     const bf16_t* qkv;     // [B, (nh + 2 nkv) * 128]
     int64_t qkv_stride;    // elements per row
     const int64_t* pos;    // [B]
-    const float* cos_sin;  // [max_pos, rotary_dim] fp32: cos | sin halves
+    const float* cos_sin;  // [n_pos, rotary_dim] fp32: cos | sin halves
+    int64_t n_pos;         // rows of cos_sin: positions are clamped into it (a padding row's position is arbitrary)
     const int32_t* slots;  // [B] cache slot of the new token
     int64_t n_slots;
     bf16_t* kc_w;          // writable views of the caches
@@ -164,7 +165,8 @@ __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
             if (hv) v[ks] = *reinterpret_cast<const u32x4_t*>(qrow + 32 * ks + 8 * g);
         }
         if (FUSED) {  // rotary_dim 64: chunk g of the first half pairs with chunk g of the second half
-            const float* cosp = fu.cos_sin + fu.pos[b] * 64 + 8 * g;
+            const int64_t ps = min(max(fu.pos[b], (int64_t)0), fu.n_pos - 1);
+            const float* cosp = fu.cos_sin + ps * 64 + 8 * g;
             u32x4_t y1, y2;
             pa_rope8(v[0], v[1], cosp, cosp + 32, y1, y2);
             v[0] = y1;
@@ -185,7 +187,8 @@ __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
             if (is_k && sub < 8) {
                 const int partner = sub < 4 ? sub + 4 : sub - 4;
                 const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(row + partner * 8);
-                const float* cosp = fu.cos_sin + fu.pos[b] * 64 + 8 * (sub & 3);
+                const int64_t ps = min(max(fu.pos[b], (int64_t)0), fu.n_pos - 1);
+                const float* cosp = fu.cos_sin + ps * 64 + 8 * (sub & 3);
                 u32x4_t y1, y2;
                 if (sub < 4) {
                     pa_rope8(xv, pv, cosp, cosp + 32, y1, y2);
@@ -561,7 +564,8 @@ extern "C" int glm_paged_attn_decode(const void* q, const void* k_cache, const v
 }
 
 extern "C" int glm_paged_attn_decode_qkv(const void* qkv, int64_t qkv_stride, const int64_t* positions,
-                                         const float* cos_sin_cache, int rotary_dim, const int32_t* slot_mapping,
+                                         const float* cos_sin_cache, int64_t n_pos, int rotary_dim,
+                                         const int32_t* slot_mapping,
                                          void* k_cache, void* v_cache, const int32_t* context_lens,
                                          const int32_t* block_tables, int64_t bt_stride, void* out, int64_t B,
                                          int nh, int nkv, int hd, int block_size, int64_t n_blocks, float scale,
@@ -569,13 +573,14 @@ extern "C" int glm_paged_attn_decode_qkv(const void* qkv, int64_t qkv_stride, co
                                          size_t workspace_bytes, glm_stream_t stream) {
     GLM_CHECK_ARG(qkv && positions && cos_sin_cache && slot_mapping && k_cache && v_cache && context_lens &&
                       block_tables && out, GLM_ERR_INVALID, "glm_paged_attn_decode_qkv: null pointer");
+    GLM_CHECK_ARG(n_pos > 0, GLM_ERR_INVALID, "glm_paged_attn_decode_qkv: empty cos_sin_cache");
     GLM_CHECK_ARG(rotary_dim == 64 && qkv_stride >= (int64_t)(nh + 2 * nkv) * hd && qkv_stride % 8 == 0 && n_blocks > 0,
                   GLM_ERR_UNSUPPORTED, "glm_paged_attn_decode_qkv: needs rotary_dim=64 (got %d) and a packed qkv row",
                   rotary_dim);
     GLM_CHECK_ARG(glm_aligned16(qkv) && glm_aligned16(k_cache) && glm_aligned16(v_cache) && glm_aligned16(out),
                   GLM_ERR_INVALID, "glm_paged_attn_decode_qkv: pointers must be 16-byte aligned");
     PaFuse fu;
-    fu.qkv = (const bf16_t*)qkv; fu.qkv_stride = qkv_stride; fu.pos = positions; fu.cos_sin = cos_sin_cache;
+    fu.qkv = (const bf16_t*)qkv; fu.qkv_stride = qkv_stride; fu.pos = positions; fu.cos_sin = cos_sin_cache; fu.n_pos = n_pos;
     fu.slots = slot_mapping; fu.n_slots = n_blocks * block_size; fu.kc_w = (bf16_t*)k_cache; fu.vc_w = (bf16_t*)v_cache;
     return pa_launch(nullptr, k_cache, v_cache, context_lens, block_tables, bt_stride, out, B, nh, nkv, hd, block_size,
                      scale, num_splits, max_context_len, workspace, workspace_bytes, stream, &fu,

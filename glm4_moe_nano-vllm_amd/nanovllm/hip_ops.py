@@ -43,7 +43,7 @@ _SIGNATURES = {
     "glm_paged_attn_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64,
                                       c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
-    "glm_paged_attn_decode_qkv": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+    "glm_paged_attn_decode_qkv": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                           c_int64, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "glm_varlen_attn_prefill": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -338,7 +338,8 @@ def paged_attn_decode_qkv(qkv: torch.Tensor, nh: int, nkv: int, hd: int, positio
     need = attn_workspace_bytes(B, nh, nkv, hd, block_size, block_tables.stride(0), num_splits, max_context_len)
     ws = _attn_workspace(qkv.device, need)
     out = torch.empty((B, nh, hd), dtype=qkv.dtype, device=qkv.device)
-    _check(lib.glm_paged_attn_decode_qkv(_p(qkv), qkv.stride(0), _p(positions), _p(cos_sin_cache), rotary_dim,
+    _check(lib.glm_paged_attn_decode_qkv(_p(qkv), qkv.stride(0), _p(positions), _p(cos_sin_cache),
+                                         cos_sin_cache.numel() // rotary_dim, rotary_dim,
                                          _p(slot_mapping), _p(k_cache), _p(v_cache), _p(context_lens),
                                          _p(block_tables), block_tables.stride(0), _p(out), B, nh, nkv, hd,
                                          block_size, n_blocks, scale, num_splits, max_context_len, _p(ws),

@@ -15,7 +15,7 @@ from nanovllm import hip_ops
 from nanovllm.distributed.parallel_state import get_tp_group
 from nanovllm.layers.activation import SiluAndMul
 from nanovllm.layers.linear import MergedColumnParallelLinear, RowParallelLinear
-from nanovllm.utils.loader import load_prefixed
+from nanovllm.utils.loader import load_one
 
 
 class Glm4MoeMLP(nn.Module):
@@ -56,9 +56,7 @@ class Glm4MoeMLP(nn.Module):
         return out
 
     def load_weights(self, model_dir: str, prefix: str):
-        sd = load_prefixed(model_dir, prefix)
-        pick = lambda suffix: next((v for k, v in sd.items() if k.endswith(suffix)), None)
-        gate_w, up_w, down_w = pick("gate_proj.weight"), pick("up_proj.weight"), pick("down_proj.weight")
+        gate_w, up_w, down_w = (load_one(model_dir, f"{prefix}.{n}.weight") for n in ("gate_proj", "up_proj", "down_proj"))
         assert gate_w is not None and up_w is not None and down_w is not None, f"MLP weights missing under {prefix}"
         self.gate_up_proj.weight_loader(self.gate_up_proj.weight, gate_w, 0)
         self.gate_up_proj.weight_loader(self.gate_up_proj.weight, up_w, 1)

@@ -16,7 +16,7 @@ import torch.nn as nn
 from nanovllm import hip_ops
 from nanovllm.distributed import expert_parallel as EP
 from nanovllm.distributed.parallel_state import get_tp_group, unsharded
-from nanovllm.utils.loader import load_prefixed
+from nanovllm.utils.loader import load_one
 from .mlp import Glm4MoeMLP
 
 
@@ -110,13 +110,13 @@ class Glm4MoeMoE(nn.Module):
 
     # ---- weights ------------------------------------------------------------------------
     def load_weights(self, path: str, prefix: str):
-        sd = load_prefixed(path, prefix)
-        if not sd:
-            raise ValueError(f"No tensors with prefix '{prefix}' found in '{path}'")
-        if f"{prefix}.gate.weight" in sd:
-            self.gate.weight.data.copy_(sd[f"{prefix}.gate.weight"])
-        if f"{prefix}.gate.e_score_correction_bias" in sd:
-            self.gate.e_score_correction_bias.copy_(sd[f"{prefix}.gate.e_score_correction_bias"])
+        gw = load_one(path, f"{prefix}.gate.weight")
+        if gw is None:
+            raise ValueError(f"No tensor '{prefix}.gate.weight' found in '{path}'")
+        self.gate.weight.data.copy_(gw)
+        gb = load_one(path, f"{prefix}.gate.e_score_correction_bias")
+        if gb is not None:
+            self.gate.e_score_correction_bias.copy_(gb)
         self._stacked()
         for expert, gid in zip(self.experts, self.expert_ids):
             expert.load_weights(path, f"{prefix}.experts.{gid}")

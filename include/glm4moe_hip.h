@@ -256,7 +256,7 @@ int glm_moe_combine_add_rmsnorm(const void* y, int64_t ldy, const int32_t* pair_
  *     the new K row and stores K/V at slot_mapping[b] (layers/attention.py:10-42) before it reads them back.
  *     Same results as glm_qkv_split_norm_rope_store followed by glm_paged_attn_decode.                       */
 int glm_paged_attn_decode_qkv(const void* qkv, int64_t qkv_stride, const int64_t* positions,
-                              const float* cos_sin_cache, int rotary_dim, const int32_t* slot_mapping,
+                              const float* cos_sin_cache, int64_t n_pos, int rotary_dim, const int32_t* slot_mapping,
                               void* k_cache, void* v_cache, const int32_t* context_lens,
                               const int32_t* block_tables, int64_t bt_stride, void* out, int64_t B,
                               int nh, int nkv, int hd, int block_size, int64_t n_blocks, float scale,
