@@ -49,14 +49,19 @@ def air64e_config(layers: int, max_pos: int):
 
 
 def init_weights(model, seed: int):
-    g = torch.Generator(device="cuda").manual_seed(seed)
+    """Every tensor from its own generator seeded by (seed, name): replicated tensors (router, norms, embedding) agree on
+    every rank even when the ranks own different parameter sets (expert parallelism)."""
+    import zlib
+    g = torch.Generator(device="cuda")
     for name, p in model.named_parameters():
+        g.manual_seed(seed + zlib.crc32(name.encode()))
         if "layernorm" in name or name.endswith("norm.weight"):
             p.data.normal_(0.0, 0.02, generator=g).add_(1.0)
         else:
             p.data.normal_(0.0, 0.02, generator=g)
     for name, b in model.named_buffers():
         if name.endswith("e_score_correction_bias"):
+            g.manual_seed(seed + zlib.crc32(name.encode()))
             b.uniform_(-0.1, 0.1, generator=g)
 
 
@@ -88,6 +93,10 @@ def main():
     ap.add_argument("--emulate-tp", type=int, default=1,
                     help="kernel-shape study on ONE GPU: run the per-rank shapes of TP=N (heads, kv heads, expert/MLP "
                          "intermediate size and vocabulary divided by N) without any collective; not a benchmark result")
+    ap.add_argument("--expert-parallel", action="store_true",
+                    help="BASELINE config 4 flavour: the experts are partitioned over the ranks (E/N each, full intermediate "
+                         "size) and token rows travel by all-to-all-v; attention stays tensor-parallel.  Eager launches "
+                         "(the split sizes are host integers).  The headline run is the default (TP only)")
     ap.add_argument("--probe-capture", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--graph-body-only", action="store_true",
                     help="debug: at 1 GPU, capture only the layer stack and run the lm_head eagerly (the TP>1 arrangement)")
@@ -145,6 +154,9 @@ def main():
         cfg.vocab_size //= n
     if args.fp8_experts:
         cfg.expert_weight_dtype = "fp8_e4m3"
+    if args.expert_parallel and world > 1:
+        cfg.expert_parallel_size = world
+        args.no_graph = True
     torch.set_default_dtype(torch.bfloat16)
     t0 = time.time()
     with torch.device(dev):
@@ -282,7 +294,8 @@ def main():
             "config": {"workload": f"GLM-4-MoE Air-64E decode bs={B} ctx={ctx} L={L} (layer0 dense), "
                                    f"random-init bf16, paged KV block 256, greedy",
                        "global_batch": B, "seq_len": ctx, "layers": L,
-                       "parallelism": f"tp{world}", "hip_graph": bool(use_graph), "hip_graph_note": graph_note,
+                       "parallelism": f"tp{world}" + (f"+ep{world}" if getattr(cfg, "expert_parallel_size", 1) > 1 else ""),
+                       "hip_graph": bool(use_graph), "hip_graph_note": graph_note,
                        "ms_per_layer": round(ms_per_step / L, 4), "model_build_s": round(t_build, 1)},
             "roofline": dom,
             "kernels": kernels,

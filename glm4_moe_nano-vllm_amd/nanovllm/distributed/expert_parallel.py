@@ -99,28 +99,39 @@ class EPExperts:
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def _staged(group) -> bool:
+    """gloo has no device all-to-all: the one-GPU rehearsal of the multi-rank control flow stages through the host."""
+    return dist.get_backend(group) == "gloo"
+
+
 def run(gen, group=None):
-    """Drive one rank's generator with torch.distributed collectives."""
+    """Drive one rank's generator with torch.distributed collectives (RCCL; gloo in CPU tests and rehearsals)."""
+    host = _staged(group)
     try:
         req = next(gen)
         while True:
             op = req[0]
+            dev = req[1].device
+            stage = (lambda x: x.cpu()) if host and dev.type != "cpu" else (lambda x: x)
             if op == "all_gather":
-                t = req[1]
+                t = stage(req[1].contiguous())
                 outl = torch.empty(dist.get_world_size(group) * t.numel(), dtype=t.dtype, device=t.device)
-                dist.all_gather_into_tensor(outl, t.contiguous(), group=group)
-                res = outl
+                dist.all_gather_into_tensor(outl, t, group=group)
+                res = outl.to(dev)
             elif op == "all_to_all":
                 _, t, in_splits, out_splits = req
+                t = stage(t.contiguous())
                 res = torch.empty((int(sum(out_splits)), t.shape[1]), dtype=t.dtype, device=t.device)
-                dist.all_to_all_single(res, t.contiguous(), out_splits, in_splits, group=group)
+                dist.all_to_all_single(res, t, out_splits, in_splits, group=group)
+                res = res.to(dev)
             elif op == "all_gather_rows":
                 _, t, sizes = req
                 per, world = max(sizes), len(sizes)  # slices are equal except the last: pad to one fixed-size gather
                 padded = t if t.shape[0] == per else torch.cat([t, t.new_zeros((per - t.shape[0], t.shape[1]))])
-                buf = torch.empty((world * per, t.shape[1]), dtype=t.dtype, device=t.device)
-                dist.all_gather_into_tensor(buf, padded.contiguous(), group=group)
-                res = torch.cat([buf[r * per:r * per + n] for r, n in enumerate(sizes)], dim=0)
+                padded = stage(padded.contiguous())
+                buf = torch.empty((world * per, t.shape[1]), dtype=t.dtype, device=padded.device)
+                dist.all_gather_into_tensor(buf, padded, group=group)
+                res = torch.cat([buf[r * per:r * per + n] for r, n in enumerate(sizes)], dim=0).to(dev)
             else:  # pragma: no cover
                 raise RuntimeError(f"unknown collective {op}")
             req = gen.send(res)

@@ -171,3 +171,50 @@ def test_moe_module_fp8_experts():
     # and close to the bf16 golden within fp8 quantisation error
     rel = float((out.cpu().float() - t["y"].float()).norm() / t["y"].float().norm())
     assert rel < 0.08, rel
+
+
+@pytest.mark.parametrize("without_residual", [True, False])
+def test_model_final_norm_variants(tmp_path, without_residual):
+    """model.py:75-76: the reference normalises the last MLP output WITHOUT the residual (its add+norm line is commented
+    out — a two-layer debugging state); `config.final_norm_without_residual = False` evaluates the add+norm a full-depth
+    checkpoint needs.  Both against the oracle, cache-less prefill of a tiny 2-layer model."""
+    import types
+    from nanovllm.layers.rotary_embedding import get_rope
+    from nanovllm.models.glm4_moe.model import Glm4MoeForCausalLM
+    from nanovllm.utils.context import reset_context, set_context
+    from util import (oracle_layers_from_checkpoint, tiny_model_config, write_tiny_checkpoint)
+    cfg = tiny_model_config(final_norm_without_residual=without_residual)
+    t = write_tiny_checkpoint(str(tmp_path), cfg, seed=5)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    get_rope.cache_clear()
+    try:
+        with torch.device("cuda"):
+            model = Glm4MoeForCausalLM(types.SimpleNamespace(**cfg))
+    finally:
+        torch.set_default_dtype(old)
+    model.load_weights(str(tmp_path))
+    captured = {}
+    _hook_router(model.model.layers[1], captured)
+    N = 37
+    ids = torch.randint(0, cfg["vocab_size"], (N,), generator=torch.Generator().manual_seed(6))
+    pos = torch.arange(N, dtype=torch.int64)
+    cu = torch.tensor([0, N], dtype=torch.int32)
+    set_context(True, cu.cuda(), cu.cuda(), N, N, None, None, None)
+    with torch.inference_mode():
+        h = model(ids.cuda(), pos.cuda())
+    reset_context()
+    layers = oracle_layers_from_checkpoint(t, cfg)
+    cs = O.build_cos_sin_cache(O.rotary_dim_of(cfg["head_dim"], cfg["partial_rotary_factor"]),
+                               cfg["max_position_embeddings"], cfg["rope_theta"])
+    meta = O.AttnMeta(True, cu_seqlens_q=cu, cu_seqlens_k=cu)
+    traces = [{} for _ in layers]
+    ref = O.model_forward(ids, pos, t["model.embed_tokens.weight"], layers, t["model.norm.weight"], cfg, cs, None, meta,
+                          final_norm_without_residual=without_residual, traces=traces)
+    other = O.model_forward(ids, pos, t["model.embed_tokens.weight"], layers, t["model.norm.weight"], cfg, cs, None, meta,
+                            final_norm_without_residual=not without_residual)
+    assert not torch.allclose(ref.float(), other.float(), atol=0.05), "the two variants must differ for this to test anything"
+    got_idx = captured["idx"].cpu()
+    rows = torch.tensor([r for r in range(N) if set(got_idx[r].tolist()) == set(traces[1]["idx"][r].tolist())])
+    assert len(rows) >= (2 * N) // 3, "too many routing differences"
+    _mixed(h, ref, f"final hidden (without_residual={without_residual})", rows)
