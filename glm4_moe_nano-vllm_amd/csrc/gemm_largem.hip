@@ -67,7 +67,10 @@ struct LmCfg {
     static constexpr int WT = LM_BN * RB;          // weight tile bytes
     static constexpr int XT = BM * RB;
     static constexpr int STAGE = WT + XT;
-    static constexpr int LDS = NSTAGE * STAGE + 16;
+    // the 16 bytes of the tile search normally follow the ring; a ring that takes the CU's whole LDS (5 x 32 KiB) lends
+    // them the tail of its LAST slot, which no DMA targets between the end of a tile's K loop and the next tile's start
+    static constexpr bool ALIAS_SH = NSTAGE * STAGE + 16 > 160 * 1024;
+    static constexpr int LDS = ALIAS_SH ? NSTAGE * STAGE : NSTAGE * STAGE + 16;
     static constexpr int DIST = NSTAGE - 1;        // prefetch distance in tiles
     static constexpr int NF = KS * (4 + MT);       // fragment registers (u32x4) per tile
     // source-chunk permutation that makes the 16-row ds_read_b128 fragment reads conflict free
@@ -75,6 +78,7 @@ struct LmCfg {
 };
 using LmCfgA = LmCfg<128, 64, 3>;
 using LmCfgB = LmCfg<256, 32, 4>;
+using LmCfgB5 = LmCfg<256, 32, 5>;  // variant LM_DEEP: prefetch distance 4
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
@@ -136,7 +140,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 //             An XCD stays in step with itself (its co-resident tiles share operand panels through its L2).
 //   LM_NT     non-temporal epilogue stores (the output is not read again by this kernel).
 constexpr int LM_LEAN = 1, LM_WIDEST = 2, LM_NOSTORE = 4, LM_DMA2 = 8, LM_DMA4 = 16, LM_LDSEPI = 32, LM_DESYNC = 64,
-              LM_NT = 128, LM_EPIORD = 256, LM_NOPRIO = 512, LM_LOADPRIO = 1024;  // issue-priority studies
+              LM_NT = 128, LM_EPIORD = 256, LM_NOPRIO = 512, LM_LOADPRIO = 1024,  // issue-priority studies
+              LM_DEEP = 2048;  // 5-stage ring (all 160 KiB of LDS): one more K tile of prefetch distance
 //   LM_EPIORD the epilogue's global LOADS (per-row scales) are issued before the next tile's ring fill, so that waiting
 //             for them does not drain the fill; and the wait that opens a tile leaves the previous tile's stores in
 //             flight (vmcnt counts in issue order and the fill was issued before them) whenever their number is
@@ -164,7 +169,8 @@ template <int DPW>
 __device__ __forceinline__ void dma_wait_leave(int tiles) {
     if (tiles <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(DPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * DPW) : "memory");
+    else if (tiles == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * DPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * DPW) : "memory");  // 5-stage ring: three tiles stay in flight
 }
 
 // Persistent: one workgroup per CU walks its XCD's contiguous run of tiles with a stride of (workgroups per XCD).
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
     // DMA instructions of a K tile issued from the MFMA phase (the rest from the load phase)
     constexpr int S2 = !LEAN ? 0 : (VAR & LM_DMA4) ? C::DPW : (VAR & LM_DMA2) ? C::DPW / 2 : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* sh = reinterpret_cast<int*>(smem + C::NSTAGE * C::STAGE);
+    int* sh = reinterpret_cast<int*>(smem + C::NSTAGE * C::STAGE - (C::ALIAS_SH ? 16 : 0));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wid & 3, wm = wid >> 2;
@@ -719,6 +725,7 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
     if (!lean_ok) var = 0;
 #define GLM_LM_CASE(V)                                                                                         \
     case V:                                                                                                    \
+        if (use_b && ((V) & LM_DEEP)) return launch_largem_cfg<MODE, LmCfgB5, V>(p, st);                       \
         return use_b ? launch_largem_cfg<MODE, LmCfgB, V>(p, st) : launch_largem_cfg<MODE, LmCfgA, V>(p, st)
     switch (var) {
         GLM_LM_CASE(1);
@@ -726,6 +733,7 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
         GLM_LM_CASE(3);
         GLM_LM_CASE(11);   // lean + wide + 2 DMA in the MFMA phase
         GLM_LM_CASE(19);   // lean + wide + 4 DMA in the MFMA phase
+        GLM_LM_CASE(2051); // lean + wide + 5-stage ring
         GLM_LM_CASE(259);  // lean + wide + epilogue ordering
         GLM_LM_CASE(771);  // ... without the MFMA-phase priority
         GLM_LM_CASE(1283); // ... with the LOAD phase at priority 1
