@@ -35,6 +35,12 @@ def layer_weights_from_module(layer, n_routed_experts: int | None = None) -> O.L
         E = n_routed_experts or len(mlp.experts)
         kw.update(gate_w=_cpu(mlp.gate.weight), gate_bias=_cpu(mlp.gate.e_score_correction_bias),
                   w13=_cpu(w13[:E]), w2=_cpu(w2[:E]), shared_w13=_cpu(w13[E]), shared_w2=_cpu(w2[E]))
+        if getattr(mlp, "expert_weight_dtype", None) == "fp8_e4m3":
+            if mlp._fp8 is None:
+                mlp.quantize_experts_fp8()
+            q13, s13, q2, s2 = mlp._fp8  # uint8 views with a padded pitch -> contiguous float8 on the CPU
+            f8 = lambda q: q.cpu().contiguous().view(torch.float8_e4m3fn)
+            kw["fp8"] = (f8(q13), s13.cpu(), f8(q2), s2.cpu())
     else:
         kw.update(dense_w13=_cpu(mlp.gate_up_proj.weight), dense_w2=_cpu(mlp.down_proj.weight))
     return O.LayerWeights(**kw)

@@ -243,6 +243,9 @@ class LayerWeights:
         # dense layer
         self.dense_w13 = kw.get("dense_w13")
         self.dense_w2 = kw.get("dense_w2")
+        # N4: fp8 weight-only experts (q13 [E+1,2I,H] float8_e4m3fn, s13 [E+1,2I] fp32, q2 [E+1,H,I], s2 [E+1,H]; the
+        # shared expert is entry E); when set, the routed and shared experts use these instead of w13/w2
+        self.fp8 = kw.get("fp8")
 
 
     def to(self, dtype):
@@ -253,6 +256,9 @@ class LayerWeights:
         reference's bf16 arithmetic)."""
         kw = {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v)
               for k, v in self.__dict__.items()}
+        if kw.get("fp8") is not None:  # the quantised bytes stay; only the scales follow the dtype
+            q13, s13, q2, s2 = kw["fp8"]
+            kw["fp8"] = (q13, s13.to(dtype) if dtype == torch.float32 else s13, q2, s2.to(dtype) if dtype == torch.float32 else s2)
         return LayerWeights(**kw)
 
 
@@ -311,7 +317,17 @@ def decoder_layer(positions, h, residual, lw: LayerWeights, cfg, cos_sin_cache, 
     if trace is not None:
         trace["attn_out"] = h
     h, residual = add_rms_forward(h, residual, lw.post_ln, eps)
-    if lw.gate_w is not None:
+    if lw.gate_w is not None and getattr(lw, "fp8", None) is not None:
+        # N4: same router, experts evaluated on the dequantised fp8 weights (moe_fp8w)
+        hh = h.reshape(-1, h.shape[-1])
+        idx, w = router(hh, lw.gate_w, lw.gate_bias, cfg["num_experts_per_tok"], cfg["routed_scaling_factor"], force_idx)
+        if trace is not None:
+            trace.update(h_router=hh, idx=idx, w=w)
+        q13, s13, q2, s2 = lw.fp8
+        E = q13.shape[0] - 1
+        h = moe_fp8w(hh, cfg["num_experts_per_tok"], idx, w, q13[:E], s13[:E], q2[:E], s2[:E], q13[E], s13[E], q2[E],
+                     s2[E]).reshape(h.shape)
+    elif lw.gate_w is not None:
         h = moe(h, lw.gate_w, lw.gate_bias, cfg["num_experts_per_tok"],
                 cfg["routed_scaling_factor"], lw.w13, lw.w2, lw.shared_w13, lw.shared_w2,
                 force_idx=force_idx, trace=trace)

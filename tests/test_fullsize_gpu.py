@@ -29,9 +29,9 @@ def ops():
     return hip_ops
 
 
-def _layer_decode_case(ops, tag: str, B: int, ctx: int, layer_idx: int, pad_rows: int = 0):
+def _layer_decode_case(ops, tag: str, B: int, ctx: int, layer_idx: int, pad_rows: int = 0, **cfg_over):
     from nanovllm.utils.context import reset_context, set_context
-    cfg = F.air_cfg()
+    cfg = F.air_cfg(**cfg_over)
     layer = F.build_layer(cfg, layer_idx, seed=0)
     nkv, hd, H = cfg.num_key_value_heads, cfg.head_dim, cfg.hidden_size
     caches, bt, cl, pos, slots = F.paged_decode_inputs(B, ctx, nkv, hd, seed=7, pad_rows=pad_rows)
@@ -116,6 +116,60 @@ def test_c2_moe_layer_decode(ops):
 def test_c2_dense_layer_decode(ops):
     """(ii) layer 0 (dense MLP, I=10944) at bs=1 ctx=1024: the dense down-projection configuration."""
     _layer_decode_case(ops, "C2.layer_dense_decode", 1, 1024, 0)
+
+
+def test_c5_tp4_rank_layer_fp8_experts(ops):
+    """BASELINE config 5 (fp8 weight-quantised experts, TP=4, bs=64, seq=8192) as ONE RANK sees it: 24 q / 2 kv heads,
+    expert intermediate 1408/4 = 352, fp8 e4m3 experts, 64 sequences at context 8192 (32 blocks each, permuted).  The
+    collectives are not part of this (TP sharding is covered by tests/test_tp_gloo_cpu.py); the oracle evaluates the
+    reference's arithmetic on the same dequantised bytes."""
+    _layer_decode_case(ops, "C5.tp4_rank_layer_fp8_decode", 64, 8192, 1, num_attention_heads=24, num_key_value_heads=2,
+                       moe_intermediate_size=352, intermediate_size=2736, expert_weight_dtype="fp8_e4m3",
+                       max_position_embeddings=8192)
+
+
+def test_c4_tp8_rank_layer_bs256(ops):
+    """BASELINE config 4 (TP=8, bs=256) as one rank's tensor-parallel layer: 12 q heads / 1 kv head, expert
+    intermediate 176, 256 sequences at context 4096."""
+    _layer_decode_case(ops, "C4.tp8_rank_layer_decode_bs256", 256, 4096, 1, num_attention_heads=12,
+                       num_key_value_heads=1, moe_intermediate_size=176, intermediate_size=1368)
+
+
+def test_c4_expert_parallel_moe_bs256(ops):
+    """BASELINE config 4's MoE block with expert-parallel all-to-all at Air dims: 8 logical ranks x 8 experts (full
+    intermediate size), 256 tokens, dispatch -> experts -> combine (distributed/expert_parallel.py, collectives done by
+    copies on one device) against the oracle's single-rank MoE and against the TP=1 kernels."""
+    from nanovllm.distributed import expert_parallel as EP
+    cfg = F.air_cfg()
+    H, E, k, I = cfg.hidden_size, cfg.n_routed_experts, cfg.num_experts_per_tok, cfg.moe_intermediate_size
+    T, ep = 256, 8
+    x, idx, w, offs, tok, scale, pos = _bench_routing(ops, cfg, T, seed=501)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    w13 = torch.empty(E + 1, 2 * I, H, device="cuda", dtype=BF).normal_(0.0, 0.02, generator=g)
+    w2 = torch.empty(E + 1, H, I, device="cuda", dtype=BF).normal_(0.0, 0.02, generator=g)
+    R = T * k + T
+    act = ops.grouped_gemm_gateup_silu(x, w13, offs, tok, R)
+    y = ops.grouped_gemm_down(act, w2, offs, scale, E)
+    ref_dev = ops.moe_combine(y, pos, T, k, T * k)
+    El = E // ep
+
+    def shared(hh):
+        a = ops.grouped_gemm_gateup_silu(hh, w13[E:E + 1], None, None, hh.shape[0])
+        return ops.grouped_gemm_down(a, w2[E:E + 1], None, None, 0)
+    gens = [EP.EPExperts(ops, ep, r, E, k, w13[r * El:(r + 1) * El], w2[r * El:(r + 1) * El], shared).forward(x, idx, w)
+            for r in range(ep)]
+    outs = EP.run_emulated(gens)
+    for o in outs:
+        assert torch.equal(o, outs[0])
+    ref = O.moe(x.cpu(), None, None, k, 1.0, w13[:E].cpu(), w2[:E].cpu(), w13[E].cpu(), w2[E].cpu(),
+                topk=(idx.cpu(), w.cpu()))
+    st_ep, st_tp1 = F.err_stats(outs[0], ref), F.err_stats(ref_dev, ref)
+    same = bool(torch.equal(outs[0], ref_dev))
+    F.report("C4.expert_parallel_moe_T256_ep8", ep_vs_oracle=st_ep, tp1_vs_oracle=st_tp1, ep_equals_tp1_bitwise=same,
+             ep_vs_tp1=F.err_stats(outs[0], ref_dev))
+    F.assert_allclose_ref_tol(outs[0], ref, "EP=8 MoE block vs oracle", outlier_frac=1e-3)
+    if not same:  # another K-split configuration on ranks with few rows: single ulps (atol for sums that cancel)
+        assert_close_bf16(outs[0], ref_dev, 2, 0.05, atol=2 ** -5, what="EP=8 vs TP=1 kernels")
 
 
 def test_graph_bucket_padding_rows(ops):
