@@ -12,7 +12,26 @@ namespace {
 // Token→expert bucketing: one 1024-thread workgroup (counting sort with LDS atomics).
 constexpr int ALIGN_MAX_G = 1024;
 
-// body shared by moe_align_kernel and the router's last-arriving workgroup; cnt/cur: ALIGN_MAX_G + 1 ints of LDS each
+// write-through (sc1) accesses for data handed between workgroups of ONE launch (Guideline 16 R1): stored this way and
+// drained before the ticket, read this way after it, the hand-off needs neither the producer's agent-scope release fence
+// nor the consumer's acquire (≈1.7 us each on this chip)
+__device__ __forceinline__ unsigned ld_sc1_u32(const void* p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_sc1_u64(const void* p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1_u32(void* p, unsigned v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1_u64(void* p, unsigned long long v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// body shared by moe_align_kernel and the router's last-arriving workgroup; cnt/cur: ALIGN_MAX_G + 1 ints of LDS each.
+// SC1: topk_idx / topk_w were written by other workgroups of this launch (write-through) and are read with sc1 loads
+// (topk_w as aligned 4-byte words: needs k even)
+template <bool SC1>
 __device__ __forceinline__ void moe_align_body(const int64_t* topk_idx, const bf16_t* topk_w, int32_t* expert_offsets,
                                                int32_t* sorted_token, bf16_t* sorted_scale, int32_t* pair_pos,
                                                int64_t T, int k, int E, int with_shared, int* cnt, int* cur) {
@@ -21,7 +40,7 @@ __device__ __forceinline__ void moe_align_body(const int64_t* topk_idx, const bf
     for (int e = tid; e <= E; e += 1024) cnt[e] = 0;
     __syncthreads();
     for (int64_t p = tid; p < P; p += 1024) {
-        const int64_t e = topk_idx[p];
+        const int64_t e = SC1 ? (int64_t)ld_sc1_u64(topk_idx + p) : topk_idx[p];
         if (e >= 0 && e < E) atomicAdd(&cnt[(int)e], 1);
     }
     __syncthreads();
@@ -39,11 +58,18 @@ __device__ __forceinline__ void moe_align_body(const int64_t* topk_idx, const bf
     }
     __syncthreads();
     for (int64_t p = tid; p < P; p += 1024) {
-        const int64_t e = topk_idx[p];
+        const int64_t e = SC1 ? (int64_t)ld_sc1_u64(topk_idx + p) : topk_idx[p];
         if (e >= 0 && e < E) {
             const int pos = atomicAdd(&cur[(int)e], 1);
             sorted_token[pos] = (int32_t)(p / k);
-            sorted_scale[pos] = topk_w[p];
+            bf16_t wv;
+            if (SC1) {
+                const unsigned pr = ld_sc1_u32(topk_w + (p & ~(int64_t)1));
+                wv = (bf16_t)((p & 1) ? (pr >> 16) : (pr & 0xffffu));
+            } else {
+                wv = topk_w[p];
+            }
+            sorted_scale[pos] = wv;
             pair_pos[p] = pos;
         } else {
             pair_pos[p] = -1;
@@ -96,6 +122,14 @@ struct RouterPre {
     float* lg_global;       // [T, E] logits (already rounded to bf16 precision)
 };
 
+// bytes of the x-row area in front of lg[]: the bf16 row, or (fused norm) the hand-over area of the squares chain,
+// 32 B per 8-element vector beyond the first 256
+__host__ __device__ inline size_t router_x_bytes(int H, bool fused_norm) {
+    size_t b = (size_t)H * 2;
+    if (fused_norm && H > 2048 && (size_t)H * 4 - 8192 > b) b = (size_t)H * 4 - 8192;
+    return (b + 15) & ~(size_t)15;
+}
+
 template <int PRE>
 __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ gw, const float* __restrict__ bias,
@@ -103,7 +137,7 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
     int H, int E, int k, float rsf, const RouterPre pre) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                        // [H]
-    float* lg = reinterpret_cast<float*>(smem + (((size_t)H * 2 + 15) & ~(size_t)15));  // [E]
+    float* lg = reinterpret_cast<float*>(smem + router_x_bytes(H, PRE != 0));  // [E]
     const int64_t t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nvec = H >> 3;
@@ -159,10 +193,29 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
                 ov[j] = pack2bf(s8[2 * j], s8[2 * j + 1]);
             }
             if (blockIdx.y == 0) reinterpret_cast<u32x4_t*>(pre.res_out + t * H)[tid] = ov;
+        }
+        // sum of squares in EXACTLY the stand-alone kernels' order (rmsnorm_vec_kernel / add_rmsnorm_partial_kernel run
+        // 256 threads, thread j folding vectors j, j+256, ... into one sequential chain): threads >= 256 hand their 8
+        // values to thread tid % 256 through LDS (the x-row area, not yet in use), which continues its chain with them.
+        // A different association flips rstd by an fp32 ulp and with it single bf16 ulps of y (found by the r02
+        // repetition test; the fixed seeds of the r01 equality test happened not to hit it).
+        float* xch = reinterpret_cast<float*>(smem);
+        if (act && tid >= 256) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xch[(tid - 256) * 8 + j] = s8[j];
+        }
+        __syncthreads();
+        if (act && tid < 256) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) ss += s8[j] * s8[j];
+            for (int v = tid + 256; v < nvec; v += 256) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = xch[(v - 256) * 8 + j];
+                    ss += f * f;
+                }
+            }
         }
-        // block sum over 16 waves; lg[] is free until the logits are written
         ss = wave_sum(ss);
         if (lane == 0) lg[wid] = ss;
         __syncthreads();
@@ -221,8 +274,8 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
                 __hip_atomic_store(reinterpret_cast<unsigned*>(pre.lg_global + t * E + e), __float_as_uint(rbf(sdot)),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // per-token hand-off: every wave drains its stores, the workgroup meets, one lane draws the token's ticket; the
-        // workgroup that draws G-1 acquires and gathers all E logits into LDS
+        // per-token hand-off: every wave drains its (write-through) stores, the workgroup meets, one lane draws the token's
+        // ticket; the workgroup that draws G-1 gathers all E logits into LDS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int* tflag = reinterpret_cast<int*>(lg);
@@ -230,17 +283,14 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
             unsigned* tk = pre.tok_ticket + t;
             const unsigned got = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = got == (unsigned)G - 1u;
-            if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             tflag[0] = last;
         }
         __syncthreads();
         if (!tflag[0]) return;
         __syncthreads();
-        for (int e = tid; e < E; e += ROUTER_NT) lg[e] = pre.lg_global[t * E + e];
+        // every logit was stored write-through and drained before its workgroup's ticket: sc1 loads, no acquire
+        for (int e = tid; e < E; e += ROUTER_NT) lg[e] = __uint_as_float(ld_sc1_u32(pre.lg_global + t * E + e));
     }
     const int nblk = G > 1 ? 0 : (E + ROUTER_EB - 1) / ROUTER_EB;
     for (int b = wid; b < nblk; b += ROUTER_NT / 64) {
@@ -363,7 +413,11 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
     for (int i = 0; i < EPL; ++i)
         if (sel[i]) part += sc[i];
     const float den = rbf(rbf(wave_sum(part)) + 1e-20f);
-    // output in ascending expert id: position = #selected experts with a smaller id
+    // output in ascending expert id: position = #selected experts with a smaller id.  When another workgroup of this
+    // launch buckets the pairs (fuse_align, k even) the routing is stored write-through: ids as 8-byte sc1 stores, the
+    // weights staged in LDS and stored as aligned 4-byte words
+    const bool wt = fuse_align && (k & 1) == 0;
+    bf16_t* wl = reinterpret_cast<bf16_t*>(lg);  // the logits live in registers by now; 2 k <= 4 E bytes
     int base = 0;
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
@@ -371,12 +425,19 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
         if (sel[i]) {
             const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
             if (pos < k) {
-                topk_idx[t * k + pos] = lane + 64 * i;
-                topk_w[t * k + pos] = f2bf(rbf(sc[i] / den) * rsf);  // R6 then R7
+                const bf16_t wv = f2bf(rbf(sc[i] / den) * rsf);  // R6 then R7
+                if (wt) {
+                    st_sc1_u64(topk_idx + t * k + pos, (unsigned long long)(lane + 64 * i));
+                    wl[pos] = wv;
+                } else {
+                    topk_idx[t * k + pos] = lane + 64 * i;
+                    topk_w[t * k + pos] = wv;
+                }
             }
         }
         base += __popcll(m);
     }
+    if (wt && lane < (k >> 1)) st_sc1_u32(topk_w + t * k + 2 * lane, reinterpret_cast<const unsigned*>(wl)[lane]);
     }  // wave 0
     if (!fuse_align) return;
 
@@ -384,29 +445,43 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
     // Hand-off (cdna_hip_programming.md Guideline 16, counter form): wave 0 is the only wave that stored routing data;
     // it drains its stores, lane 0 releases at agent scope and draws a ticket.  The workgroup that draws T-1 acquires,
     // waits, and only then — behind the workgroup barrier — do all its waves read the other workgroups' rows.
-    int* flag = reinterpret_cast<int*>(lg);  // lg[] (>= 16 floats) is dead: every logit has been consumed
+    // With write-through routing stores (k even) neither fence is needed: the drain before the ticket publishes, the
+    // bucketing reads with sc1 loads (Guideline 16 R1; valid-forms table, row 1: one lane of each storing workgroup
+    // adds to one counter, the last adder's workgroup loads behind its barrier).
+    const bool wt2 = (k & 1) == 0;
+    int* flag = reinterpret_cast<int*>(lg) + 32;  // beside the staged weights; lg[] holds >= 64 floats whenever E >= 64...
+    if (E < 64) flag = reinterpret_cast<int*>(smem);  // ... else the x row (dead: every logit has been consumed)
     if (wid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!wt2) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             const unsigned got = __hip_atomic_fetch_add(pre.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = got == (unsigned)gridDim.x - 1u;  // one drawer per token (the token's selecting workgroup)
             if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!wt2) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
                 __hip_atomic_store(pre.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
             }
             flag[0] = last;
         }
     }
     __syncthreads();
-    if (!flag[0]) return;
+    const int is_last = flag[0];
     __syncthreads();  // flag read by everyone before the LDS is reused
+    if (!is_last) return;
     int* cnt = reinterpret_cast<int*>(smem);  // the x row is dead; 2 * (E + 1) ints fit (host checks)
     int* cur = cnt + (E + 1);
-    moe_align_body(topk_idx, topk_w, pre.al_offsets, pre.al_token, pre.al_scale, pre.al_pos, (int64_t)gridDim.x, k, E,
-                   pre.al_with_shared, cnt, cur);
+    if (wt2)
+        moe_align_body<true>(topk_idx, topk_w, pre.al_offsets, pre.al_token, pre.al_scale, pre.al_pos, (int64_t)gridDim.x, k,
+                             E, pre.al_with_shared, cnt, cur);
+    else
+        moe_align_body<false>(topk_idx, topk_w, pre.al_offsets, pre.al_token, pre.al_scale, pre.al_pos, (int64_t)gridDim.x, k,
+                              E, pre.al_with_shared, cnt, cur);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -417,7 +492,7 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(
     int with_shared) {
     __shared__ int cnt[ALIGN_MAX_G + 1];
     __shared__ int cur[ALIGN_MAX_G + 1];
-    moe_align_body(topk_idx, topk_w, expert_offsets, sorted_token, sorted_scale, pair_pos, T, k, E, with_shared, cnt, cur);
+    moe_align_body<false>(topk_idx, topk_w, expert_offsets, sorted_token, sorted_scale, pair_pos, T, k, E, with_shared, cnt, cur);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -625,7 +700,7 @@ extern "C" int glm_router_topk(const void* x, const void* gate_w,
                   "glm_router_topk: needs E<=256, k<=64, H%%8==0, H<=32768, 16B-aligned x/W (E=%d k=%d H=%d)",
                   E, k, H);
     if (T == 0) return GLM_OK;
-    const size_t shm = (((size_t)H * 2 + 15) & ~(size_t)15) + (size_t)E * 4;
+    const size_t shm = router_x_bytes(H, false) + (size_t)(E > 16 ? E : 16) * 4;
     RouterPre pre;
     memset(&pre, 0, sizeof(pre));
     hipLaunchKernelGGL(router_topk_kernel<0>, dim3((unsigned)T), dim3(ROUTER_NT), shm, glm_s(stream),
@@ -703,7 +778,7 @@ static int add_rmsnorm_router_impl(const void* x, const float* part, int nslices
                   "glm_add_rmsnorm_router_topk: needs E<=256, k<=64, H%%8==0, H<=%d, 16B-aligned buffers (E=%d k=%d H=%d)",
                   8 * ROUTER_NT, E, k, H);
     if (T == 0) return GLM_OK;
-    const size_t shm = (((size_t)H * 2 + 15) & ~(size_t)15) + (size_t)(E > ROUTER_NT / 64 ? E : ROUTER_NT / 64) * 4;
+    const size_t shm = router_x_bytes(H, true) + (size_t)(E > ROUTER_NT / 64 ? E : ROUTER_NT / 64) * 4;
     RouterPre pre;
     pre.x = (const bf16_t*)x; pre.part = part; pre.nslices = nslices; pre.slice_stride = slice_stride;
     pre.res_in = (const bf16_t*)residual_in; pre.norm_w = (const bf16_t*)norm_weight; pre.y = (bf16_t*)y;

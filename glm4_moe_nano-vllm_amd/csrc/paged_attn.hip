@@ -71,6 +71,11 @@ __device__ __forceinline__ void store16_sc1(float* base, int64_t elem_off, f32x4
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, (int)(elem_off * 4), 0, 16);
 }
 
+__device__ __forceinline__ f32x4_t load16_sc1(const float* base, int64_t elem_off) {
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+    return __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(elem_off * 4), 0, 16));
+}
+
 // issue the 16 LDS-DMA instructions of one 32-key group into `stage` (wave-private)
 __device__ __forceinline__ void issue_group(const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
                                             char* stage, int64_t phys_block, int in_block_off,
@@ -388,9 +393,9 @@ __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
 
     // ---- merge of the kv-splits by the LAST workgroup of this (sequence, kv-head) to finish (no second launch) ----
     // Hand-off (cdna_hip_programming.md Guideline 16 R1, counter form): the partials were stored write-through (sc1);
-    // every wave drains its stores, the workgroup meets, one lane draws a ticket; the drawer of num_splits-1 acquires
-    // at agent scope, waits and puts the counter back to zero; only behind the next workgroup barrier do its waves
-    // read the other splits' partials.
+    // every wave drains its stores, the workgroup meets, one lane draws a ticket; the drawer of num_splits-1 puts the
+    // counter back to zero, and behind the next workgroup barrier its waves read the other splits' partials with sc1
+    // loads (no acquire: valid-forms table, row 1).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int* flag = reinterpret_cast<int*>(smem + PA_WAVES * PA_RING);  // the block-table slice is dead
@@ -398,11 +403,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
         unsigned* tk = tickets + b * nkv + kvh;
         const unsigned got = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = got == (unsigned)num_splits - 1u;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         flag[0] = last;
     }
     __syncthreads();
@@ -412,17 +413,24 @@ __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
         const int h = tid >> 4, d0 = (tid & 15) * 8;
         if (h < gq) {
             const int64_t bh = b * nh + (int64_t)kvh * gq + h;
+            // every partial was stored write-through and drained before its split's ticket: sc1 loads, no acquire
             float M = -INFINITY;
-            for (int sp = 0; sp < num_splits; ++sp) M = fmaxf(M, part_ml[(bh * num_splits + sp) * 2]);
+            for (int sp = 0; sp < num_splits; ++sp) {
+                const unsigned long long ml = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(part_ml + (bh * num_splits + sp) * 2),
+                                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                M = fmaxf(M, __uint_as_float((unsigned)ml));
+            }
             float L = 0.f, o[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = 0.f;
             for (int sp = 0; sp < num_splits; ++sp) {
-                const float m = part_ml[(bh * num_splits + sp) * 2];
+                const unsigned long long ml = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(part_ml + (bh * num_splits + sp) * 2),
+                                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float m = __uint_as_float((unsigned)ml);
                 const float f = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - M);
-                L += f * part_ml[(bh * num_splits + sp) * 2 + 1];
-                const float* po = part_o + (bh * num_splits + sp) * PA_HD + d0;
-                const f32x4_t a = *reinterpret_cast<const f32x4_t*>(po), c4 = *reinterpret_cast<const f32x4_t*>(po + 4);
+                L += f * __uint_as_float((unsigned)(ml >> 32));
+                const int64_t po = (bh * num_splits + sp) * PA_HD + d0;
+                const f32x4_t a = load16_sc1(part_o, po), c4 = load16_sc1(part_o, po + 4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     o[i] += f * a[i];

@@ -24,8 +24,32 @@ class TPGroup:
     def rank(self) -> int:
         return dist.get_rank(self._group) if dist.is_available() and dist.is_initialized() else 0
 
+    _oneshot = None          # OneShotAllReduce once set up; False = tried and unavailable
+    ONESHOT_MAX_ELEMS = 512 * 8192
+
+    def _oneshot_for(self, t: torch.Tensor):
+        """Opt-in (GLM_ONESHOT_ALLREDUCE=1) one-hop all-reduce over mapped peer buffers for the small [T, H] tensors of
+        the RowParallel sites; RCCL otherwise.  Set up collectively at the first eligible call; any failure keeps RCCL."""
+        if self._oneshot is False:
+            return None
+        from nanovllm.distributed import oneshot_allreduce as osa
+        if not osa.enabled() or not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous() or \
+                t.numel() % 8 or t.numel() > self.ONESHOT_MAX_ELEMS or self.world_size > osa.N_FLAGS:
+            return None
+        if self._oneshot is None:
+            try:
+                self._oneshot = osa.OneShotAllReduce.for_group(self.ONESHOT_MAX_ELEMS, t.device, self._group)
+            except Exception as e:  # noqa: BLE001 - stay on RCCL
+                print(f"[nanovllm] one-shot all-reduce unavailable ({e!r}); using RCCL")
+                self._oneshot = False
+                return None
+        return self._oneshot
+
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
         if self.world_size > 1:
+            fast = self._oneshot_for(t)
+            if fast is not None:
+                return fast.all_reduce(t)
             dist.all_reduce(t, group=self._group)
         return t
 

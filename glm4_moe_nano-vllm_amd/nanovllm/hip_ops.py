@@ -80,6 +80,8 @@ _SIGNATURES = {
                                                   c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                                   c_int, c_void_p, c_size_t, c_void_p]),
     "glm_router_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "glm_allreduce_oneshot": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, ctypes.c_uint,
+                                      c_void_p, c_void_p, c_void_p]),
     "glm_gather_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "glm_scatter_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "glm_moe_combine_scaled": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,

@@ -277,6 +277,18 @@ int glm_moe_combine_scaled(const void* y, int64_t ldy, const int32_t* pair_pos, 
                            const void* shared_rows, int64_t ld_shared, void* out, int64_t T, int k, int H,
                            glm_stream_t stream);
 
+/* N3  one-shot all-reduce(sum) of a small bf16 tensor over directly mapped peer buffers (the RowParallel all-reduce,
+ *     layers/linear.py:153-154, as ONE hop over all xGMI links instead of a ring).  Every rank owns a comm buffer of
+ *     2 * n_max bf16 (two halves used by epoch parity) and 8 uint32 flags, both mapped into every peer (hipIpc);
+ *     peer_bufs / peer_flags are HOST arrays of `world` device pointers as seen by THIS process (entry `rank` = own).
+ *     epoch: 1, 2, 3, … identical on all ranks, one per call.  local_counter (uint32, zero before the first call) and
+ *     status (uint32, zero = ok; k+1 = gave up waiting for rank k) live in this rank's memory.  Sums are formed in
+ *     ascending rank order in fp32 and rounded once: bit-identical on every rank.  Spins are bounded.  NOT the default
+ *     path: RCCL is; this entry has run with world = 1 and with two ranks emulated on one device only.             */
+int glm_allreduce_oneshot(const void* in, void* out, void* const* peer_bufs, void* const* peer_flags, int rank, int world,
+                          int64_t n, int64_t n_max, unsigned epoch, void* local_counter, void* status,
+                          glm_stream_t stream);
+
 /* Tuning studies only (tools/largem_ab.py): kernel variant of the LDS-tiled large-M GEMM for the next launches of this
  * process — a bit set of lean load phase (1), 16-byte epilogue stores (2), … (csrc/gemm_largem.hip); < 0 restores the
  * default.  Every variant that stores results is bit-identical to variant 0.  Returns the previous value.          */

@@ -689,3 +689,63 @@ def test_expert_parallel_emulated_equals_single_gpu(ops, ep, T, E, k, H, I):
         assert_close_bf16(outs[0], ref_dev, 2, 0.05, atol=2 ** -5, what="expert-parallel vs single-GPU kernels")
     ref = O.moe(x, None, None, k, 1.0, w13[:E], w2[:E], w13[E], w2[E], topk=(idx, w))
     assert_mixed(outs[0], ref, 2 ** -6, 2 ** -6 * float(ref.float().abs().max()), "expert-parallel vs oracle")
+
+
+def test_in_launch_handoffs_under_repetition(ops):
+    """The router's two hand-offs (per-token logits gather, pair bucketing by the last workgroup) and the attention's
+    kv-split merge read data that OTHER workgroups wrote in the same launch, from buffers that are reused launch after
+    launch.  New inputs every repetition (a stale line from the previous launch would show), other kernels in between,
+    results against the stand-alone kernels / the oracle every time."""
+    T, H, E, k = 32, 4096, 64, 8
+    nw = rnd(H, seed=702) * 0.1 + 1.0
+    gw = rnd(E, H, seed=703, scale=H ** -0.5)
+    bias = (torch.rand(E, generator=torch.Generator().manual_seed(704)) * 0.2 - 0.1).float()
+    for rep in range(16):
+        x, res = dev(rnd(T, H, seed=800 + rep)), dev(rnd(T, H, seed=900 + rep))
+        y0, r0 = ops.add_rmsnorm(x, res, dev(nw), 1e-5)
+        i0, w0 = ops.router_topk(y0, dev(gw), dev(bias), k, 1.0)
+        y1, r1, i1, w1, al = ops.add_rmsnorm_router_topk(x, res, dev(nw), 1e-5, dev(gw), dev(bias), k, 1.0,
+                                                         align_with_shared=True)
+        ops.gemm_bf16(dev(rnd(32, 4096, seed=rep)), dev(rnd(2048, 4096, seed=1, scale=0.02)))  # keep other CUs busy
+        assert torch.equal(i0, i1) and torch.equal(w0, w1) and torch.equal(y0, y1), f"rep {rep}"
+        _check_align(*al, i1.cpu(), w1.cpu(), E, True)
+    scale = 128 ** -0.5
+    for rep in range(8):
+        q, kc, vc, cl, bt = _paged_case([1024 - 37 * rep, 640 + rep], 96, 8, seed=1000 + rep)
+        ref = O.attn_decode_paged(q, kc, vc, cl, bt, scale)
+        out = ops.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(cl), dev(bt), scale)  # 8 splits, in-kernel merge
+        assert_mixed(out, ref, 1.6e-2, 4e-3, f"split merge rep {rep}")
+
+
+# ------------------------------------------------------------------------------------------
+# N3: one-shot all-reduce (opt-in; RCCL is the default path)
+def test_oneshot_allreduce_world1_and_two_streams(ops):
+    from nanovllm.distributed.oneshot_allreduce import OneShotAllReduce
+    dev0 = torch.device("cuda", 0)
+    n = 32 * 4096
+    # world = 1: the degenerate path (publish, signal self, sum of one buffer)
+    ar = OneShotAllReduce(n, dev0, 0, 1)
+    x = dev(rnd(32, 4096, seed=1101))
+    ref = x.clone()
+    for _ in range(3):
+        y = x.clone()
+        ar.all_reduce(y)
+        assert torch.equal(y, ref)
+    assert ar.status() == 0
+    # two ranks emulated on ONE device: each "rank" is a stream, the peer pointers are the other rank's buffers.
+    # Both kernels must be resident together (64 workgroups each); every spin in the kernel is bounded.
+    a0, a1 = OneShotAllReduce(n, dev0, 0, 2), OneShotAllReduce(n, dev0, 1, 2)
+    for a in (a0, a1):
+        a.peer_bufs, a.peer_flags = [a0.buf, a1.buf], [a0.flags, a1.flags]
+    s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(6):
+        x0, x1 = dev(rnd(32, 4096, seed=1200 + rep)), dev(rnd(32, 4096, seed=1300 + rep))
+        exp = (x0.float() + x1.float()).to(BF)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s0):
+            a0.all_reduce(x0)
+        with torch.cuda.stream(s1):
+            a1.all_reduce(x1)
+        torch.cuda.synchronize()
+        assert a0.status() == 0 and a1.status() == 0, "a rank gave up waiting (the two kernels did not overlap?)"
+        assert torch.equal(x0, exp) and torch.equal(x1, exp), f"rep {rep}"
