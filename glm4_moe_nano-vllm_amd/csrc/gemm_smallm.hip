@@ -990,6 +990,14 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
     if (mode == GEMM_DOWN && p.G == 1 && p.R >= GLM_SM_DMA_MIN_ROWS && p.K >= 4096) return launch_cfg_dma<GEMM_DOWN, GLM_SM_DMA_DOWN_DENSE>(p, st);
 #endif
     // a K of one or two chunks (TP=8 shard: 176) leaves the ring nothing to overlap: 37 vs 31 us for the VGPR body
+    // few rows per group (bs=32: 4.4 on average): 16-row blocks in two-wave workgroups — 24 KiB of LDS per wave, six waves
+    // per CU instead of five, and a third less activation DMA; a 32-row group (the shared expert) then reads its weights
+    // twice (+1.6 % bytes).  r02 sweep at C3: 114.7 -> 108.8 us (1,1,2,1: 110.5).  Larger batches keep 32-row blocks.
+#ifndef GLM_SM_DMA_DOWN_FEWROWS
+#define GLM_SM_DMA_DOWN_FEWROWS 2, 1, 2, 1
+#endif
+    if (mode == GEMM_DOWN && p.R >= GLM_SM_DMA_MIN_ROWS && p.K >= 512 && p.G > 1 && p.R <= 6 * (int64_t)p.G)
+        return launch_cfg_dma<GEMM_DOWN, GLM_SM_DMA_DOWN_FEWROWS>(p, st);
     if (mode == GEMM_DOWN && p.R >= GLM_SM_DMA_MIN_ROWS && p.K >= 512) return launch_cfg_dma<GEMM_DOWN, GLM_SM_DMA_DOWN>(p, st);
 #endif
 #ifndef GLM_SM_CFG_GATEUP_R16
