@@ -28,6 +28,17 @@ __device__ __forceinline__ void st_sc1_u64(void* p, unsigned long long v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// inclusive prefix sum over the 64 lanes of a wave on DPP row shifts / row broadcasts (no LDS round trips)
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1, out-of-row lanes read 0
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8 -> inclusive inside each row of 16
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // body shared by moe_align_kernel and the router's last-arriving workgroup; cnt/cur: ALIGN_MAX_G + 1 ints of LDS each.
 // SC1: topk_idx / topk_w were written by other workgroups of this launch (write-through) and are read with sc1 loads
 // (topk_w as aligned 4-byte words: needs k even)
@@ -39,31 +50,53 @@ __device__ __forceinline__ void moe_align_body(const int64_t* topk_idx, const bf
     const int64_t P = T * k;
     for (int e = tid; e <= E; e += 1024) cnt[e] = 0;
     __syncthreads();
+    // a thread's first pair (all of them when P <= 1024: every decode batch) stays in registers for the second pass,
+    // its routing weight fetched in the same round trip
+    int64_t e_first = -1;
+    bf16_t w_first = 0;
     for (int64_t p = tid; p < P; p += 1024) {
         const int64_t e = SC1 ? (int64_t)ld_sc1_u64(topk_idx + p) : topk_idx[p];
+        if (p == tid) {
+            e_first = e;
+            if (SC1) {
+                const unsigned pr = ld_sc1_u32(topk_w + (p & ~(int64_t)1));
+                w_first = (bf16_t)((p & 1) ? (pr >> 16) : (pr & 0xffffu));
+            } else {
+                w_first = topk_w[p];
+            }
+        }
         if (e >= 0 && e < E) atomicAdd(&cnt[(int)e], 1);
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < 64) {  // wave 0: exclusive scan of the counts, 64 experts at a time
         int run = 0;
-        for (int e = 0; e < E; ++e) {
-            const int c = cnt[e];
-            cur[e] = run;
-            expert_offsets[e] = run;
-            run += c;
+        for (int e0 = 0; e0 < E; e0 += 64) {
+            const int e = e0 + tid;
+            const int c = e < E ? cnt[e] : 0;
+            const int incl = wave_scan_incl(c);
+            if (e < E) {
+                cur[e] = run + incl - c;
+                expert_offsets[e] = run + incl - c;
+            }
+            run += __builtin_amdgcn_readlane(incl, 63);
         }
-        expert_offsets[E] = run;  // == number of valid pairs; start of the shared group
-        cur[E] = run;
-        if (with_shared) expert_offsets[E + 1] = run + (int)T;
+        if (tid == 0) {
+            expert_offsets[E] = run;  // == number of valid pairs; start of the shared group
+            cur[E] = run;
+            if (with_shared) expert_offsets[E + 1] = run + (int)T;
+        }
     }
     __syncthreads();
     for (int64_t p = tid; p < P; p += 1024) {
-        const int64_t e = SC1 ? (int64_t)ld_sc1_u64(topk_idx + p) : topk_idx[p];
+        const bool first = p == tid;
+        const int64_t e = first ? e_first : (SC1 ? (int64_t)ld_sc1_u64(topk_idx + p) : topk_idx[p]);
         if (e >= 0 && e < E) {
             const int pos = atomicAdd(&cur[(int)e], 1);
             sorted_token[pos] = (int32_t)(p / k);
             bf16_t wv;
-            if (SC1) {
+            if (first) {
+                wv = w_first;
+            } else if (SC1) {
                 const unsigned pr = ld_sc1_u32(topk_w + (p & ~(int64_t)1));
                 wv = (bf16_t)((p & 1) ? (pr >> 16) : (pr & 0xffffu));
             } else {
@@ -130,7 +163,23 @@ __host__ __device__ inline size_t router_x_bytes(int H, bool fused_norm) {
     return (b + 15) & ~(size_t)15;
 }
 
-template <int PRE>
+// Phase timeline of the fused router launch (study builds only: build.py --variant _rtrace GLM_ROUTER_TRACE=1): thread 0
+// of every workgroup stamps the 100 MHz wall clock at each phase boundary; tools/router_trace.py reads it back.
+#ifdef GLM_ROUTER_TRACE
+constexpr int RTRACE_SLOTS = 12, RTRACE_WGS = 4096;
+__device__ unsigned long long g_rtrace[RTRACE_WGS * RTRACE_SLOTS];
+#define RT_MARK(i)                                                                                                \
+    do {                                                                                                          \
+        const unsigned wg_ = blockIdx.x * gridDim.y + blockIdx.y;                                                 \
+        if (threadIdx.x == 0 && wg_ < RTRACE_WGS) g_rtrace[wg_ * RTRACE_SLOTS + (i)] = wall_clock64();            \
+    } while (0)
+#else
+#define RT_MARK(i) ((void)0)
+#endif
+
+// SPLIT: the experts of a token are divided over gridDim.y workgroups (compile-time: the two dot-product loops in one
+// kernel body pushed the 1024-thread kernel past its 128-VGPR budget)
+template <int PRE, bool SPLIT>
 __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ gw, const float* __restrict__ bias,
     int64_t* __restrict__ topk_idx, bf16_t* __restrict__ topk_w, bf16_t* __restrict__ logits_out,
@@ -141,6 +190,8 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
     const int64_t t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nvec = H >> 3;
+    RT_MARK(0);
+    constexpr int EPL = ROUTER_MAX_E / 64;
     if (PRE == 0) {
         const u32x4_t* src = reinterpret_cast<const u32x4_t*>(x + t * H);
         u32x4_t* dst = reinterpret_cast<u32x4_t*>(xs);
@@ -163,16 +214,16 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
             } else {
                 const float* pp = pre.part + t * H + (int64_t)tid * 8;
                 f32x4_t a = *reinterpret_cast<const f32x4_t*>(pp), b = *reinterpret_cast<const f32x4_t*>(pp + 4);
-                for (int s0 = 1; s0 < pre.nslices; s0 += 8) {  // slice order, up to 8 loads in flight
-                    f32x4_t ta[8], tb[8];
+                for (int s0 = 1; s0 < pre.nslices; s0 += 4) {  // slice order, up to 4 loads in flight (8 cost 64 VGPRs)
+                    f32x4_t ta[4], tb[4];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < 4; ++j) {
                         const int sl = min(s0 + j, pre.nslices - 1);
                         ta[j] = *reinterpret_cast<const f32x4_t*>(pp + sl * pre.slice_stride);
                         tb[j] = *reinterpret_cast<const f32x4_t*>(pp + sl * pre.slice_stride + 4);
                     }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
+                    for (int j = 0; j < 4; ++j)
                         if (s0 + j < pre.nslices) {
                             a += ta[j];
                             b += tb[j];
@@ -200,6 +251,7 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
         // A different association flips rstd by an fp32 ulp and with it single bf16 ulps of y (found by the r02
         // repetition test; the fixed seeds of the r01 equality test happened not to hit it).
         float* xch = reinterpret_cast<float*>(smem);
+        RT_MARK(1);  // inputs loaded
         if (act && tid >= 256) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) xch[(tid - 256) * 8 + j] = s8[j];
@@ -237,35 +289,55 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
             reinterpret_cast<u32x4_t*>(xs)[tid] = o;
         }
     }
-    __syncthreads();
+    // the correction bias is needed by wave 0 only after the logits (~5 us from here) and is cold by then (~2.5 us):
+    // requested now as an LDS-DMA — no register to hold, nothing the compiler could sink to the use — behind the input
+    // loads (vector memory returns in order).  The barrier below must not wait for it: only LDS traffic (the normalised
+    // row) has to be complete, hence the raw barrier instead of __syncthreads().
+    float* bias_l = lg + (E > 16 ? E : 16);  // [ROUTER_MAX_E]
+    if (wid == 0) {
+#pragma unroll
+        for (int i = 0; i < EPL; ++i)
+            if (64 * i < E)  // lanes past E re-read the last entry into slots nobody reads
+                __builtin_amdgcn_global_load_lds(
+                    (__attribute__((address_space(1))) const void*)(bias + min(64 * i + lane, E - 1)),
+                    (__attribute__((address_space(3))) void*)(bias_l + 64 * i), 4, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    RT_MARK(2);  // normalised row in LDS
 
     // R1: logits = bf16( fp32 dot )
-    const int G = gridDim.y;
-    if (G > 1) {
+    const int G = SPLIT ? gridDim.y : 1;
+    if constexpr (SPLIT) {
         // this workgroup's experts, one per wave at a time, every K step's gate-row load in flight at once.  Per expert
         // the FMA chain runs over the lane's chunks lane, lane+64, ... in ascending order and ends in the same
         // wave_sum as the blocked loop below: the logits are bit-identical however the experts are distributed.
         const int Eg = (E + G - 1) / G;
         const int e_lo = blockIdx.y * Eg, e_hi = min(E, e_lo + Eg);
-        constexpr int MAXSTEP = 8 * ROUTER_NT / 8 / 64;  // H <= 8 * ROUTER_NT (host check) -> at most 16 steps
+        // H <= 8 * ROUTER_NT (host check) -> at most 16 K steps per lane, taken 8 at a time (all of H = 4096 in one go;
+        // 16 at once cost 64 VGPRs and pushed the 1024-thread kernel over its 128-register budget)
+        constexpr int STEPS = 8;
         for (int e = e_lo + wid; e < e_hi; e += ROUTER_NT / 64) {
             const u32x4_t* grow = reinterpret_cast<const u32x4_t*>(gw + (int64_t)e * H);
-            u32x4_t wv[MAXSTEP];
-#pragma unroll
-            for (int u = 0; u < MAXSTEP; ++u) {
-                wv[u] = u32x4_t{0, 0, 0, 0};
-                if (64 * u < nvec) wv[u] = grow[lane + 64 * u < nvec ? lane + 64 * u : lane];  // uniform guard
-            }
             float acc = 0.f;
+            for (int c0 = 0; c0 < nvec; c0 += 64 * STEPS) {
+                u32x4_t wv[STEPS];
 #pragma unroll
-            for (int u = 0; u < MAXSTEP; ++u) {
-                const int c = lane + 64 * u;
-                if (c < nvec) {
-                    const u32x4_t xv = reinterpret_cast<const u32x4_t*>(xs)[c];
+                for (int u = 0; u < STEPS; ++u) {
+                    wv[u] = u32x4_t{0, 0, 0, 0};
+                    if (c0 + 64 * u < nvec)  // uniform guard
+                        wv[u] = grow[c0 + lane + 64 * u < nvec ? c0 + lane + 64 * u : lane];
+                }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        acc = fmaf(bflo(xv[q]), bflo(wv[u][q]), acc);
-                        acc = fmaf(bfhi(xv[q]), bfhi(wv[u][q]), acc);
+                for (int u = 0; u < STEPS; ++u) {
+                    const int c = c0 + lane + 64 * u;
+                    if (c < nvec) {
+                        const u32x4_t xv = reinterpret_cast<const u32x4_t*>(xs)[c];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc = fmaf(bflo(xv[q]), bflo(wv[u][q]), acc);
+                            acc = fmaf(bfhi(xv[q]), bfhi(wv[u][q]), acc);
+                        }
                     }
                 }
             }
@@ -276,8 +348,10 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
         }
         // per-token hand-off: every wave drains its (write-through) stores, the workgroup meets, one lane draws the token's
         // ticket; the workgroup that draws G-1 gathers all E logits into LDS
+        RT_MARK(3);  // wave 0's dot products done
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        RT_MARK(4);  // logits drained, workgroup met
         int* tflag = reinterpret_cast<int*>(lg);
         if (tid == 0) {
             unsigned* tk = pre.tok_ticket + t;
@@ -287,12 +361,13 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
             tflag[0] = last;
         }
         __syncthreads();
+        RT_MARK(5);  // token ticket drawn
         if (!tflag[0]) return;
         __syncthreads();
         // every logit was stored write-through and drained before its workgroup's ticket: sc1 loads, no acquire
         for (int e = tid; e < E; e += ROUTER_NT) lg[e] = __uint_as_float(ld_sc1_u32(pre.lg_global + t * E + e));
     }
-    const int nblk = G > 1 ? 0 : (E + ROUTER_EB - 1) / ROUTER_EB;
+    const int nblk = SPLIT ? 0 : (E + ROUTER_EB - 1) / ROUTER_EB;
     for (int b = wid; b < nblk; b += ROUTER_NT / 64) {
         const int e0 = b * ROUTER_EB;
         float acc[ROUTER_EB];
@@ -335,12 +410,13 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
         }
     }
     __syncthreads();
+    RT_MARK(6);  // all logits of the token in LDS
     const bool fuse_align = pre.al_offsets != nullptr;  // uniform (kernel argument)
     if (wid != 0 && !fuse_align) return;
     if (wid == 0) {
 
     // wave 0: R2..R7.  lane owns experts lane + 64*i.
-    constexpr int EPL = ROUTER_MAX_E / 64;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the bias DMA has landed
     float sc[EPL], ch[EPL];
     bool sel[EPL];
 #pragma unroll
@@ -351,7 +427,7 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
             const float l = lg[e];
             if (logits_out) logits_out[t * E + e] = f2bf(l);
             sc[i] = rbf(sigmoid_f(l));  // R2: bf16 sigmoid
-            ch[i] = sc[i] + bias[e];    // R3: fp32 (bias buffer is fp32)
+            ch[i] = sc[i] + bias_l[e];  // R3: fp32 (bias buffer is fp32)
         } else {
             sc[i] = 0.f;
             ch[i] = -INFINITY;
@@ -379,6 +455,26 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
         hi = take ? ohi : hi;
         lo = take ? olo : lo;
     };
+    if (E <= 64) {
+        // one expert per lane: selected <=> fewer than k experts precede it in the total order (key descending, then id
+        // ascending) — the same set the k arg-max rounds below pick, in ~1/4 of the instructions.  Keys go through LDS
+        // (the x row is dead) and come back as broadcast 16-byte reads.
+        unsigned* keys = reinterpret_cast<unsigned*>(smem);
+        keys[lane] = kh[0];  // lanes >= E hold key 0, below every real key
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned mine = kh[0];
+        int rank = 0;
+#pragma unroll
+        for (int j4 = 0; j4 < 16; ++j4) {
+            const u32x4_t kk = reinterpret_cast<const u32x4_t*>(keys)[j4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = 4 * j4 + q;
+                rank += (kk[q] > mine || (kk[q] == mine && j < lane)) ? 1 : 0;
+            }
+        }
+        sel[0] = lane < E && rank < k;
+    } else
     for (int r = 0; r < k; ++r) {
         unsigned hi = 0u, lo = 0u;
 #pragma unroll
@@ -439,6 +535,7 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
     }
     if (wt && lane < (k >> 1)) st_sc1_u32(topk_w + t * k + 2 * lane, reinterpret_cast<const unsigned*>(wl)[lane]);
     }  // wave 0
+    RT_MARK(7);  // selection stored
     if (!fuse_align) return;
 
     // ---- last-arriving workgroup: token -> expert bucketing over ALL tokens' routing (glm_moe_align) ----
@@ -473,6 +570,7 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
     __syncthreads();
     const int is_last = flag[0];
     __syncthreads();  // flag read by everyone before the LDS is reused
+    RT_MARK(8);  // global ticket drawn
     if (!is_last) return;
     int* cnt = reinterpret_cast<int*>(smem);  // the x row is dead; 2 * (E + 1) ints fit (host checks)
     int* cur = cnt + (E + 1);
@@ -482,6 +580,8 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
     else
         moe_align_body<false>(topk_idx, topk_w, pre.al_offsets, pre.al_token, pre.al_scale, pre.al_pos, (int64_t)gridDim.x, k,
                               E, pre.al_with_shared, cnt, cur);
+    __syncthreads();
+    RT_MARK(9);  // bucketing done
 }
 
 // ------------------------------------------------------------------------------------------
@@ -686,6 +786,18 @@ __global__ __launch_bounds__(CN_NT) void moe_combine_add_rmsnorm_kernel(
 
 }  // namespace
 
+#ifdef GLM_ROUTER_TRACE
+extern "C" int glm_debug_router_trace(unsigned long long* host_dst, int clear) {
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_rtrace)) != hipSuccess) return -1;
+        return hipMemset(p, 0, sizeof(unsigned long long) * RTRACE_WGS * RTRACE_SLOTS) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_rtrace), sizeof(unsigned long long) * RTRACE_WGS * RTRACE_SLOTS) ==
+                   hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int glm_router_topk(const void* x, const void* gate_w,
                                const float* e_score_correction_bias, int64_t* topk_idx,
                                void* topk_w, void* logits_out, int64_t T, int H, int E, int k,
@@ -700,10 +812,10 @@ extern "C" int glm_router_topk(const void* x, const void* gate_w,
                   "glm_router_topk: needs E<=256, k<=64, H%%8==0, H<=32768, 16B-aligned x/W (E=%d k=%d H=%d)",
                   E, k, H);
     if (T == 0) return GLM_OK;
-    const size_t shm = router_x_bytes(H, false) + (size_t)(E > 16 ? E : 16) * 4;
+    const size_t shm = router_x_bytes(H, false) + (size_t)(E > 16 ? E : 16) * 4 + ROUTER_MAX_E * 4;  // x | logits | bias
     RouterPre pre;
     memset(&pre, 0, sizeof(pre));
-    hipLaunchKernelGGL(router_topk_kernel<0>, dim3((unsigned)T), dim3(ROUTER_NT), shm, glm_s(stream),
+    hipLaunchKernelGGL((router_topk_kernel<0, false>), dim3((unsigned)T), dim3(ROUTER_NT), shm, glm_s(stream),
                        (const bf16_t*)x, (const bf16_t*)gate_w, e_score_correction_bias, topk_idx,
                        (bf16_t*)topk_w, (bf16_t*)logits_out, H, E, k, routed_scaling_factor, pre);
     GLM_CHECK_LAUNCH("glm_router_topk");
@@ -778,7 +890,7 @@ static int add_rmsnorm_router_impl(const void* x, const float* part, int nslices
                   "glm_add_rmsnorm_router_topk: needs E<=256, k<=64, H%%8==0, H<=%d, 16B-aligned buffers (E=%d k=%d H=%d)",
                   8 * ROUTER_NT, E, k, H);
     if (T == 0) return GLM_OK;
-    const size_t shm = router_x_bytes(H, true) + (size_t)(E > ROUTER_NT / 64 ? E : ROUTER_NT / 64) * 4;
+    const size_t shm = router_x_bytes(H, true) + (size_t)(E > ROUTER_NT / 64 ? E : ROUTER_NT / 64) * 4 + ROUTER_MAX_E * 4;
     RouterPre pre;
     pre.x = (const bf16_t*)x; pre.part = part; pre.nslices = nslices; pre.slice_stride = slice_stride;
     pre.res_in = (const bf16_t*)residual_in; pre.norm_w = (const bf16_t*)norm_weight; pre.y = (bf16_t*)y;
@@ -795,14 +907,18 @@ static int add_rmsnorm_router_impl(const void* x, const float* part, int nslices
         pre.lg_global = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ROUTER_WS_HEAD);
     }
     const dim3 grid((unsigned)T, G);
-    if (x)
-        hipLaunchKernelGGL(router_topk_kernel<1>, grid, dim3(ROUTER_NT), shm, glm_s(stream), (const bf16_t*)y,
-                           (const bf16_t*)gate_w, e_score_correction_bias, topk_idx, (bf16_t*)topk_w, (bf16_t*)nullptr, H, E,
-                           k, routed_scaling_factor, pre);
-    else
-        hipLaunchKernelGGL(router_topk_kernel<2>, grid, dim3(ROUTER_NT), shm, glm_s(stream), (const bf16_t*)y,
-                           (const bf16_t*)gate_w, e_score_correction_bias, topk_idx, (bf16_t*)topk_w, (bf16_t*)nullptr, H, E,
-                           k, routed_scaling_factor, pre);
+#define GLM_ROUTER_LAUNCH(PRE_, SPLIT_)                                                                                 \
+    hipLaunchKernelGGL((router_topk_kernel<PRE_, SPLIT_>), grid, dim3(ROUTER_NT), shm, glm_s(stream), (const bf16_t*)y, \
+                       (const bf16_t*)gate_w, e_score_correction_bias, topk_idx, (bf16_t*)topk_w, (bf16_t*)nullptr, H,  \
+                       E, k, routed_scaling_factor, pre)
+    if (x) {
+        if (G > 1) GLM_ROUTER_LAUNCH(1, true);
+        else GLM_ROUTER_LAUNCH(1, false);
+    } else {
+        if (G > 1) GLM_ROUTER_LAUNCH(2, true);
+        else GLM_ROUTER_LAUNCH(2, false);
+    }
+#undef GLM_ROUTER_LAUNCH
     GLM_CHECK_LAUNCH("glm_add_rmsnorm_router_topk");
     return GLM_OK;
 }
