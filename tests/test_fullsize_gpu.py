@@ -172,6 +172,105 @@ def test_c4_expert_parallel_moe_bs256(ops):
         assert_close_bf16(outs[0], ref_dev, 2, 0.05, atol=2 ** -5, what="EP=8 vs TP=1 kernels")
 
 
+def _layer_prefill_case(ops, tag: str, seqlens, layer_idx: int, **cfg_over):
+    """One decoder layer over a ragged prefill batch at Air dims (varlen causal attention, new K/V rows stored through a
+    permuted slot mapping, large-M GEMMs, prefill router + bucketing), against the oracle's prefill branch
+    (layers/attention.py:85-100, decode_layer.py:79-100)."""
+    from nanovllm.utils.context import reset_context, set_context
+    cfg = F.air_cfg(**cfg_over)
+    layer = F.build_layer(cfg, layer_idx, seed=0)
+    nkv, hd, H = cfg.num_key_value_heads, cfg.head_dim, cfg.hidden_size
+    T = int(sum(seqlens))
+    cu = torch.tensor([0] + list(seqlens), dtype=torch.int32).cumsum(0).to(torch.int32)
+    pos = torch.cat([torch.arange(n) for n in seqlens]).to(torch.int64)
+    bs = 256
+    nblk = sum((n + bs - 1) // bs for n in seqlens) + 1
+    g = torch.Generator().manual_seed(11)
+    perm = torch.randperm(nblk, generator=g)
+    slots, b0 = [], 0
+    for n in seqlens:  # each sequence owns its own (permuted) blocks
+        nb = (n + bs - 1) // bs
+        blocks = perm[b0:b0 + nb]
+        b0 += nb
+        t = torch.arange(n)
+        slots.append(blocks[t // bs] * bs + t % bs)
+    slots = torch.cat(slots).to(torch.int32)
+    kc = torch.zeros(nblk, bs, nkv, hd, dtype=BF, device="cuda")
+    vc = torch.zeros_like(kc)
+    layer.self_attn.attn.k_cache, layer.self_attn.attn.v_cache = kc, vc
+    h, res = F.randn_bf16(T, H, seed=1), F.randn_bf16(T, H, seed=2)
+    cap = {}
+    is_moe = hasattr(layer.mlp, "gate")
+    if is_moe:
+        layer.mlp.register_forward_pre_hook(
+            lambda m, a, kw: cap.update(h_router=a[0], routing=kw.get("routing")), with_kwargs=True)
+        layer.mlp.gate.register_forward_hook(lambda m, i, o: cap.update(gate_out=o, gate_in=i[0]))
+    set_context(True, cu.cuda(), cu.cuda(), max(seqlens), max(seqlens), slots.cuda(), None, None)
+    with torch.inference_mode():
+        out, res_out = layer(pos.cuda(), h, res)
+    reset_context()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all() and torch.isfinite(res_out.float()).all()
+
+    lw, cfgd, cs = F.oracle_layer_inputs(layer, cfg)
+    meta = O.AttnMeta(True, slot_mapping=slots, cu_seqlens_q=cu, cu_seqlens_k=cu)
+    hc, rc = h.cpu(), res.cpu()
+    kz = torch.zeros(nblk, bs, nkv, hd, dtype=BF)
+    kc_ref, vc_ref = kz.clone(), kz.clone()
+    tr = {}
+    ref_out, ref_res = O.decoder_layer(pos, hc, rc, lw, cfgd, cs, kc_ref, vc_ref, meta, trace=tr)
+    out32, res32 = O.decoder_layer(pos, hc.float(), rc.float(), lw.to(torch.float32), cfgd, cs, kz.float(), kz.float(),
+                                   meta, force_idx=tr.get("idx"))
+    D = nkv * hd
+    sl = slots.long()
+    kg, vg = kc.cpu().view(-1, D), vc.cpu().view(-1, D)
+    untouched = torch.ones(kg.shape[0], dtype=torch.bool)
+    untouched[sl] = False
+    assert not kg[untouched].any() and not vg[untouched].any(), f"{tag}: cache rows outside the slot mapping written"
+    st_k, st_v = F.err_stats(kg[sl], kc_ref.view(-1, D)[sl]), F.err_stats(vg[sl], vc_ref.view(-1, D)[sl])
+    st_res = F.err_stats(res_out, ref_res)
+    routing, rows = {}, None
+    if is_moe:
+        gate = layer.mlp.gate
+        if cap.get("routing") is not None:
+            idx_f, w_f = cap["routing"]
+            h_router = cap["h_router"]
+        else:  # un-fused path: the gate module ran on its own input
+            idx_f, w_f = cap["gate_out"][0], cap["gate_out"][1]
+            h_router = cap["gate_in"]
+        routing = F.router_proof(ops, h_router, gate.weight.data, gate.e_score_correction_bias, gate.top_k,
+                                 float(gate.routed_scaling_factor), idx_f, w_f, n_valid=T)
+        _, _, choice = O.router_scores(tr["h_router"], lw.gate_w, lw.gate_bias)
+        rows, moved = F.same_set_rows(idx_f.cpu(), tr["idx"], router_margin(choice, gate.top_k), 0.016)
+        routing["rows_moved_by_upstream_rounding"] = len(moved)
+        assert len(moved) <= max(1, T // 8), f"{tag}: {len(moved)}/{T} rows routed differently"
+    st_out = F.err_stats(out, ref_out, rows)
+    st_out32 = F.err_stats(out, out32, rows)
+    st_ref32 = F.err_stats(ref_out, out32, rows)
+    F.report(tag, T=T, seqlens=list(seqlens), layer_idx=layer_idx, k_rows=st_k, v_rows=st_v, residual=st_res,
+             residual_vs_fp32=F.err_stats(res_out, res32), oracle_residual_bf16_vs_fp32=F.err_stats(ref_res, res32),
+             out_vs_oracle_bf16=st_out, out_vs_fp32=st_out32, oracle_bf16_vs_fp32=st_ref32, routing=routing)
+    assert_close_bf16(vg[sl], vc_ref.view(-1, D)[sl], 1, 0.05, atol=2 ** -9, what=f"{tag} v rows")
+    assert_close_bf16(kg[sl], kc_ref.view(-1, D)[sl], 2, 0.05, atol=2 ** -5, what=f"{tag} k rows")
+    # residual = bf16(a + r), a = the o_proj output, r = the residual input (exact).  With few keys per query the attention
+    # output is not averaged down as at ctx = 4096: |a| ~ 1, and a — a K = 12288 sum with cancellation — differs between two
+    # bf16 evaluations by ~2^-9 of its ROW rms (attention P in bf16 here, fp32 in the stand-in oracle), not by ulps of the
+    # element.  Same acceptance as for the layer output: as close to the reference's bf16 result as that is to exact.
+    F.assert_close_like_reference(res_out, ref_res, res32, f"{tag} residual")
+    F.assert_close_like_reference(out, ref_out, out32, f"{tag} out", rows)
+
+
+def test_c3_moe_layer_prefill_ragged(ops):
+    """Prefill side of config 3 at Air dims: three ragged prompts (1, 383 and 640 tokens = 1024 rows, 8192 + 1024 expert
+    rows through the large-M grouped GEMMs), block-permuted slot mapping."""
+    _layer_prefill_case(ops, "C3.layer_moe_prefill_ragged", (383, 1, 640), 1)
+
+
+def test_c3_dense_layer_prefill(ops):
+    """Layer 0 (dense MLP, I=10944) over one 300-token prompt."""
+    _layer_prefill_case(ops, "C3.layer_dense_prefill", (300,), 0)
+
+
 def test_graph_bucket_padding_rows(ops):
     """bs=3 in a 4-bucket at Air dims: the padding row (slot -1, context_len 0, block table -1) goes through the fused
     decode attention (paged_attn.hip) without touching the cache or producing NaNs; the real rows still match."""
