@@ -111,7 +111,30 @@ struct PaFuse {
     int64_t n_slots;
     bf16_t* kc_w;          // writable views of the caches
     bf16_t* vc_w;
+    // optional: the QKV projection handed over as fp32 K-slice partial sums (glm_gemm_bf16_partial) instead of bf16 rows;
+    // the rows are then formed on load as bf16(sum of the slices in slice order + bias), the linear layer's own rounding
+    const float* part;     // [nslices][B][qkv_stride] or nullptr
+    int nslices;
+    int64_t slice_stride;
+    const bf16_t* bias;    // [qkv_stride] or nullptr
 };
+
+// 8 consecutive elements of row b of the packed QKV matrix, starting at column col (a multiple of 8)
+__device__ __forceinline__ u32x4_t pa_qkv8(const PaFuse& fu, int64_t b, int64_t col) {
+    if (fu.part == nullptr) return *reinterpret_cast<const u32x4_t*>(fu.qkv + b * fu.qkv_stride + col);
+    const float* pp = fu.part + b * fu.qkv_stride + col;
+    f32x4_t lo = *reinterpret_cast<const f32x4_t*>(pp), hi = *reinterpret_cast<const f32x4_t*>(pp + 4);
+    for (int sl = 1; sl < fu.nslices; ++sl) {
+        lo += *reinterpret_cast<const f32x4_t*>(pp + sl * fu.slice_stride);
+        hi += *reinterpret_cast<const f32x4_t*>(pp + sl * fu.slice_stride + 4);
+    }
+    if (fu.bias != nullptr) {
+        const u32x4_t bv = *reinterpret_cast<const u32x4_t*>(fu.bias + col);
+        lo[0] += bflo(bv[0]); lo[1] += bfhi(bv[0]); lo[2] += bflo(bv[1]); lo[3] += bfhi(bv[1]);
+        hi[0] += bflo(bv[2]); hi[1] += bfhi(bv[2]); hi[2] += bflo(bv[3]); hi[3] += bfhi(bv[3]);
+    }
+    return u32x4_t{pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]), pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3])};
+}
 
 // NeoX rotation of 8 packed bf16 pairs: y1 = a*cos - b*sin, y2 = b*cos + a*sin (rope8, elementwise.hip)
 __device__ __forceinline__ void pa_rope8(const u32x4_t a, const u32x4_t b, const float* cosp, const float* sinp,
@@ -161,13 +184,13 @@ __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
     bf16x8_t qf[4];
     {
         const bool hv = c < gq;
-        const bf16_t* qrow = FUSED ? fu.qkv + b * fu.qkv_stride + ((int64_t)kvh * gq + (hv ? c : 0)) * PA_HD
-                                   : q + (b * nh + (int64_t)kvh * gq + (hv ? c : 0)) * PA_HD;
+        const int64_t qcol = ((int64_t)kvh * gq + (hv ? c : 0)) * PA_HD;  // FUSED: column of the head in the packed row
+        const bf16_t* qrow = q + (b * nh + (int64_t)kvh * gq + (hv ? c : 0)) * PA_HD;
         u32x4_t v[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             v[ks] = u32x4_t{0, 0, 0, 0};
-            if (hv) v[ks] = *reinterpret_cast<const u32x4_t*>(qrow + 32 * ks + 8 * g);
+            if (hv) v[ks] = FUSED ? pa_qkv8(fu, b, qcol + 32 * ks + 8 * g) : *reinterpret_cast<const u32x4_t*>(qrow + 32 * ks + 8 * g);
         }
         if (FUSED) {  // rotary_dim 64: chunk g of the first half pairs with chunk g of the second half
             const int64_t ps = min(max(fu.pos[b], (int64_t)0), fu.n_pos - 1);
@@ -187,11 +210,11 @@ __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
             // lanes 16-31 copy the V row
             const int sub = lane & 15;
             const bool is_k = lane < 16;
-            const bf16_t* row = fu.qkv + b * fu.qkv_stride + ((int64_t)nh + (is_k ? 0 : nkv) + kvh) * PA_HD;
-            u32x4_t xv = *reinterpret_cast<const u32x4_t*>(row + sub * 8);
+            const int64_t rcol = ((int64_t)nh + (is_k ? 0 : nkv) + kvh) * PA_HD;
+            u32x4_t xv = pa_qkv8(fu, b, rcol + sub * 8);
             if (is_k && sub < 8) {
                 const int partner = sub < 4 ? sub + 4 : sub - 4;
-                const u32x4_t pv = *reinterpret_cast<const u32x4_t*>(row + partner * 8);
+                const u32x4_t pv = pa_qkv8(fu, b, rcol + partner * 8);
                 const int64_t ps = min(max(fu.pos[b], (int64_t)0), fu.n_pos - 1);
                 const float* cosp = fu.cos_sin + ps * 64 + 8 * (sub & 3);
                 u32x4_t y1, y2;
@@ -590,7 +613,36 @@ extern "C" int glm_paged_attn_decode_qkv(const void* qkv, int64_t qkv_stride, co
     PaFuse fu;
     fu.qkv = (const bf16_t*)qkv; fu.qkv_stride = qkv_stride; fu.pos = positions; fu.cos_sin = cos_sin_cache; fu.n_pos = n_pos;
     fu.slots = slot_mapping; fu.n_slots = n_blocks * block_size; fu.kc_w = (bf16_t*)k_cache; fu.vc_w = (bf16_t*)v_cache;
+    fu.part = nullptr; fu.nslices = 0; fu.slice_stride = 0; fu.bias = nullptr;
     return pa_launch(nullptr, k_cache, v_cache, context_lens, block_tables, bt_stride, out, B, nh, nkv, hd, block_size,
                      scale, num_splits, max_context_len, workspace, workspace_bytes, stream, &fu,
                      "glm_paged_attn_decode_qkv");
+}
+
+extern "C" int glm_paged_attn_decode_qkv_partial(const float* qkv_part, int nslices, int64_t slice_stride,
+                                                 const void* qkv_bias, const int64_t* positions,
+                                                 const float* cos_sin_cache, int64_t n_pos, int rotary_dim,
+                                                 const int32_t* slot_mapping, void* k_cache, void* v_cache,
+                                                 const int32_t* context_lens, const int32_t* block_tables,
+                                                 int64_t bt_stride, void* out, int64_t B, int nh, int nkv, int hd,
+                                                 int block_size, int64_t n_blocks, float scale, int num_splits,
+                                                 int max_context_len, void* workspace, size_t workspace_bytes,
+                                                 glm_stream_t stream) {
+    GLM_CHECK_ARG(qkv_part && positions && cos_sin_cache && slot_mapping && k_cache && v_cache && context_lens &&
+                      block_tables && out, GLM_ERR_INVALID, "glm_paged_attn_decode_qkv_partial: null pointer");
+    const int64_t width = (int64_t)(nh + 2 * nkv) * hd;
+    GLM_CHECK_ARG(n_pos > 0 && nslices >= 1 && slice_stride >= B * width, GLM_ERR_INVALID,
+                  "glm_paged_attn_decode_qkv_partial: bad shape (nslices=%d)", nslices);
+    GLM_CHECK_ARG(rotary_dim == 64 && slice_stride % 4 == 0 && n_blocks > 0, GLM_ERR_UNSUPPORTED,
+                  "glm_paged_attn_decode_qkv_partial: needs rotary_dim=64 (got %d)", rotary_dim);
+    GLM_CHECK_ARG(glm_aligned16(qkv_part) && (qkv_bias == nullptr || glm_aligned16(qkv_bias)) && glm_aligned16(k_cache) &&
+                      glm_aligned16(v_cache) && glm_aligned16(out),
+                  GLM_ERR_INVALID, "glm_paged_attn_decode_qkv_partial: pointers must be 16-byte aligned");
+    PaFuse fu;
+    fu.qkv = nullptr; fu.qkv_stride = width; fu.pos = positions; fu.cos_sin = cos_sin_cache; fu.n_pos = n_pos;
+    fu.slots = slot_mapping; fu.n_slots = n_blocks * block_size; fu.kc_w = (bf16_t*)k_cache; fu.vc_w = (bf16_t*)v_cache;
+    fu.part = qkv_part; fu.nslices = nslices; fu.slice_stride = slice_stride; fu.bias = (const bf16_t*)qkv_bias;
+    return pa_launch(nullptr, k_cache, v_cache, context_lens, block_tables, bt_stride, out, B, nh, nkv, hd, block_size,
+                     scale, num_splits, max_context_len, workspace, workspace_bytes, stream, &fu,
+                     "glm_paged_attn_decode_qkv_partial");
 }

@@ -46,6 +46,10 @@ _SIGNATURES = {
     "glm_paged_attn_decode_qkv": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                           c_int64, c_float, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "glm_paged_attn_decode_qkv_partial": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                                  c_int64, c_int, c_int, c_int, c_int, c_int64, c_float, c_int, c_int,
+                                                  c_void_p, c_size_t, c_void_p]),
     "glm_varlen_attn_prefill": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                         c_int, c_int, c_float, c_void_p]),
@@ -321,25 +325,46 @@ def paged_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
     return out
 
 
-def paged_attn_decode_qkv(qkv: torch.Tensor, nh: int, nkv: int, hd: int, positions: torch.Tensor,
+def paged_attn_decode_qkv(qkv, nh: int, nkv: int, hd: int, positions: torch.Tensor,
                           cos_sin_cache: torch.Tensor, rotary_dim: int, slot_mapping: torch.Tensor,
                           k_cache: torch.Tensor, v_cache: torch.Tensor, context_lens: torch.Tensor,
                           block_tables: torch.Tensor, scale: float, num_splits: int = 0,
-                          max_context_len: int = 0) -> torch.Tensor:
+                          max_context_len: int = 0, qkv_bias: torch.Tensor | None = None) -> torch.Tensor:
     """Decode attention straight from the packed QKV rows [B, (nh+2nkv)*hd]: rotary on Q/K, K/V cache store and the
-    paged attention in one launch (no head RMSNorm, rotary_dim 64)."""
-    _bf16(qkv, "qkv"); _bf16(k_cache, "k_cache"); _bf16(v_cache, "v_cache")
-    B = qkv.shape[0]
+    paged attention in one launch (no head RMSNorm, rotary_dim 64).  qkv may be a PartialSum (K-slice partial sums of
+    the QKV projection, gemm_bf16_partial) together with the projection's bias: the kernel reduces them on load."""
+    _bf16(k_cache, "k_cache"); _bf16(v_cache, "v_cache")
+    partial = isinstance(qkv, PartialSum)
+    if partial:
+        part = qkv.part
+        assert part.is_contiguous() and part.dtype == torch.float32 and part.shape[2] == (nh + 2 * nkv) * hd
+        if qkv_bias is not None:
+            _bf16(qkv_bias, "qkv_bias")
+            assert qkv_bias.is_contiguous() and qkv_bias.numel() == part.shape[2]
+        B = part.shape[1]
+        dev_, dt_ = part.device, k_cache.dtype
+    else:
+        _bf16(qkv, "qkv")
+        assert qkv_bias is None, "a bias belongs to partial sums only (bf16 rows already include it)"
+        B = qkv.shape[0]
+        dev_, dt_ = qkv.device, qkv.dtype
     n_blocks, block_size, nkv_c, _ = k_cache.shape
-    assert qkv.dim() == 2 and qkv.stride(1) == 1 and nkv_c == nkv
+    assert nkv_c == nkv and (partial or (qkv.dim() == 2 and qkv.stride(1) == 1))
     assert k_cache.is_contiguous() and v_cache.is_contiguous() and cos_sin_cache.dtype == torch.float32
     assert cos_sin_cache.is_contiguous() and cos_sin_cache.shape[-1] == rotary_dim
     assert positions.dtype == torch.int64 and slot_mapping.dtype == torch.int32
     assert context_lens.dtype == torch.int32 and block_tables.dtype == torch.int32 and block_tables.stride(1) == 1
     lib = load_library()
     need = attn_workspace_bytes(B, nh, nkv, hd, block_size, block_tables.stride(0), num_splits, max_context_len)
-    ws = _attn_workspace(qkv.device, need)
-    out = torch.empty((B, nh, hd), dtype=qkv.dtype, device=qkv.device)
+    ws = _attn_workspace(dev_, need)
+    out = torch.empty((B, nh, hd), dtype=dt_, device=dev_)
+    if partial:
+        _check(lib.glm_paged_attn_decode_qkv_partial(
+            _p(part), part.shape[0], part.shape[1] * part.shape[2], _p(qkv_bias), _p(positions), _p(cos_sin_cache),
+            cos_sin_cache.numel() // rotary_dim, rotary_dim, _p(slot_mapping), _p(k_cache), _p(v_cache), _p(context_lens),
+            _p(block_tables), block_tables.stride(0), _p(out), B, nh, nkv, hd, block_size, n_blocks, scale, num_splits,
+            max_context_len, _p(ws), ws.numel() if ws is not None else 0, _stream()), "glm_paged_attn_decode_qkv_partial")
+        return out
     _check(lib.glm_paged_attn_decode_qkv(_p(qkv), qkv.stride(0), _p(positions), _p(cos_sin_cache),
                                          cos_sin_cache.numel() // rotary_dim, rotary_dim,
                                          _p(slot_mapping), _p(k_cache), _p(v_cache), _p(context_lens),

@@ -66,6 +66,20 @@ class ColumnParallelLinear(LinearBase):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self._gemm(x)
 
+    # decode batches: the output as fp32 K-slice partial sums WITHOUT the bias, for a consumer kernel that reduces them
+    # on load (the fused decode attention).  Measured r02 (Air dims): the QKV GEMM alone 27.2 -> 22.3 us at M=32 and
+    # 21.1 -> 19.9 us at M=1 as 2 slices; the consumer's wider loads give part of it back: layer 474.5 -> 472.2-473.5 us
+    # at bs=32, 141.9 -> 143.3 us at bs=1 — hence only from 17 rows on.
+    partial_slices = 2
+    partial_min_rows = 17
+
+    def can_defer_reduce(self, x: torch.Tensor) -> bool:
+        return (x.dim() == 2 and self.partial_min_rows <= x.shape[0] <= 32 and x.shape[1] >= 2048
+                and x.shape[1] % 8 == 0 and x.is_contiguous())
+
+    def forward_partial(self, x: torch.Tensor):
+        return hip_ops.gemm_bf16_partial(x, self.weight.data, self.partial_slices)
+
 
 class MergedColumnParallelLinear(ColumnParallelLinear):
 

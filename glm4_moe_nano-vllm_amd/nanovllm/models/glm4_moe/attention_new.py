@@ -6,6 +6,8 @@ paged decode / varlen prefill attention → o GEMM (+ RCCL all-reduce when tp > 
 reference's per-call debug file read (attention_new.py:288-292) is not reproduced."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -59,6 +61,7 @@ class Glm4MoeAttention(nn.Module):
                               cache_config=None, quant_config=quant_config, prefix=f"{prefix}.attn")
 
     fuse_decode_attention = True
+    defer_qkv_reduce = os.environ.get("GLM4MOE_DEFER_QKV_REDUCE", "1") != "0"  # A/B switch
 
     def _fusable(self) -> bool:
         lph = self.head_dim // 8
@@ -68,19 +71,26 @@ class Glm4MoeAttention(nn.Module):
     def forward(self, hidden_states: torch.Tensor, positions: torch.Tensor, defer_o_reduce: bool = False):
         """defer_o_reduce: the caller feeds the result straight into RMSNorm.forward(x, residual) and accepts a
         hip_ops.PartialSum (K-slice partial sums of o_proj, reduced inside that add-RMSNorm kernel)."""
-        qkv = self.qkv_proj(hidden_states)
         ctx = get_context()
         attn = self.attn
         has_cache = attn.k_cache.numel() > 0 and attn.v_cache.numel() > 0
         if (self.fuse_decode_attention and not ctx.is_prefill and has_cache and not self.use_qk_norm
-                and self.head_dim == 128 and self.rotary_emb.rotary_dim == 64 and qkv.dim() == 2
+                and self.head_dim == 128 and self.rotary_emb.rotary_dim == 64 and hidden_states.dim() == 2
                 and self.num_heads // self.num_kv_heads <= 16 and attn.k_cache.shape[1] % 32 == 0):
-            # decode: rotary, K/V cache store and paged attention in one launch, straight from the QKV rows
+            # decode: rotary, K/V cache store and paged attention in one launch, straight from the QKV rows — or, at
+            # decode batch sizes, from the QKV projection's K-slice partial sums (reduced + biased on load)
+            bias = None
+            if self.defer_qkv_reduce and self.qkv_proj.can_defer_reduce(hidden_states):
+                qkv = self.qkv_proj.forward_partial(hidden_states)
+                bias = self.qkv_proj.bias.data if self.qkv_proj.bias is not None else None
+            else:
+                qkv = self.qkv_proj(hidden_states)
             o = hip_ops.paged_attn_decode_qkv(
                 qkv, self.num_heads, self.num_kv_heads, self.head_dim, positions, self.rotary_emb.cos_sin_cache,
                 self.rotary_emb.rotary_dim, ctx.slot_mapping, attn.k_cache, attn.v_cache, ctx.context_lens,
-                ctx.block_tables, attn.scale)
+                ctx.block_tables, attn.scale, qkv_bias=bias)
             return self.o_proj(o.reshape(o.shape[0], -1), defer_reduce=defer_o_reduce)
+        qkv = self.qkv_proj(hidden_states)
         if self._fusable():
             need_kv = ctx.is_prefill and ctx.block_tables is None
             q, k, v = hip_ops.qkv_split_norm_rope_store(

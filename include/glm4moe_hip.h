@@ -263,6 +263,18 @@ int glm_paged_attn_decode_qkv(const void* qkv, int64_t qkv_stride, const int64_t
                               int num_splits, int max_context_len, void* workspace,
                               size_t workspace_bytes, glm_stream_t stream);
 
+/* The same launch fed by the QKV projection's fp32 K-slice partial sums (glm_gemm_bf16_partial, [nslices][B][(nh+2nkv)*hd],
+ *     slices slice_stride floats apart) and the projection's bias: a Q/K/V element is formed on load as
+ *     bf16(slice 0 + slice 1 + ... + bias), the linear layer's own output rounding (linear.py:74-75).  The QKV GEMM then
+ *     runs as a K-split over more workgroups (decode: 27 -> 22 us at M=32) and its reduction costs no launch.        */
+int glm_paged_attn_decode_qkv_partial(const float* qkv_part, int nslices, int64_t slice_stride, const void* qkv_bias,
+                                      const int64_t* positions, const float* cos_sin_cache, int64_t n_pos,
+                                      int rotary_dim, const int32_t* slot_mapping, void* k_cache, void* v_cache,
+                                      const int32_t* context_lens, const int32_t* block_tables, int64_t bt_stride,
+                                      void* out, int64_t B, int nh, int nkv, int hd, int block_size, int64_t n_blocks,
+                                      float scale, int num_splits, int max_context_len, void* workspace,
+                                      size_t workspace_bytes, glm_stream_t stream);
+
 /* N3  expert-parallel dispatch / combine (BASELINE config 4; no reference counterpart: parallel_state_ref.py:792-810
  *     only has dead dispatch/combine stubs).  Row pack / unpack around the all-to-all: gather dst[i] = src[idx[i]],
  *     scatter dst[idx[i]] = src[i] (rows of `cols` bf16; idx < 0 skips).  glm_moe_combine_scaled = glm_moe_combine on

@@ -198,6 +198,54 @@ def test_paged_attn_decode_from_qkv(ops, lens, nh, nkv, splits):
     assert torch.equal(out0, out1)
 
 
+@pytest.mark.parametrize("lens,nh,nkv,splits,ns,with_bias", [([300, 256, 5, 33], 4, 2, 0, 2, True),
+                                                              ([2048, 129], 96, 8, 0, 2, True), ([17], 16, 1, 2, 3, False),
+                                                              ([513, 512, 1], 12, 1, 5, 4, True)])
+def test_paged_attn_decode_from_qkv_partial_sums(ops, lens, nh, nkv, splits, ns, with_bias):
+    """The fused decode attention fed by fp32 K-slice partial sums of the QKV projection + bias == the same launch fed by
+    the bf16 rows bf16(slice 0 + slice 1 + ... + bias), bit for bit (outputs and cache contents): the reduction on load
+    is the linear layer's own output rounding (linear.py:74-75)."""
+    _, kc, vc, cl, bt = _paged_case(lens, nh, nkv, seed=len(lens) * 13 + nh)
+    B, hd, bs, rd = len(lens), 128, 256, 64
+    W = (nh + 2 * nkv) * hd
+    g = torch.Generator().manual_seed(4321 + nh)
+    part = torch.randn(ns, B, W, generator=g) * (1.5 / ns ** 0.5)
+    bias = (torch.randn(W, generator=g) * 0.1).to(BF) if with_bias else None
+    tot = part[0].clone()
+    for i in range(1, ns):
+        tot += part[i]
+    if with_bias:
+        tot += bias.float()
+    qkv = tot.to(BF)
+    pos = torch.tensor([n - 1 for n in lens], dtype=torch.int64)
+    slots = torch.tensor([int(bt[b, (n - 1) // bs]) * bs + (n - 1) % bs for b, n in enumerate(lens)], dtype=torch.int32)
+    inv = 1.0 / (1e6 ** (torch.arange(0, rd, 2, dtype=torch.float) / rd))
+    fr = torch.outer(torch.arange(4096, dtype=torch.float), inv)
+    cs = torch.cat((fr.cos(), fr.sin()), -1).unsqueeze(1).contiguous()
+    scale = hd ** -0.5
+    kc0, vc0, kc1, vc1 = dev(kc), dev(vc), dev(kc), dev(vc)
+    out0 = ops.paged_attn_decode_qkv(dev(qkv), nh, nkv, hd, dev(pos), dev(cs), rd, dev(slots), kc0, vc0, dev(cl),
+                                     dev(bt), scale, num_splits=splits)
+    out1 = ops.paged_attn_decode_qkv(ops.PartialSum(dev(part)), nh, nkv, hd, dev(pos), dev(cs), rd, dev(slots), kc1, vc1,
+                                     dev(cl), dev(bt), scale, num_splits=splits,
+                                     qkv_bias=dev(bias) if with_bias else None)
+    assert torch.equal(kc0, kc1) and torch.equal(vc0, vc1), "cache contents differ"
+    assert torch.equal(out0, out1)
+
+
+def test_qkv_projection_as_partial_sums_matches_one_pass(ops):
+    """gemm_bf16_partial at the QKV shape (2 slices) + bias, reduced as the attention kernel does, against the one-pass
+    gemm_bf16: the same bf16 values up to fp32 summation order (<= 1 ulp on a few per cent)."""
+    M, K, N = 32, 4096, 14336
+    x, w = dev(rnd(M, K, seed=401)), dev(rnd(N, K, seed=402, scale=0.02))
+    b = dev(rnd(N, seed=403, scale=0.02))
+    one = ops.gemm_bf16(x, w, b)
+    ps = ops.gemm_bf16_partial(x, w, 2)
+    assert ps.part.shape[0] == 2
+    red = (ps.part[0] + ps.part[1] + b.float()).to(BF)
+    assert_close_bf16(red, one, 1, 0.05, atol=2 ** -9, what="QKV partial sums vs one pass")
+
+
 def test_paged_attn_decode_spiky_scores(ops):
     """Force the online-softmax rescale: one key far above the rest late in the sequence."""
     q, kc, vc, cl, bt = _paged_case([777], 12, 1, seed=99)
