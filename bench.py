@@ -490,9 +490,12 @@ def measure_kernels(model, cfg, ops, B, ctx, world, iters, dev):
     m, md = timeit(f_attn, iters)
     rec("paged_attn_decode", m, md, B * ctx * nkv * hd * 2 * 2, "B*ctx*nkv*hd*2(K,V)*2 B")
 
-    def f_qkv(i):
+    def f_qkv(i):  # as the decoder layer runs it: K-slice partial sums from 17 rows on (reduced by the attention's loads)
         a = attn_layers[i % len(attn_layers)]
-        a.qkv_proj(x)
+        if a.defer_qkv_reduce and a.qkv_proj.can_defer_reduce(x):
+            a.qkv_proj.forward_partial(x)
+        else:
+            a.qkv_proj(x)
     m, md = timeit(f_qkv, iters)
     rec("gemm_qkv", m, md, (nh + 2 * nkv) * hd * H * 2, "(nh+2nkv)*hd*H*2 B of W_qkv")
 

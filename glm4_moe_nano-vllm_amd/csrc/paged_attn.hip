@@ -23,6 +23,10 @@
 #include "common.h"
 #include <string.h>
 
+#ifndef GLM_PA_EARLY_DMA
+#define GLM_PA_EARLY_DMA 1  // 0: the r01 prologue (everything in front of the first K/V DMA) for A/B builds
+#endif
+
 namespace {
 
 constexpr int PA_HD = 128;               // head_dim supported by this kernel
@@ -180,20 +184,59 @@ __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
     const int blk1 = G0 < G1 ? (G1 - 1) / gpb + 1 : 0;
     for (int i = tid; i < blk1 - blk0; i += 256) bt_lds[i] = block_tables[b * bt_stride + blk0 + i];
 
-    // Q^T fragments (B operand): lane (c,g), k-step ks holds Q[head c][32ks + 8g .. +8)
-    bf16x8_t qf[4];
+    // ---- prologue, ordered so that the K/V stream starts as early as possible ----
+    // Everything below needs one memory round trip per line: (1) block table, raw Q chunks, position, the new token's raw
+    // K/V row; (2) cos/sin of the position (address depends on it); (3) the acknowledge of the new row's store.  Only
+    // the block table gates the first K/V DMAs; the new row gates the DMA of the LAST key group alone.  So a workgroup
+    // whose last group is at least four rounds away (all of them at long contexts) starts its ring right after the block
+    // table barrier and finishes the rotary and the new-row store while the first stages are in flight; a raw barrier at
+    // the top of iteration 2 — before any wave can issue that last group — orders the store against its reader.  Before
+    // r02 the whole chain ran in front of the first DMA (~3 round trips; 88.6 us in-graph at C3, 91.7 with the wider
+    // partial-sum loads).
+    const int nmine = (G1 - G0 - wid + PA_WAVES - 1) / PA_WAVES;  // groups G0+wid, +4, ...
+    auto issue = [&](int it) {
+        const int gi = G0 + wid + it * PA_WAVES;
+        const int pb = __builtin_amdgcn_readfirstlane(bt_lds[gi / gpb - blk0]);
+        const int valid = min(PA_GK, len - gi * PA_GK);
+        issue_group(kc, vc, ring + (it & 1) * PA_STAGE, pb, (gi % gpb) * PA_GK, valid, block_size,
+                    nkv, kvh, lane);
+    };
+    const int glast = len > 0 ? (len - 1) / PA_GK : -1;
+    const bool owner = FUSED && len > 0 && glast >= G0 && glast < G1;         // this workgroup reads the new token's key
+    const bool early = GLM_PA_EARLY_DMA && (!owner || glast - G0 >= 4 * PA_WAVES);  // workgroup-uniform
+
+    // (1) raw loads: Q^T chunks (B operand: lane (c,g), k-step ks holds Q[head c][32ks + 8g .. +8)), position, new row
+    const bool hv = c < gq;
+    u32x4_t v[4];
     {
-        const bool hv = c < gq;
         const int64_t qcol = ((int64_t)kvh * gq + (hv ? c : 0)) * PA_HD;  // FUSED: column of the head in the packed row
         const bf16_t* qrow = q + (b * nh + (int64_t)kvh * gq + (hv ? c : 0)) * PA_HD;
-        u32x4_t v[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             v[ks] = u32x4_t{0, 0, 0, 0};
             if (hv) v[ks] = FUSED ? pa_qkv8(fu, b, qcol + 32 * ks + 8 * g) : *reinterpret_cast<const u32x4_t*>(qrow + 32 * ks + 8 * g);
         }
-        if (FUSED) {  // rotary_dim 64: chunk g of the first half pairs with chunk g of the second half
-            const int64_t ps = min(max(fu.pos[b], (int64_t)0), fu.n_pos - 1);
+    }
+    int64_t ps = 0;
+    if (FUSED) ps = min(max(fu.pos[b], (int64_t)0), fu.n_pos - 1);
+    const bool row_lane = owner && wid == 0 && lane < 32;  // lanes 0-15 rotate and store the K row, 16-31 copy the V row
+    const int sub = lane & 15;
+    const bool is_k = lane < 16;
+    u32x4_t xv = {0, 0, 0, 0}, pv = {0, 0, 0, 0};
+    if (FUSED && row_lane) {
+        const int64_t rcol = ((int64_t)nh + (is_k ? 0 : nkv) + kvh) * PA_HD;
+        xv = pa_qkv8(fu, b, rcol + sub * 8);
+        if (is_k && sub < 8) pv = pa_qkv8(fu, b, rcol + (sub < 4 ? sub + 4 : sub - 4) * 8);
+    }
+    __syncthreads();  // block table visible
+    if (early) {
+        if (nmine > 0) issue(0);
+        if (nmine > 1) issue(1);
+    }
+    // (2) rotary (rotary_dim 64: chunk g of the first half pairs with chunk g of the second half)
+    bf16x8_t qf[4];
+    {
+        if (FUSED) {
             const float* cosp = fu.cos_sin + ps * 64 + 8 * g;
             u32x4_t y1, y2;
             pa_rope8(v[0], v[1], cosp, cosp + 32, y1, y2);
@@ -203,36 +246,29 @@ __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_bit_cast(bf16x8_t, v[ks]);
     }
-    if (FUSED && len > 0) {
-        const int glast = (len - 1) / PA_GK;
-        if (glast >= G0 && glast < G1 && wid == 0 && lane < 32) {
-            // this workgroup reads the new token's key: lanes 0-15 rotate and store the K row (16 chunks of 8 dims),
-            // lanes 16-31 copy the V row
-            const int sub = lane & 15;
-            const bool is_k = lane < 16;
-            const int64_t rcol = ((int64_t)nh + (is_k ? 0 : nkv) + kvh) * PA_HD;
-            u32x4_t xv = pa_qkv8(fu, b, rcol + sub * 8);
-            if (is_k && sub < 8) {
-                const int partner = sub < 4 ? sub + 4 : sub - 4;
-                const u32x4_t pv = pa_qkv8(fu, b, rcol + partner * 8);
-                const int64_t ps = min(max(fu.pos[b], (int64_t)0), fu.n_pos - 1);
-                const float* cosp = fu.cos_sin + ps * 64 + 8 * (sub & 3);
-                u32x4_t y1, y2;
-                if (sub < 4) {
-                    pa_rope8(xv, pv, cosp, cosp + 32, y1, y2);
-                    xv = y1;
-                } else {
-                    pa_rope8(pv, xv, cosp, cosp + 32, y1, y2);
-                    xv = y2;
-                }
+    // (3) the new token's K/V row into the cache
+    if (FUSED && row_lane) {
+        if (is_k && sub < 8) {
+            const float* cosp = fu.cos_sin + ps * 64 + 8 * (sub & 3);
+            u32x4_t y1, y2;
+            if (sub < 4) {
+                pa_rope8(xv, pv, cosp, cosp + 32, y1, y2);
+                xv = y1;
+            } else {
+                pa_rope8(pv, xv, cosp, cosp + 32, y1, y2);
+                xv = y2;
             }
-            const int64_t slot = fu.slots[b];
-            if (slot >= 0 && slot < fu.n_slots)
-                *reinterpret_cast<u32x4_t*>((is_k ? fu.kc_w : fu.vc_w) + (slot * nkv + kvh) * PA_HD + sub * 8) = xv;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row is in L2 before the barrier releases the DMA
         }
+        const int64_t slot = fu.slots[b];
+        if (slot >= 0 && slot < fu.n_slots)
+            *reinterpret_cast<u32x4_t*>((is_k ? fu.kc_w : fu.vc_w) + (slot * nkv + kvh) * PA_HD + sub * 8) = xv;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row is in L2 before a barrier releases its reader
     }
-    __syncthreads();  // bt_lds visible; FUSED: new K/V row written
+    if (!early) {
+        __syncthreads();  // new K/V row written before anybody's first DMA (short ranges: the first rounds may hold it)
+        if (nmine > 0) issue(0);
+        if (nmine > 1) issue(1);
+    }
 
     f32x4_t acc[8];
 #pragma unroll
@@ -250,23 +286,15 @@ __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
         for (int dt = 0; dt < 8; ++dt)
             v_rel[dt] = row * PA_ROWB + (((2 * dt + (pp >> 1)) ^ ((row & 7) << 1)) << 4) + ((pp & 1) << 3);
     }
-    // make the Q loads land before the first DMA is issued (otherwise hipcc waits vmcnt(0) for
-    // them at their first use, i.e. with two ring stages already in flight)
+    // the Q fragments are complete here (hipcc waits for their loads; with the early ring that wait also covers the two
+    // stages in flight, which iteration 0 needs anyway) — never inside the loop, where it would drain the ring
     asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
-
-    const int nmine = (G1 - G0 - wid + PA_WAVES - 1) / PA_WAVES;  // groups G0+wid, +4, ...
-    auto issue = [&](int it) {
-        const int gi = G0 + wid + it * PA_WAVES;
-        const int pb = __builtin_amdgcn_readfirstlane(bt_lds[gi / gpb - blk0]);
-        const int valid = min(PA_GK, len - gi * PA_GK);
-        issue_group(kc, vc, ring + (it & 1) * PA_STAGE, pb, (gi % gpb) * PA_GK, valid, block_size,
-                    nkv, kvh, lane);
-    };
-    if (nmine > 0) issue(0);
-    if (nmine > 1) issue(1);
 
     for (int it = 0; it < nmine; ++it) {
         char* st = ring + (it & 1) * PA_STAGE;
+        // the new row's store (wave 0, drained) is ordered before the issue of round 4 and later; rounds 0-3, issued
+        // before this point, cannot hold it (early => the last group is at least four rounds away, every wave gets here)
+        if (FUSED && it == 2 && owner && early) __builtin_amdgcn_s_barrier();
         if (it + 1 < nmine) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 

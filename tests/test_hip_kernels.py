@@ -173,7 +173,12 @@ def test_paged_attn_decode(ops, lens, nh, nkv, splits):
 
 
 @pytest.mark.parametrize("lens,nh,nkv,splits", [([300, 256, 5, 33], 4, 2, 0), ([1, 31, 32, 33, 1000], 24, 2, 3),
-                                                 ([2048, 129], 96, 8, 0), ([17], 16, 1, 2), ([513, 512], 12, 1, 5)])
+                                                 ([2048, 129], 96, 8, 0), ([17], 16, 1, 2), ([513, 512], 12, 1, 5),
+                                                 # one split over many key groups: the ring starts before the new row is
+                                                 # stored (513 = the new key alone in the last group; 544 = 17 groups, the
+                                                 # shortest range that takes that path; 512 = 16 groups, the longest that
+                                                 # does not)
+                                                 ([1500, 513, 544, 512], 12, 1, 1), ([4096, 3000], 16, 2, 1)])
 def test_paged_attn_decode_from_qkv(ops, lens, nh, nkv, splits):
     """One launch (rotary + K/V cache store + attention from the packed QKV rows) == split/rope/store followed by
     the paged attention, bit for bit: outputs and cache contents."""
@@ -200,7 +205,8 @@ def test_paged_attn_decode_from_qkv(ops, lens, nh, nkv, splits):
 
 @pytest.mark.parametrize("lens,nh,nkv,splits,ns,with_bias", [([300, 256, 5, 33], 4, 2, 0, 2, True),
                                                               ([2048, 129], 96, 8, 0, 2, True), ([17], 16, 1, 2, 3, False),
-                                                              ([513, 512, 1], 12, 1, 5, 4, True)])
+                                                              ([513, 512, 1], 12, 1, 5, 4, True),
+                                                              ([1500, 544, 512], 12, 1, 1, 2, True)])
 def test_paged_attn_decode_from_qkv_partial_sums(ops, lens, nh, nkv, splits, ns, with_bias):
     """The fused decode attention fed by fp32 K-slice partial sums of the QKV projection + bias == the same launch fed by
     the bf16 rows bf16(slice 0 + slice 1 + ... + bias), bit for bit (outputs and cache contents): the reduction on load

@@ -16,8 +16,9 @@ import csv, glob, json, statistics, collections, re
 names = {  # kernel-name pattern -> bench.py kernel key
     r"gemm_smallm_dma_kernel<1,": "grouped_gemm_gateup_silu",
     r"gemm_smallm_dma_kernel<2,": "grouped_gemm_down",
-    r"gemm_smallm_dma_kernel<0, 2, 1, 2, 2": "gemm_qkv",  # lm_head shares the config; the median over launches is QKV
-    r"gemm_smallm_dma_kernel<0, 2, 1, 4, 2": "gemm_o",
+    # K-slice partial-sum launches: QKV (2 slices of 14336 columns, 117 MB) and o_proj (4 slices of 4096, 101 MB) share
+    # the kernel; told apart by the grid (Grid_Size_X = column tiles x 128 threads)
+    r"gemm_smallm_dma_kernel<0, 2, 1, 4, 2": "gemm_partial",
     r"paged_attn_decode_kernel": "paged_attn_decode",
     r"gemm_largem_kernel<1,": "grouped_gemm_gateup_silu@prefill16k",
     r"gemm_largem_kernel<2,": "grouped_gemm_down@prefill16k",
@@ -27,7 +28,16 @@ for f in glob.glob("$R/gpurun_out/pmc_tr/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         for pat, key in names.items():
             if pat in r["Kernel_Name"]:
+                if key == "gemm_partial":
+                    key = f"gemm_partial@grid{r.get('Grid_Size', '?')}"
                 vals[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+# the two partial-sum launches of a layer: the one that fetches more is QKV (117 MB of weights against 101 MB)
+parts = sorted((k for k in vals if k.startswith("gemm_partial@") and "FETCH_SIZE" in vals[k]),
+               key=lambda k: -statistics.median(vals[k]["FETCH_SIZE"]))
+for k, name in zip(parts, ("gemm_qkv", "gemm_o")):
+    vals[name] = vals.pop(k)
+for k in [k for k in vals if k.startswith("gemm_partial@")]:
+    vals.pop(k)
 out = {}
 for key, d in vals.items():
     if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
