@@ -23,10 +23,6 @@
 #include "common.h"
 #include <string.h>
 
-#ifndef GLM_PA_EARLY_DMA
-#define GLM_PA_EARLY_DMA 1  // 0: the r01 prologue (everything in front of the first K/V DMA) for A/B builds
-#endif
-
 namespace {
 
 constexpr int PA_HD = 128;               // head_dim supported by this kernel
@@ -37,7 +33,8 @@ constexpr int PA_NSTAGE = 2;
 constexpr int PA_WAVES = 4;
 constexpr int PA_RING = PA_NSTAGE * PA_STAGE;  // per wave
 constexpr int PA_MAX_BT = 4096;                // block-table entries cached in LDS per workgroup
-constexpr int PA_LDS = PA_WAVES * PA_RING + PA_MAX_BT * 4;
+constexpr int PA_NEWROW = 2 * PA_ROWB;             // FUSED: the new token's rotated K row | V row, natural chunk order
+constexpr int PA_LDS = PA_WAVES * PA_RING + PA_MAX_BT * 4 + PA_NEWROW;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
@@ -58,6 +55,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 template <int OFF>
 __device__ __forceinline__ void lds_read_b128(u32x4_t& dst, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+__device__ __forceinline__ void lds_write_b128(unsigned addr, const u32x4_t& v) {
+    asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 template <int OFF>
 __device__ __forceinline__ void lds_read_tr16_b64(u32x2_t& dst, unsigned addr) {
@@ -185,14 +185,12 @@ __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
     for (int i = tid; i < blk1 - blk0; i += 256) bt_lds[i] = block_tables[b * bt_stride + blk0 + i];
 
     // ---- prologue, ordered so that the K/V stream starts as early as possible ----
-    // Everything below needs one memory round trip per line: (1) block table, raw Q chunks, position, the new token's raw
-    // K/V row; (2) cos/sin of the position (address depends on it); (3) the acknowledge of the new row's store.  Only
-    // the block table gates the first K/V DMAs; the new row gates the DMA of the LAST key group alone.  So a workgroup
-    // whose last group is at least four rounds away (all of them at long contexts) starts its ring right after the block
-    // table barrier and finishes the rotary and the new-row store while the first stages are in flight; a raw barrier at
-    // the top of iteration 2 — before any wave can issue that last group — orders the store against its reader.  Before
-    // r02 the whole chain ran in front of the first DMA (~3 round trips; 88.6 us in-graph at C3, 91.7 with the wider
-    // partial-sum loads).
+    // One memory round trip per line: (1) block table, raw Q chunks, position, slot, the new token's raw K/V row; (2)
+    // cos/sin of the position.  Only the block table gates the K/V DMAs.  The new token's row never has to come back from
+    // the cache: wave 0 rotates it, leaves it in LDS (PA_NEWROW) and fires the cache store without waiting for it; the
+    // wave that reaches the last key group overwrites that row (and the clamped copies of it behind it) in its landed
+    // stage before it reads fragments.  Before r02 the row was stored, acknowledged and barriered in front of the first
+    // DMA: ~4 round trips of prologue (in-graph 88.6 us at C3 against 85.8 us for the plain kernel).
     const int nmine = (G1 - G0 - wid + PA_WAVES - 1) / PA_WAVES;  // groups G0+wid, +4, ...
     auto issue = [&](int it) {
         const int gi = G0 + wid + it * PA_WAVES;
@@ -202,8 +200,8 @@ __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
                     nkv, kvh, lane);
     };
     const int glast = len > 0 ? (len - 1) / PA_GK : -1;
-    const bool owner = FUSED && len > 0 && glast >= G0 && glast < G1;         // this workgroup reads the new token's key
-    const bool early = GLM_PA_EARLY_DMA && (!owner || glast - G0 >= 4 * PA_WAVES);  // workgroup-uniform
+    const bool owner = FUSED && len > 0 && glast >= G0 && glast < G1;  // this workgroup reads the new token's key
+    char* newrow = smem + PA_WAVES * PA_RING + PA_MAX_BT * 4;
 
     // (1) raw loads: Q^T chunks (B operand: lane (c,g), k-step ks holds Q[head c][32ks + 8g .. +8)), position, new row
     const bool hv = c < gq;
@@ -223,16 +221,16 @@ __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
     const int sub = lane & 15;
     const bool is_k = lane < 16;
     u32x4_t xv = {0, 0, 0, 0}, pv = {0, 0, 0, 0};
+    int64_t slot = -1;
     if (FUSED && row_lane) {
         const int64_t rcol = ((int64_t)nh + (is_k ? 0 : nkv) + kvh) * PA_HD;
         xv = pa_qkv8(fu, b, rcol + sub * 8);
         if (is_k && sub < 8) pv = pa_qkv8(fu, b, rcol + (sub < 4 ? sub + 4 : sub - 4) * 8);
+        slot = fu.slots[b];
     }
     __syncthreads();  // block table visible
-    if (early) {
-        if (nmine > 0) issue(0);
-        if (nmine > 1) issue(1);
-    }
+    if (nmine > 0) issue(0);
+    if (nmine > 1) issue(1);
     // (2) rotary (rotary_dim 64: chunk g of the first half pairs with chunk g of the second half)
     bf16x8_t qf[4];
     {
@@ -259,15 +257,13 @@ __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
                 xv = y2;
             }
         }
-        const int64_t slot = fu.slots[b];
-        if (slot >= 0 && slot < fu.n_slots)
+        lds_write_b128(lds_addr(newrow) + (is_k ? 0 : PA_ROWB) + sub * 16, xv);
+        if (slot >= 0 && slot < fu.n_slots)  // for later steps; nobody in this launch reads it back
             *reinterpret_cast<u32x4_t*>((is_k ? fu.kc_w : fu.vc_w) + (slot * nkv + kvh) * PA_HD + sub * 8) = xv;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row is in L2 before a barrier releases its reader
     }
-    if (!early) {
-        __syncthreads();  // new K/V row written before anybody's first DMA (short ranges: the first rounds may hold it)
-        if (nmine > 0) issue(0);
-        if (nmine > 1) issue(1);
+    if (owner) {  // workgroup-uniform: the row in LDS is visible to the wave that will reach the last group
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 
     f32x4_t acc[8];
@@ -292,11 +288,22 @@ __global__ __launch_bounds__(256, 2) void paged_attn_decode_kernel(
 
     for (int it = 0; it < nmine; ++it) {
         char* st = ring + (it & 1) * PA_STAGE;
-        // the new row's store (wave 0, drained) is ordered before the issue of round 4 and later; rounds 0-3, issued
-        // before this point, cannot hold it (early => the last group is at least four rounds away, every wave gets here)
-        if (FUSED && it == 2 && owner && early) __builtin_amdgcn_s_barrier();
         if (it + 1 < nmine) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (FUSED && owner && G0 + wid + it * PA_WAVES == glast) {
+            // the stage holds the cache's (stale) image of position len-1 and, behind it, the clamped re-reads of that
+            // row (issue_group): all of them become the new token's row, in the stage's swizzled chunk order
+            const int r0 = (len - 1) % PA_GK, p16 = lane & 15;
+            u32x4_t nk, nv;
+            lds_read_b128<0>(nk, lds_addr(newrow) + p16 * 16);
+            lds_read_b128<PA_ROWB>(nv, lds_addr(newrow) + p16 * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nk), "+v"(nv)::"memory");
+            for (int row = r0 + (lane >> 4); row < PA_GK; row += 4) {
+                lds_write_b128(lds_addr(st) + row * PA_ROWB + ((p16 ^ (row & 15)) << 4), nk);
+                lds_write_b128(lds_addr(st) + PA_GK * PA_ROWB + row * PA_ROWB + ((p16 ^ ((row & 7) << 1)) << 4), nv);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
 
         // ---- fragment reads: K (row reads, 16 B) and V (transposed reads, 8 B) ----
         // K: lane (c,g) reads row 16t+c, chunk (4ks+g)^c.  V: lane 4qq+pp of group g reads row
