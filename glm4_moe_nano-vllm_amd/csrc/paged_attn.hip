@@ -104,7 +104,8 @@ __device__ __forceinline__ void issue_group(const bf16_t* __restrict__ kc, const
 //   * Q: lane (head c, g) holds dims [32ks + 8g, +8) of its head; NeoX pairs (d, d+32) for d < 32 are this lane's
 //     ks=0 / ks=1 fragments, so the rotation is lane-local (same arithmetic and rounding as rope8 in elementwise.hip).
 //   * K/V of the new token: the workgroup whose key range holds position len-1 rotates the K row, writes K and V
-//     to the cache slot, waits for the writes and only then (workgroup barrier) lets its waves start their DMA.
+//     to the cache slot (not waited for) and keeps the row in LDS; the wave that reaches the last key group patches it
+//     into its landed stage (see the prologue comment in the kernel).
 struct PaFuse {
     const bf16_t* qkv;     // [B, (nh + 2 nkv) * 128]
     int64_t qkv_stride;    // elements per row
