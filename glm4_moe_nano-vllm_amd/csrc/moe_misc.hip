@@ -153,6 +153,7 @@ struct RouterPre {
     // that finishes last (per-token ticket) gathers the logits and selects
     unsigned* tok_ticket;   // [T], zero before the first launch, restored by the kernel
     float* lg_global;       // [T, E] logits (already rounded to bf16 precision)
+    int gate_lds;           // split launch: the workgroup's gate rows are staged in LDS by DMA at kernel entry (host: they fit)
 };
 
 // bytes of the x-row area in front of lg[]: the bf16 row, or (fused norm) the hand-over area of the squares chain,
@@ -177,6 +178,36 @@ __device__ unsigned long long g_rtrace[RTRACE_WGS * RTRACE_SLOTS];
 #define RT_MARK(i) ((void)0)
 #endif
 
+// workgroup barrier that orders LDS traffic only (no wait for vector-memory operations in flight)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// bytes of one wave's gate row in LDS (whole 1 KiB DMA pieces)
+__host__ __device__ inline size_t router_gate_row_bytes(int H) { return (size_t)((H / 8 + 63) / 64) * 1024; }
+// LDS offset of the staged gate rows: behind the x-row area, the logits and the bias
+__host__ __device__ inline size_t router_gate_lds_offset(int H, int E, bool fused_norm) {
+    return (router_x_bytes(H, fused_norm) + (size_t)(E > 16 ? E : 16) * 4 + ROUTER_MAX_E * 4 + 15) & ~(size_t)15;
+}
+
+// Split launch: wave w of workgroup (t, y) owns gate row e = y * ceil(E / gridDim.y) + w.  The row does not depend on the
+// activations, so its 2 H bytes are requested into LDS by DMA as early as the wave can afford — no registers held, no
+// load the compiler could sink — and the dot product later reads it from LDS instead of waiting 2-3 us for cold HBM.
+__device__ __forceinline__ void router_stage_gate_row(const RouterPre& pre, const bf16_t* gw, char* smem, int H, int E,
+                                                      bool fused_norm, int lane, int wid) {
+    if (!pre.gate_lds) return;
+    const int Eg = (E + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int e = blockIdx.y * Eg + wid;
+    if (wid >= Eg || e >= E) return;
+    const int nvec = H >> 3;
+    const bf16_t* grow = gw + (int64_t)e * H;
+    char* dst = smem + router_gate_lds_offset(H, E, fused_norm) + (size_t)wid * router_gate_row_bytes(H);
+    for (int u = 0; 64 * u < nvec; ++u)  // lanes past the row re-read its last chunk into padding nobody reads
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(grow + (int64_t)min(64 * u + lane, nvec - 1) * 8),
+                                         (__attribute__((address_space(3))) void*)(dst + u * 1024), 16, 0, 0);
+}
+
 // SPLIT: the experts of a token are divided over gridDim.y workgroups (compile-time: the two dot-product loops in one
 // kernel body pushed the 1024-thread kernel past its 128-VGPR budget)
 template <int PRE, bool SPLIT>
@@ -192,16 +223,44 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
     const int nvec = H >> 3;
     RT_MARK(0);
     constexpr int EPL = ROUTER_MAX_E / 64;
+    // The correction bias is needed by wave 0 only after the logits and is cold by then (~2.5 us): requested as an
+    // LDS-DMA — no register to hold, nothing the compiler could sink to the use — behind the input loads (a wave's vector
+    // memory returns in order) and in front of the gate-row DMAs (hipcc drains vmcnt before an LDS-DMA that follows
+    // others).  No barrier up to the selection may wait for it: they are raw barriers that order LDS traffic only.
+    float* bias_l = lg + (E > 16 ? E : 16);  // [ROUTER_MAX_E]
+    auto stage_bias = [&]() {
+        if (wid == 0) {
+#pragma unroll
+            for (int i = 0; i < EPL; ++i)
+                if (64 * i < E)  // lanes past E re-read the last entry into slots nobody reads
+                    __builtin_amdgcn_global_load_lds(
+                        (__attribute__((address_space(1))) const void*)(bias + min(64 * i + lane, E - 1)),
+                        (__attribute__((address_space(3))) void*)(bias_l + 64 * i), 4, 0, 0);
+        }
+    };
     if (PRE == 0) {
         const u32x4_t* src = reinterpret_cast<const u32x4_t*>(x + t * H);
         u32x4_t* dst = reinterpret_cast<u32x4_t*>(xs);
         for (int i = tid; i < nvec; i += ROUTER_NT) dst[i] = src[i];
+        stage_bias();
     } else {
         // add-RMSNorm, one 8-element vector per thread (host checks H <= 8 * ROUTER_NT); same arithmetic and
         // rounding points as rmsnorm_vec_kernel<ADD> / add_rmsnorm_partial_kernel in elementwise.hip
         float s8[8];
         float ss = 0.f;
         const bool act = tid < nvec;
+        // the norm weight is requested with the inputs: a load issued behind the gate-row DMAs below would, when waited
+        // for, wait for them as well (vector memory returns in order)
+        // ... and unpacked at once, so that no wait for it is left behind the DMAs
+        float nwf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (act) {
+            const u32x4_t nw = reinterpret_cast<const u32x4_t*>(pre.norm_w)[tid];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                nwf[2 * j] = bflo(nw[j]);
+                nwf[2 * j + 1] = bfhi(nw[j]);
+            }
+        }
         if (act) {
             float xv[8];
             if (PRE == 1) {
@@ -214,16 +273,20 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
             } else {
                 const float* pp = pre.part + t * H + (int64_t)tid * 8;
                 f32x4_t a = *reinterpret_cast<const f32x4_t*>(pp), b = *reinterpret_cast<const f32x4_t*>(pp + 4);
-                for (int s0 = 1; s0 < pre.nslices; s0 += 4) {  // slice order, up to 4 loads in flight (8 cost 64 VGPRs)
-                    f32x4_t ta[4], tb[4];
+                // slice order; all loads of a group in flight together: one memory round trip per group.  The split
+                // kernel has the registers for 8 at once (o_proj hands over 8 slices: one round trip instead of two),
+                // the unsplit one sits at its 128-VGPR budget with 4
+                constexpr int SG = SPLIT ? 8 : 4;
+                for (int s0 = 1; s0 < pre.nslices; s0 += SG) {
+                    f32x4_t ta[SG], tb[SG];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < SG; ++j) {
                         const int sl = min(s0 + j, pre.nslices - 1);
                         ta[j] = *reinterpret_cast<const f32x4_t*>(pp + sl * pre.slice_stride);
                         tb[j] = *reinterpret_cast<const f32x4_t*>(pp + sl * pre.slice_stride + 4);
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < SG; ++j)
                         if (s0 + j < pre.nslices) {
                             a += ta[j];
                             b += tb[j];
@@ -245,6 +308,8 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
             }
             if (blockIdx.y == 0) reinterpret_cast<u32x4_t*>(pre.res_out + t * H)[tid] = ov;
         }
+        stage_bias();
+        if constexpr (SPLIT) router_stage_gate_row(pre, gw, smem, H, E, true, lane, wid);
         // sum of squares in EXACTLY the stand-alone kernels' order (rmsnorm_vec_kernel / add_rmsnorm_partial_kernel run
         // 256 threads, thread j folding vectors j, j+256, ... into one sequential chain): threads >= 256 hand their 8
         // values to thread tid % 256 through LDS (the x-row area, not yet in use), which continues its chain with them.
@@ -256,7 +321,8 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
 #pragma unroll
             for (int j = 0; j < 8; ++j) xch[(tid - 256) * 8 + j] = s8[j];
         }
-        __syncthreads();
+        // the barriers of the norm order LDS traffic only and must not wait for the gate-row / bias DMAs in flight
+        lds_barrier();
         if (act && tid < 256) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) ss += s8[j] * s8[j];
@@ -270,37 +336,23 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
         }
         ss = wave_sum(ss);
         if (lane == 0) lg[wid] = ss;
-        __syncthreads();
+        lds_barrier();
         float tot = 0.f;
 #pragma unroll
         for (int w = 0; w < ROUTER_NT / 64; ++w) tot += lg[w];
-        __syncthreads();
+        lds_barrier();
         const float rstd = 1.0f / sqrtf(tot / (float)H + pre.eps);
         if (act) {
-            const u32x4_t wv = reinterpret_cast<const u32x4_t*>(pre.norm_w)[tid];
             u32x4_t o;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float a = rbf(s8[2 * i] * rstd) * bflo(wv[i]);
-                const float b = rbf(s8[2 * i + 1] * rstd) * bfhi(wv[i]);
+                const float a = rbf(s8[2 * i] * rstd) * nwf[2 * i];
+                const float b = rbf(s8[2 * i + 1] * rstd) * nwf[2 * i + 1];
                 o[i] = pack2bf(a, b);
             }
             if (blockIdx.y == 0) reinterpret_cast<u32x4_t*>(pre.y + t * H)[tid] = o;
             reinterpret_cast<u32x4_t*>(xs)[tid] = o;
         }
-    }
-    // the correction bias is needed by wave 0 only after the logits (~5 us from here) and is cold by then (~2.5 us):
-    // requested now as an LDS-DMA — no register to hold, nothing the compiler could sink to the use — behind the input
-    // loads (vector memory returns in order).  The barrier below must not wait for it: only LDS traffic (the normalised
-    // row) has to be complete, hence the raw barrier instead of __syncthreads().
-    float* bias_l = lg + (E > 16 ? E : 16);  // [ROUTER_MAX_E]
-    if (wid == 0) {
-#pragma unroll
-        for (int i = 0; i < EPL; ++i)
-            if (64 * i < E)  // lanes past E re-read the last entry into slots nobody reads
-                __builtin_amdgcn_global_load_lds(
-                    (__attribute__((address_space(1))) const void*)(bias + min(64 * i + lane, E - 1)),
-                    (__attribute__((address_space(3))) void*)(bias_l + 64 * i), 4, 0, 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -317,8 +369,12 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
         // H <= 8 * ROUTER_NT (host check) -> at most 16 K steps per lane, taken 8 at a time (all of H = 4096 in one go;
         // 16 at once cost 64 VGPRs and pushed the 1024-thread kernel over its 128-register budget)
         constexpr int STEPS = 8;
+        const bool staged = pre.gate_lds != 0;  // then Eg <= 16: one expert per wave, its row is in LDS
+        if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's own row has landed
         for (int e = e_lo + wid; e < e_hi; e += ROUTER_NT / 64) {
-            const u32x4_t* grow = reinterpret_cast<const u32x4_t*>(gw + (int64_t)e * H);
+            const u32x4_t* grow = staged ? reinterpret_cast<const u32x4_t*>(smem + router_gate_lds_offset(H, E, PRE != 0) +
+                                                                            (size_t)wid * router_gate_row_bytes(H))
+                                         : reinterpret_cast<const u32x4_t*>(gw + (int64_t)e * H);
             float acc = 0.f;
             for (int c0 = 0; c0 < nvec; c0 += 64 * STEPS) {
                 u32x4_t wv[STEPS];
@@ -900,17 +956,30 @@ static int add_rmsnorm_router_impl(const void* x, const float* part, int nslices
     pre.tok_ticket = nullptr; pre.lg_global = nullptr;
     // experts of a token over several workgroups (16 gate rows each) when the workspace holds the logits and the tickets
     unsigned G = 1;
+    size_t lds = shm;
+    pre.gate_lds = 0;
     if (workspace != nullptr && E >= 32 && T <= (int64_t)ROUTER_WS_TICKETS &&
         workspace_bytes >= ROUTER_WS_HEAD + (size_t)T * E * sizeof(float)) {
         G = (unsigned)((E + 15) / 16);
         pre.tok_ticket = workspace + 16;
         pre.lg_global = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ROUTER_WS_HEAD);
+        // the workgroup's gate rows staged in LDS when they fit beside the row and the logits (H = 4096: 16 x 8 KiB)
+        const unsigned Eg = ((unsigned)E + G - 1) / G;
+        const size_t with_rows = router_gate_lds_offset(H, E, true) + (size_t)Eg * router_gate_row_bytes(H);
+        if (Eg <= ROUTER_NT / 64 && with_rows <= 160 * 1024) {
+            pre.gate_lds = 1;
+            lds = with_rows > shm ? with_rows : shm;
+        }
     }
     const dim3 grid((unsigned)T, G);
-#define GLM_ROUTER_LAUNCH(PRE_, SPLIT_)                                                                                 \
-    hipLaunchKernelGGL((router_topk_kernel<PRE_, SPLIT_>), grid, dim3(ROUTER_NT), shm, glm_s(stream), (const bf16_t*)y, \
-                       (const bf16_t*)gate_w, e_score_correction_bias, topk_idx, (bf16_t*)topk_w, (bf16_t*)nullptr, H,  \
-                       E, k, routed_scaling_factor, pre)
+#define GLM_ROUTER_LAUNCH(PRE_, SPLIT_)                                                                                  \
+    do {                                                                                                                 \
+        if (lds > 64 * 1024)                                                                                             \
+            GLM_SET_MAX_LDS((router_topk_kernel<PRE_, SPLIT_>), 160 * 1024, "glm_add_rmsnorm_router_topk");               \
+        hipLaunchKernelGGL((router_topk_kernel<PRE_, SPLIT_>), grid, dim3(ROUTER_NT), lds, glm_s(stream),                \
+                           (const bf16_t*)y, (const bf16_t*)gate_w, e_score_correction_bias, topk_idx, (bf16_t*)topk_w,  \
+                           (bf16_t*)nullptr, H, E, k, routed_scaling_factor, pre);                                       \
+    } while (0)
     if (x) {
         if (G > 1) GLM_ROUTER_LAUNCH(1, true);
         else GLM_ROUTER_LAUNCH(1, false);
