@@ -966,7 +966,8 @@ static int add_rmsnorm_router_impl(const void* x, const float* part, int nslices
         // the workgroup's gate rows staged in LDS when they fit beside the row and the logits (H = 4096: 16 x 8 KiB)
         const unsigned Eg = ((unsigned)E + G - 1) / G;
         const size_t with_rows = router_gate_lds_offset(H, E, true) + (size_t)Eg * router_gate_row_bytes(H);
-        if (Eg <= ROUTER_NT / 64 && with_rows <= 160 * 1024) {
+        // ... and only while the grid is one workgroup per CU anyway: the rows cost the second workgroup of a CU
+        if (Eg <= ROUTER_NT / 64 && with_rows <= 160 * 1024 && T * (int64_t)G <= 256) {
             pre.gate_lds = 1;
             lds = with_rows > shm ? with_rows : shm;
         }
