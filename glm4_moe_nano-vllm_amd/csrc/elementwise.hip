@@ -314,73 +314,90 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(
     bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, const int32_t* __restrict__ slots,
     int64_t n_slots, int64_t T, int nh, int nkv) {
     constexpr int hd = 8 * LPH;
+    constexpr int TPB = 4;  // tokens per workgroup, their loads in flight together
     const int nheads = nh + 2 * nkv;
-    const int64_t gid = (int64_t)blockIdx.x * (256 / LPH) + threadIdx.x / LPH;
+    // grid = (block of TPB tokens, block of 256 / LPH heads): no per-thread 64-bit division, and a thread moves 4 x 16 B
+    // instead of 16 B — at T = 16384 the one-chunk-per-thread form launched 114688 workgroups of 8 KB each and ran at
+    // 2.2 TB/s (459 us for 1 GB)
+    const int hraw = (int)blockIdx.y * (256 / LPH) + (int)threadIdx.x / LPH;
     const int sub = threadIdx.x % LPH;
-    const bool valid = gid < T * nheads;
-    const int64_t t = valid ? gid / nheads : 0;
-    const int hh = valid ? (int)(gid % nheads) : 0;
+    const bool hvalid = hraw < nheads;
+    const int hh = hvalid ? hraw : 0;
     const bool is_q = hh < nh, is_k = !is_q && hh < nh + nkv;
-
-    u32x4_t xv = {0, 0, 0, 0};
-    if (valid) xv = *reinterpret_cast<const u32x4_t*>(qkv + t * qkvs + (int64_t)hh * hd + sub * 8);
-
-    // optional per-head RMSNorm on q / k (a4): y = bf16(w32 * (x32 * rstd))
     const bf16_t* nw = is_q ? qnw : (is_k ? knw : nullptr);
-    if (nw != nullptr) {  // uniform per LPH-group; shuffles below run for all lanes
-        float s[8];
-        float ss = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[2 * j] = bflo(xv[j]);
-            s[2 * j + 1] = bfhi(xv[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ss += s[j] * s[j];
-#pragma unroll
-        for (int o = LPH / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        const float rstd = 1.0f / sqrtf(ss / (float)hd + eps);
-        u32x4_t wv = *reinterpret_cast<const u32x4_t*>(nw + sub * 8);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            xv[j] = pack2bf(bflo(wv[j]) * (s[2 * j] * rstd), bfhi(wv[j]) * (s[2 * j + 1] * rstd));
-    }
-
-    // rotary on q and k: chunk `sub` pairs with chunk sub±nc
     const int nc = rd >> 4;
-    {
-        const int partner = sub < nc ? sub + nc : sub - nc;  // only meaningful for sub < 2nc
-        const int src_lane = (threadIdx.x & 63) - sub + (partner & (LPH - 1));
-        u32x4_t pv;
+    const bool rot = (is_q || is_k) && sub < 2 * nc;
+    const bool to_cache = !is_q && kc != nullptr && slots != nullptr;
+
+    u32x4_t xv[TPB];
+    int64_t pp[TPB], sl[TPB];
+    bool tv[TPB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pv[j] = __shfl(xv[j], src_lane, 64);
-        if (valid && (is_q || is_k) && sub < 2 * nc) {
-            const int64_t p = pos[t];
-            const int u = sub < nc ? sub : sub - nc;
-            const float* cosp = cs + p * rd + u * 8;
-            const float* sinp = cosp + (rd >> 1);
-            u32x4_t y1, y2;
-            if (sub < nc) {
-                rope8(xv, pv, cosp, sinp, y1, y2);
-                xv = y1;
-            } else {
-                rope8(pv, xv, cosp, sinp, y1, y2);
-                xv = y2;
+    for (int i = 0; i < TPB; ++i) {
+        const int64_t t = (int64_t)blockIdx.x * TPB + i;
+        tv[i] = hvalid && t < T;
+        xv[i] = u32x4_t{0, 0, 0, 0};
+        pp[i] = 0;
+        sl[i] = -1;
+        if (tv[i]) {
+            xv[i] = *reinterpret_cast<const u32x4_t*>(qkv + t * qkvs + (int64_t)hh * hd + sub * 8);
+            if (rot) pp[i] = pos[t];
+            if (to_cache) sl[i] = slots[t];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TPB; ++i) {
+        const int64_t t = (int64_t)blockIdx.x * TPB + i;
+        // optional per-head RMSNorm on q / k (a4): y = bf16(w32 * (x32 * rstd))
+        if (nw != nullptr) {  // uniform per LPH-group; shuffles below run for all lanes
+            float s[8];
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[2 * j] = bflo(xv[i][j]);
+                s[2 * j + 1] = bfhi(xv[i][j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += s[j] * s[j];
+#pragma unroll
+            for (int o = LPH / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            const float rstd = 1.0f / sqrtf(ss / (float)hd + eps);
+            u32x4_t wv = *reinterpret_cast<const u32x4_t*>(nw + sub * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                xv[i][j] = pack2bf(bflo(wv[j]) * (s[2 * j] * rstd), bfhi(wv[j]) * (s[2 * j + 1] * rstd));
+        }
+        // rotary on q and k: chunk `sub` pairs with chunk sub±nc
+        {
+            const int partner = sub < nc ? sub + nc : sub - nc;  // only meaningful for sub < 2nc
+            const int src_lane = (threadIdx.x & 63) - sub + (partner & (LPH - 1));
+            u32x4_t pv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pv[j] = __shfl(xv[i][j], src_lane, 64);
+            if (tv[i] && rot) {
+                const int u = sub < nc ? sub : sub - nc;
+                const float* cosp = cs + pp[i] * rd + u * 8;
+                const float* sinp = cosp + (rd >> 1);
+                u32x4_t y1, y2;
+                if (sub < nc) {
+                    rope8(xv[i], pv, cosp, sinp, y1, y2);
+                    xv[i] = y1;
+                } else {
+                    rope8(pv, xv[i], cosp, sinp, y1, y2);
+                    xv[i] = y2;
+                }
             }
         }
-    }
-    if (!valid) return;
-    if (is_q) {
-        *reinterpret_cast<u32x4_t*>(qo + (t * nh + hh) * hd + sub * 8) = xv;
-    } else {
-        const int kh = is_k ? hh - nh : hh - nh - nkv;
-        bf16_t* o = is_k ? ko : vo;
-        if (o != nullptr) *reinterpret_cast<u32x4_t*>(o + (t * nkv + kh) * hd + sub * 8) = xv;
-        if (kc != nullptr && slots != nullptr) {
-            const int64_t slot = slots[t];
-            if (slot >= 0 && slot < n_slots) {
-                bf16_t* c = (is_k ? kc : vc) + (slot * nkv + kh) * hd + sub * 8;
-                *reinterpret_cast<u32x4_t*>(c) = xv;
+        if (!tv[i]) continue;
+        if (is_q) {
+            *reinterpret_cast<u32x4_t*>(qo + (t * nh + hh) * hd + sub * 8) = xv[i];
+        } else {
+            const int kh = is_k ? hh - nh : hh - nh - nkv;
+            bf16_t* o = is_k ? ko : vo;
+            if (o != nullptr) *reinterpret_cast<u32x4_t*>(o + (t * nkv + kh) * hd + sub * 8) = xv[i];
+            if (to_cache && sl[i] >= 0 && sl[i] < n_slots) {
+                bf16_t* c = (is_k ? kc : vc) + (sl[i] * nkv + kh) * hd + sub * 8;
+                *reinterpret_cast<u32x4_t*>(c) = xv[i];
             }
         }
     }
@@ -674,9 +691,11 @@ extern "C" int glm_qkv_split_norm_rope_store(const void* qkv, int64_t qkv_stride
                   "(hd=%d rotary_dim=%d)", hd, rotary_dim);
     if (T == 0) return GLM_OK;
     hipStream_t st = glm_s(stream);
-    const int64_t groups = T * (int64_t)(nh + 2 * nkv);
+    GLM_CHECK_ARG(T <= 0x7fffffffll, GLM_ERR_UNSUPPORTED, "glm_qkv_split_norm_rope_store: too many rows (%ld)", (long)T);
+    const int nheads_all = nh + 2 * nkv;
 #define QKVP(L)                                                                                      \
-    hipLaunchKernelGGL((qkv_post_kernel<L>), dim3(nblocks(groups, 256 / L)), dim3(256), 0, st,       \
+    hipLaunchKernelGGL((qkv_post_kernel<L>), dim3((unsigned)((T + 3) / 4), (unsigned)((nheads_all + 256 / L - 1) / (256 / L))), \
+                       dim3(256), 0, st,                                                             \
                        (const bf16_t*)qkv, qkv_stride, (bf16_t*)q_out, (bf16_t*)k_out,               \
                        (bf16_t*)v_out, (const bf16_t*)q_norm_w, (const bf16_t*)k_norm_w, eps,        \
                        positions, cos_sin_cache, rotary_dim, (bf16_t*)k_cache, (bf16_t*)v_cache,     \

@@ -178,6 +178,135 @@ __device__ unsigned long long g_rtrace[RTRACE_WGS * RTRACE_SLOTS];
 #define RT_MARK(i) ((void)0)
 #endif
 
+// R2..R7 for ONE token by ONE wave (moe.py:28-50): lane owns experts lane + 64 i.  lg: the token's E logits (fp32 values
+// of bf16 precision), bias_l: the E correction biases, both in LDS; keys_scratch: 64 words of LDS (E <= 64 path),
+// wl_scratch: k bf16 of LDS (write-through output form only).  Shared by the decode router kernel (its wave 0) and by
+// router_select_kernel (prefill: logits from a GEMM) so that both select bit-identically.
+template <int EPL>
+__device__ __forceinline__ void router_select_wave(const float* lg, const float* bias_l, unsigned* keys_scratch,
+                                                   bf16_t* wl_scratch, int lane, int E, int k, float rsf, int64_t t,
+                                                   int64_t* __restrict__ topk_idx, bf16_t* __restrict__ topk_w,
+                                                   bf16_t* __restrict__ logits_out, bool write_through) {
+    // wave 0: R2..R7.  lane owns experts lane + 64*i.
+    float sc[EPL], ch[EPL];
+    bool sel[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int e = lane + 64 * i;
+        sel[i] = false;
+        if (e < E) {
+            const float l = lg[e];
+            if (logits_out) logits_out[t * E + e] = f2bf(l);
+            sc[i] = rbf(sigmoid_f(l));  // R2: bf16 sigmoid
+            ch[i] = sc[i] + bias_l[e];  // R3: fp32 (bias buffer is fp32)
+        } else {
+            sc[i] = 0.f;
+            ch[i] = -INFINITY;
+        }
+    }
+    // R4: k rounds of wave arg-max (ties → lowest expert id).  NaN scores are demoted to -inf so the
+    // comparisons stay a total order and every lane agrees on the winner.
+#pragma unroll
+    for (int i = 0; i < EPL; ++i)
+        if (!(ch[i] == ch[i])) ch[i] = -INFINITY;
+    // Each candidate becomes one 64-bit key (order-preserving image of the score, then ~id so that the lowest id wins
+    // a tie); "no candidate" is key 0.  The wave maximum runs on DPP row permutations and the two lane-swap
+    // instructions instead of 12 LDS round trips (ds_bpermute) per round.
+    unsigned kh[EPL], kl[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int e = lane + 64 * i;
+        const unsigned u = __float_as_uint(ch[i] + 0.0f);  // -0 -> +0: equal scores must give equal keys
+        kh[i] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        kl[i] = ~(unsigned)e;
+        if (e >= E) kh[i] = 0u, kl[i] = 0u;
+    }
+    auto take_max = [](unsigned& hi, unsigned& lo, unsigned ohi, unsigned olo) {
+        const bool take = ohi > hi || (ohi == hi && olo > lo);
+        hi = take ? ohi : hi;
+        lo = take ? olo : lo;
+    };
+    if (E <= 64) {
+        // one expert per lane: selected <=> fewer than k experts precede it in the total order (key descending, then id
+        // ascending) — the same set the k arg-max rounds below pick, in ~1/4 of the instructions.  Keys go through LDS
+        // (the x row is dead) and come back as broadcast 16-byte reads.
+        unsigned* keys = keys_scratch;
+        keys[lane] = kh[0];  // lanes >= E hold key 0, below every real key
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned mine = kh[0];
+        int rank = 0;
+#pragma unroll
+        for (int j4 = 0; j4 < 16; ++j4) {
+            const u32x4_t kk = reinterpret_cast<const u32x4_t*>(keys)[j4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = 4 * j4 + q;
+                rank += (kk[q] > mine || (kk[q] == mine && j < lane)) ? 1 : 0;
+            }
+        }
+        sel[0] = lane < E && rank < k;
+    } else
+    for (int r = 0; r < k; ++r) {
+        unsigned hi = 0u, lo = 0u;
+#pragma unroll
+        for (int i = 0; i < EPL; ++i)
+            if (!sel[i]) take_max(hi, lo, kh[i], kl[i]);
+#define GLM_DPP_STEP(CTRL)                                                                                      \
+    take_max(hi, lo, (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xF, 0xF, true),                   \
+             (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xF, 0xF, true))
+        GLM_DPP_STEP(0xB1);   // quad_perm [1,0,3,2]: lane ^ 1
+        GLM_DPP_STEP(0x4E);   // quad_perm [2,3,0,1]: lane ^ 2
+        GLM_DPP_STEP(0x141);  // row_half_mirror: the other quad of the 8
+        GLM_DPP_STEP(0x140);  // row_mirror: the other 8 of the row
+#undef GLM_DPP_STEP
+        {
+            const u32x2_t a = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+            const u32x2_t b = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+            hi = a[0], lo = b[0];
+            take_max(hi, lo, a[1], b[1]);
+            const u32x2_t c2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+            const u32x2_t d = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+            hi = c2[0], lo = d[0];
+            take_max(hi, lo, c2[1], d[1]);
+        }
+        const int bi = (int)~lo;  // wave-uniform; k <= E guarantees a candidate
+#pragma unroll
+        for (int i = 0; i < EPL; ++i)
+            if (lane + 64 * i == bi) sel[i] = true;
+    }
+    // R5/R6: weights = scores (without bias) of the selected experts, renormalised in bf16
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i)
+        if (sel[i]) part += sc[i];
+    const float den = rbf(rbf(wave_sum(part)) + 1e-20f);
+    // output in ascending expert id: position = #selected experts with a smaller id.  When another workgroup of this
+    // launch buckets the pairs (fuse_align, k even) the routing is stored write-through: ids as 8-byte sc1 stores, the
+    // weights staged in LDS and stored as aligned 4-byte words
+    const bool wt = write_through && (k & 1) == 0;
+    bf16_t* wl = wl_scratch;  // the logits live in registers by now; 2 k <= 4 E bytes
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const unsigned long long m = __ballot(sel[i]);
+        if (sel[i]) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < k) {
+                const bf16_t wv = f2bf(rbf(sc[i] / den) * rsf);  // R6 then R7
+                if (wt) {
+                    st_sc1_u64(topk_idx + t * k + pos, (unsigned long long)(lane + 64 * i));
+                    wl[pos] = wv;
+                } else {
+                    topk_idx[t * k + pos] = lane + 64 * i;
+                    topk_w[t * k + pos] = wv;
+                }
+            }
+        }
+        base += __popcll(m);
+    }
+    if (wt && lane < (k >> 1)) st_sc1_u32(topk_w + t * k + 2 * lane, reinterpret_cast<const unsigned*>(wl)[lane]);
+}
+
 // workgroup barrier that orders LDS traffic only (no wait for vector-memory operations in flight)
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -470,126 +599,9 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
     const bool fuse_align = pre.al_offsets != nullptr;  // uniform (kernel argument)
     if (wid != 0 && !fuse_align) return;
     if (wid == 0) {
-
-    // wave 0: R2..R7.  lane owns experts lane + 64*i.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the bias DMA has landed
-    float sc[EPL], ch[EPL];
-    bool sel[EPL];
-#pragma unroll
-    for (int i = 0; i < EPL; ++i) {
-        const int e = lane + 64 * i;
-        sel[i] = false;
-        if (e < E) {
-            const float l = lg[e];
-            if (logits_out) logits_out[t * E + e] = f2bf(l);
-            sc[i] = rbf(sigmoid_f(l));  // R2: bf16 sigmoid
-            ch[i] = sc[i] + bias_l[e];  // R3: fp32 (bias buffer is fp32)
-        } else {
-            sc[i] = 0.f;
-            ch[i] = -INFINITY;
-        }
-    }
-    // R4: k rounds of wave arg-max (ties → lowest expert id).  NaN scores are demoted to -inf so the
-    // comparisons stay a total order and every lane agrees on the winner.
-#pragma unroll
-    for (int i = 0; i < EPL; ++i)
-        if (!(ch[i] == ch[i])) ch[i] = -INFINITY;
-    // Each candidate becomes one 64-bit key (order-preserving image of the score, then ~id so that the lowest id wins
-    // a tie); "no candidate" is key 0.  The wave maximum runs on DPP row permutations and the two lane-swap
-    // instructions instead of 12 LDS round trips (ds_bpermute) per round.
-    unsigned kh[EPL], kl[EPL];
-#pragma unroll
-    for (int i = 0; i < EPL; ++i) {
-        const int e = lane + 64 * i;
-        const unsigned u = __float_as_uint(ch[i] + 0.0f);  // -0 -> +0: equal scores must give equal keys
-        kh[i] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-        kl[i] = ~(unsigned)e;
-        if (e >= E) kh[i] = 0u, kl[i] = 0u;
-    }
-    auto take_max = [](unsigned& hi, unsigned& lo, unsigned ohi, unsigned olo) {
-        const bool take = ohi > hi || (ohi == hi && olo > lo);
-        hi = take ? ohi : hi;
-        lo = take ? olo : lo;
-    };
-    if (E <= 64) {
-        // one expert per lane: selected <=> fewer than k experts precede it in the total order (key descending, then id
-        // ascending) — the same set the k arg-max rounds below pick, in ~1/4 of the instructions.  Keys go through LDS
-        // (the x row is dead) and come back as broadcast 16-byte reads.
-        unsigned* keys = reinterpret_cast<unsigned*>(smem);
-        keys[lane] = kh[0];  // lanes >= E hold key 0, below every real key
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const unsigned mine = kh[0];
-        int rank = 0;
-#pragma unroll
-        for (int j4 = 0; j4 < 16; ++j4) {
-            const u32x4_t kk = reinterpret_cast<const u32x4_t*>(keys)[j4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = 4 * j4 + q;
-                rank += (kk[q] > mine || (kk[q] == mine && j < lane)) ? 1 : 0;
-            }
-        }
-        sel[0] = lane < E && rank < k;
-    } else
-    for (int r = 0; r < k; ++r) {
-        unsigned hi = 0u, lo = 0u;
-#pragma unroll
-        for (int i = 0; i < EPL; ++i)
-            if (!sel[i]) take_max(hi, lo, kh[i], kl[i]);
-#define GLM_DPP_STEP(CTRL)                                                                                      \
-    take_max(hi, lo, (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xF, 0xF, true),                   \
-             (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xF, 0xF, true))
-        GLM_DPP_STEP(0xB1);   // quad_perm [1,0,3,2]: lane ^ 1
-        GLM_DPP_STEP(0x4E);   // quad_perm [2,3,0,1]: lane ^ 2
-        GLM_DPP_STEP(0x141);  // row_half_mirror: the other quad of the 8
-        GLM_DPP_STEP(0x140);  // row_mirror: the other 8 of the row
-#undef GLM_DPP_STEP
-        {
-            const u32x2_t a = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-            const u32x2_t b = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-            hi = a[0], lo = b[0];
-            take_max(hi, lo, a[1], b[1]);
-            const u32x2_t c2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-            const u32x2_t d = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-            hi = c2[0], lo = d[0];
-            take_max(hi, lo, c2[1], d[1]);
-        }
-        const int bi = (int)~lo;  // wave-uniform; k <= E guarantees a candidate
-#pragma unroll
-        for (int i = 0; i < EPL; ++i)
-            if (lane + 64 * i == bi) sel[i] = true;
-    }
-    // R5/R6: weights = scores (without bias) of the selected experts, renormalised in bf16
-    float part = 0.f;
-#pragma unroll
-    for (int i = 0; i < EPL; ++i)
-        if (sel[i]) part += sc[i];
-    const float den = rbf(rbf(wave_sum(part)) + 1e-20f);
-    // output in ascending expert id: position = #selected experts with a smaller id.  When another workgroup of this
-    // launch buckets the pairs (fuse_align, k even) the routing is stored write-through: ids as 8-byte sc1 stores, the
-    // weights staged in LDS and stored as aligned 4-byte words
-    const bool wt = fuse_align && (k & 1) == 0;
-    bf16_t* wl = reinterpret_cast<bf16_t*>(lg);  // the logits live in registers by now; 2 k <= 4 E bytes
-    int base = 0;
-#pragma unroll
-    for (int i = 0; i < EPL; ++i) {
-        const unsigned long long m = __ballot(sel[i]);
-        if (sel[i]) {
-            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-            if (pos < k) {
-                const bf16_t wv = f2bf(rbf(sc[i] / den) * rsf);  // R6 then R7
-                if (wt) {
-                    st_sc1_u64(topk_idx + t * k + pos, (unsigned long long)(lane + 64 * i));
-                    wl[pos] = wv;
-                } else {
-                    topk_idx[t * k + pos] = lane + 64 * i;
-                    topk_w[t * k + pos] = wv;
-                }
-            }
-        }
-        base += __popcll(m);
-    }
-    if (wt && lane < (k >> 1)) st_sc1_u32(topk_w + t * k + 2 * lane, reinterpret_cast<const unsigned*>(wl)[lane]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the bias DMA has landed
+        router_select_wave<EPL>(lg, bias_l, reinterpret_cast<unsigned*>(smem), reinterpret_cast<bf16_t*>(lg), lane, E, k,
+                                rsf, t, topk_idx, topk_w, logits_out, fuse_align);
     }  // wave 0
     RT_MARK(7);  // selection stored
     if (!fuse_align) return;
@@ -641,6 +653,35 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Prefill-size router: R1 (logits = bf16(x . Wg^T), moe.py:33) is a plain [T, H] x [H, E] GEMM there (glm_gemm_bf16) and
+// this kernel does R2..R7 from its bf16 output, one wave per token, with the decode kernel's own selection code.  At
+// T = 16384 the token-per-workgroup kernel above costs 1.2 ms per layer (65536 workgroups of 1024 threads, each redoing
+// the norm and pulling 128 KiB of gate rows from L2); norm + GEMM + this + bucketing cost 0.34 ms.
+__global__ __launch_bounds__(256) void router_select_kernel(const bf16_t* __restrict__ logits, int64_t ld_logits,
+                                                            const float* __restrict__ bias,
+                                                            int64_t* __restrict__ topk_idx, bf16_t* __restrict__ topk_w,
+                                                            int64_t T, int E, int k, float rsf) {
+    constexpr int EPL = ROUTER_MAX_E / 64;
+    __shared__ float lg_s[4][ROUTER_MAX_E];
+    __shared__ float bias_s[ROUTER_MAX_E];
+    __shared__ unsigned keys_s[4][64];
+    __shared__ bf16_t wl_s[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int e = tid; e < E; e += 256) bias_s[e] = bias[e];
+    const int64_t t = (int64_t)blockIdx.x * 4 + wid;
+    if (t < T) {
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) {
+            const int e = lane + 64 * i;
+            if (e < E) lg_s[wid][e] = bf2f(logits[t * ld_logits + e]);
+        }
+    }
+    __syncthreads();
+    if (t >= T) return;
+    router_select_wave<EPL>(lg_s[wid], bias_s, keys_s[wid], wl_s[wid], lane, E, k, rsf, t, topk_idx, topk_w, nullptr, false);
+}
+
+// ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void moe_align_kernel(
     const int64_t* __restrict__ topk_idx, const bf16_t* __restrict__ topk_w,
     int32_t* __restrict__ expert_offsets, int32_t* __restrict__ sorted_token,
@@ -649,6 +690,91 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(
     __shared__ int cnt[ALIGN_MAX_G + 1];
     __shared__ int cur[ALIGN_MAX_G + 1];
     moe_align_body<false>(topk_idx, topk_w, expert_offsets, sorted_token, sorted_scale, pair_pos, T, k, E, with_shared, cnt, cur);
+}
+
+// ------------------------------------------------------------------------------------------
+// Bucketing at prefill sizes (T k >= ALIGN_PAR_MIN_PAIRS): the single-workgroup kernel above walks 131072 pairs in 128
+// serial rounds (200 us at T = 16384).  Three launches over chunks of ALIGN_CHUNK pairs instead:
+//   count:   chunk c histograms its pairs in LDS and reserves, per expert, a range inside the expert's group with ONE
+//            global add per (chunk, expert): base[c][e] = atomicAdd(total[e], hist[e])  (total[] zeroed by the host side)
+//   offsets: exclusive scan of total[] -> expert_offsets (one wave)
+//   scatter: chunk c redoes its LDS ranking from expert_offsets[e] + base[c][e] and writes the rows.
+// Rows of one expert end up in arrival order of the chunks' adds — as with the LDS atomics of the small kernel the order
+// inside a group is not specified (no consumer depends on it: pair_pos carries the permutation).
+constexpr int ALIGN_CHUNK = 8192;  // pairs per workgroup (8 per thread)
+
+__global__ __launch_bounds__(1024) void moe_align_count_kernel(const int64_t* __restrict__ topk_idx, int64_t P, int E,
+                                                               int32_t* __restrict__ total, int32_t* __restrict__ base) {
+    __shared__ int hist[ALIGN_MAX_G];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < E; e += 1024) hist[e] = 0;
+    __syncthreads();
+    const int64_t p0 = (int64_t)blockIdx.x * ALIGN_CHUNK;
+#pragma unroll
+    for (int i = 0; i < ALIGN_CHUNK / 1024; ++i) {
+        const int64_t p = p0 + i * 1024 + tid;
+        if (p < P) {
+            const int64_t e = topk_idx[p];
+            if (e >= 0 && e < E) atomicAdd(&hist[(int)e], 1);
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < E; e += 1024) {
+        const int c = hist[e];
+        base[(int64_t)blockIdx.x * E + e] = c ? atomicAdd(&total[e], c) : 0;
+    }
+}
+
+__global__ __launch_bounds__(64) void moe_align_offsets_kernel(const int32_t* __restrict__ total, int E, int64_t T,
+                                                               int with_shared, int32_t* __restrict__ expert_offsets) {
+    const int lane = threadIdx.x;
+    int run = 0;
+    for (int e0 = 0; e0 < E; e0 += 64) {
+        const int e = e0 + lane;
+        const int c = e < E ? total[e] : 0;
+        const int incl = wave_scan_incl(c);
+        if (e < E) expert_offsets[e] = run + incl - c;
+        run += __builtin_amdgcn_readlane(incl, 63);
+    }
+    if (lane == 0) {
+        expert_offsets[E] = run;
+        if (with_shared) expert_offsets[E + 1] = run + (int)T;
+    }
+}
+
+__global__ __launch_bounds__(1024) void moe_align_scatter_kernel(
+    const int64_t* __restrict__ topk_idx, const bf16_t* __restrict__ topk_w, const int32_t* __restrict__ expert_offsets,
+    const int32_t* __restrict__ base, int32_t* __restrict__ sorted_token, bf16_t* __restrict__ sorted_scale,
+    int32_t* __restrict__ pair_pos, int64_t T, int k, int E, int with_shared) {
+    __shared__ int cur[ALIGN_MAX_G];
+    const int tid = threadIdx.x;
+    const int64_t P = T * k;
+    for (int e = tid; e < E; e += 1024) cur[e] = expert_offsets[e] + base[(int64_t)blockIdx.x * E + e];
+    __syncthreads();
+    const int64_t p0 = (int64_t)blockIdx.x * ALIGN_CHUNK;
+#pragma unroll
+    for (int i = 0; i < ALIGN_CHUNK / 1024; ++i) {
+        const int64_t p = p0 + i * 1024 + tid;
+        if (p < P) {
+            const int64_t e = topk_idx[p];
+            if (e >= 0 && e < E) {
+                const int pos = atomicAdd(&cur[(int)e], 1);
+                sorted_token[pos] = (int32_t)(p / k);
+                sorted_scale[pos] = topk_w[p];
+                pair_pos[p] = pos;
+            } else {
+                pair_pos[p] = -1;
+            }
+        }
+    }
+    if (with_shared) {  // the shared group's rows of this chunk's token range
+        const int sbase = expert_offsets[E];
+        const int64_t t0 = (int64_t)blockIdx.x * ALIGN_CHUNK;  // chunks outnumber ceil(T / ALIGN_CHUNK): k >= 1
+        for (int64_t t = t0 + tid; t < min(T, t0 + ALIGN_CHUNK); t += 1024) {
+            sorted_token[sbase + t] = (int32_t)t;
+            sorted_scale[sbase + t] = 0x3F80;  // bf16 1.0
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -878,6 +1004,22 @@ extern "C" int glm_router_topk(const void* x, const void* gate_w,
     return GLM_OK;
 }
 
+extern "C" int glm_router_select(const void* logits, int64_t ld_logits, const float* e_score_correction_bias,
+                                 int64_t* topk_idx, void* topk_w, int64_t T, int E, int k,
+                                 float routed_scaling_factor, glm_stream_t stream) {
+    GLM_CHECK_ARG(logits && e_score_correction_bias && topk_idx && topk_w, GLM_ERR_INVALID, "glm_router_select: null pointer");
+    GLM_CHECK_ARG(T >= 0 && E > 0 && k > 0 && k <= E && ld_logits >= E, GLM_ERR_INVALID,
+                  "glm_router_select: bad shape T=%ld E=%d k=%d", (long)T, E, k);
+    GLM_CHECK_ARG(E <= ROUTER_MAX_E && k <= 64 && T <= 0x7fffffffll * 4, GLM_ERR_UNSUPPORTED,
+                  "glm_router_select: needs E<=256, k<=64 (E=%d k=%d)", E, k);
+    if (T == 0) return GLM_OK;
+    hipLaunchKernelGGL(router_select_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, glm_s(stream),
+                       (const bf16_t*)logits, ld_logits, e_score_correction_bias, topk_idx, (bf16_t*)topk_w, T, E, k,
+                       routed_scaling_factor);
+    GLM_CHECK_LAUNCH("glm_router_select");
+    return GLM_OK;
+}
+
 static int add_rmsnorm_router_impl(const void* x, const float* part, int nslices, int64_t slice_stride,
                                    const void* residual_in, const void* norm_weight, float eps, void* y,
                                    void* residual_out, const void* gate_w, const float* e_score_correction_bias,
@@ -1005,6 +1147,40 @@ extern "C" int glm_moe_align(const int64_t* topk_idx, const void* topk_w, int32_
                        (const bf16_t*)topk_w, expert_offsets, sorted_token, (bf16_t*)sorted_scale,
                        pair_pos, T, k, E, with_shared);
     GLM_CHECK_LAUNCH("glm_moe_align");
+    return GLM_OK;
+}
+
+extern "C" size_t glm_moe_align_workspace_bytes(int64_t T, int k, int E) {
+    const int64_t P = (T > 0 ? T : 0) * (int64_t)(k > 0 ? k : 0);
+    const int64_t chunks = (P + ALIGN_CHUNK - 1) / ALIGN_CHUNK;
+    return (size_t)(E > 0 ? E : 0) * sizeof(int32_t) * (size_t)(1 + chunks);
+}
+
+// glm_moe_align over many workgroups (prefill sizes).  workspace: glm_moe_align_workspace_bytes(T, k, E), its first E
+// words (the per-expert totals) ZERO on entry — the caller clears them (hipMemsetAsync / a zeroed tensor) per call.
+extern "C" int glm_moe_align_parallel(const int64_t* topk_idx, const void* topk_w, int32_t* expert_offsets,
+                                      int32_t* sorted_token, void* sorted_scale, int32_t* pair_pos, int64_t T, int k,
+                                      int E, int with_shared, int32_t* workspace, size_t workspace_bytes,
+                                      glm_stream_t stream) {
+    GLM_CHECK_ARG(topk_idx && topk_w && expert_offsets && sorted_token && sorted_scale && pair_pos && workspace,
+                  GLM_ERR_INVALID, "glm_moe_align_parallel: null pointer");
+    GLM_CHECK_ARG(T >= 0 && k > 0 && E > 0, GLM_ERR_INVALID, "glm_moe_align_parallel: bad shape");
+    GLM_CHECK_ARG(E < ALIGN_MAX_G && T * (int64_t)(k + 1) < (1ll << 31), GLM_ERR_UNSUPPORTED,
+                  "glm_moe_align_parallel: needs E<%d and T*(k+1) < 2^31", ALIGN_MAX_G);
+    GLM_CHECK_ARG(workspace_bytes >= glm_moe_align_workspace_bytes(T, k, E), GLM_ERR_WORKSPACE,
+                  "glm_moe_align_parallel: workspace %zu < %zu bytes", workspace_bytes, glm_moe_align_workspace_bytes(T, k, E));
+    const int64_t P = T * k;
+    const unsigned chunks = (unsigned)((P + ALIGN_CHUNK - 1) / ALIGN_CHUNK);
+    hipStream_t st = glm_s(stream);
+    int32_t* total = workspace;
+    int32_t* base = workspace + E;
+    if (chunks > 0)
+        hipLaunchKernelGGL(moe_align_count_kernel, dim3(chunks), dim3(1024), 0, st, topk_idx, P, E, total, base);
+    hipLaunchKernelGGL(moe_align_offsets_kernel, dim3(1), dim3(64), 0, st, total, E, T, with_shared, expert_offsets);
+    if (chunks > 0)
+        hipLaunchKernelGGL(moe_align_scatter_kernel, dim3(chunks), dim3(1024), 0, st, topk_idx, (const bf16_t*)topk_w,
+                           expert_offsets, base, sorted_token, (bf16_t*)sorted_scale, pair_pos, T, k, E, with_shared);
+    GLM_CHECK_LAUNCH("glm_moe_align_parallel");
     return GLM_OK;
 }
 

@@ -55,6 +55,10 @@ _SIGNATURES = {
                                         c_int, c_int, c_float, c_void_p]),
     "glm_router_topk": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    "glm_moe_align_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "glm_moe_align_parallel": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                       c_int, c_void_p, c_size_t, c_void_p]),
+    "glm_router_select": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     "glm_moe_align": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                               c_int, c_int, c_int, c_void_p]),
     "glm_grouped_gemm_gateup_silu": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p,
@@ -392,6 +396,29 @@ def varlen_attn_prefill(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, scale
 
 # ------------------------------------------------------------------------------------------
 # MoE
+# From this many rows on the router's logits (R1, moe.py:33: bf16(x . Wg^T)) are computed as what they are at that size,
+# a [T, H] x [H, E] GEMM, and glm_router_select does R2..R7 from them; below, the token-per-workgroup kernel
+# (glm_router_topk / the fused add-RMSNorm + router + bucketing launch), which is built for decode latency: at T = 16384
+# it takes 1.2 ms per layer against 0.34 ms for norm + GEMM + select + bucketing (tools/prefill_router_probe.py).
+ROUTER_GEMM_MIN_ROWS = 1024
+
+
+def router_by_gemm(T: int, E: int) -> bool:
+    return T >= ROUTER_GEMM_MIN_ROWS and E % 8 == 0  # the GEMM kernels want 16-byte output rows
+
+
+def router_select(logits: torch.Tensor, bias: torch.Tensor, k: int, routed_scaling_factor: float):
+    """R2..R7 from bf16 logits [T, E] (glm_router_select): (topk_idx int64 ascending per row, topk_w bf16)."""
+    _bf16(logits, "logits")
+    assert bias.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1
+    T, E = logits.shape
+    idx = torch.empty((T, k), dtype=torch.int64, device=logits.device)
+    w = torch.empty((T, k), dtype=torch.bfloat16, device=logits.device)
+    _check(load_library().glm_router_select(_p(logits), logits.stride(0), _p(bias), _p(idx), _p(w), T, E, k,
+                                            routed_scaling_factor, _stream()), "glm_router_select")
+    return idx, w
+
+
 def router_topk(x: torch.Tensor, gate_w: torch.Tensor, bias: torch.Tensor, k: int,
                 routed_scaling_factor: float, return_logits: bool = False):
     _bf16(x, "x"); _bf16(gate_w, "gate_w")
@@ -399,6 +426,10 @@ def router_topk(x: torch.Tensor, gate_w: torch.Tensor, bias: torch.Tensor, k: in
     T, H = x.shape
     E = gate_w.shape[0]
     x = x.contiguous()
+    if router_by_gemm(T, E):
+        logits = gemm_bf16(x, gate_w, None)
+        idx, w = router_select(logits, bias, k, routed_scaling_factor)
+        return (idx, w, logits) if return_logits else (idx, w)
     idx = torch.empty((T, k), dtype=torch.int64, device=x.device)
     w = torch.empty((T, k), dtype=torch.bfloat16, device=x.device)
     logits = torch.empty((T, E), dtype=torch.bfloat16, device=x.device) if return_logits else None
@@ -439,6 +470,14 @@ def add_rmsnorm_router_topk(x, residual: torch.Tensor, norm_weight: torch.Tensor
     r2 = residual.reshape(-1, H).contiguous()
     T = r2.shape[0]
     E = gate_w.shape[0]
+    if router_by_gemm(T, E) and not isinstance(x, PartialSum):
+        # prefill sizes: norm, logits GEMM + selection, bucketing as separate launches (see ROUTER_GEMM_MIN_ROWS)
+        yn, rn = add_rmsnorm(x.reshape(-1, H), r2, norm_weight, eps)
+        idx, w = router_topk(yn, gate_w, bias, k, routed_scaling_factor)
+        if align_with_shared is None:
+            return yn.view(residual.shape), rn.view(residual.shape), idx, w
+        return (yn.view(residual.shape), rn.view(residual.shape), idx, w,
+                moe_align(idx, w, E, bool(align_with_shared)))
     y = torch.empty_like(r2)
     ro = torch.empty_like(r2)
     idx = torch.empty((T, k), dtype=torch.int64, device=r2.device)
@@ -474,6 +513,9 @@ def add_rmsnorm_router_topk(x, residual: torch.Tensor, norm_weight: torch.Tensor
     return y.view(residual.shape), ro.view(residual.shape), idx, w
 
 
+ALIGN_PARALLEL_MIN_PAIRS = 16384  # from here on the one-workgroup bucketing kernel is the slower one (200 us at 131072 pairs)
+
+
 def moe_align(topk_idx: torch.Tensor, topk_w: torch.Tensor, E: int, with_shared: bool):
     T, k = topk_idx.shape
     G = E + (1 if with_shared else 0)
@@ -483,6 +525,13 @@ def moe_align(topk_idx: torch.Tensor, topk_w: torch.Tensor, E: int, with_shared:
     tok = torch.empty(R, dtype=torch.int32, device=dev)
     scale = torch.empty(R, dtype=torch.bfloat16, device=dev)
     pos = torch.empty(T * k, dtype=torch.int32, device=dev)
+    if T * k >= ALIGN_PARALLEL_MIN_PAIRS:  # prefill sizes: count / offsets / scatter over many workgroups
+        lib = load_library()
+        ws = torch.zeros(lib.glm_moe_align_workspace_bytes(T, k, E) // 4, dtype=torch.int32, device=dev)
+        _check(lib.glm_moe_align_parallel(_p(topk_idx), _p(topk_w), _p(offs), _p(tok), _p(scale), _p(pos), T, k, E,
+                                          1 if with_shared else 0, _p(ws), ws.numel() * 4, _stream()),
+               "glm_moe_align_parallel")
+        return offs, tok, scale, pos
     _check(load_library().glm_moe_align(_p(topk_idx), _p(topk_w), _p(offs), _p(tok), _p(scale),
                                         _p(pos), T, k, E, 1 if with_shared else 0, _stream()),
            "glm_moe_align")

@@ -135,6 +135,12 @@ int glm_router_topk(const void* x, const void* gate_w, const float* e_score_corr
                     int64_t T, int H, int E, int k, float routed_scaling_factor,
                     glm_stream_t stream);
 
+/* a11 at prefill sizes: R2..R7 from logits that a GEMM produced (R1 = glm_gemm_bf16(x, W_gate): [T, E] bf16, row stride
+ *     ld_logits) — the same selection code as glm_router_topk, one wave per token.  idx ascending per row.          */
+int glm_router_select(const void* logits, int64_t ld_logits, const float* e_score_correction_bias,
+                      int64_t* topk_idx, void* topk_w, int64_t T, int E, int k,
+                      float routed_scaling_factor, glm_stream_t stream);
+
 /* Token→expert bucketing for the grouped GEMM (replaces the mask/where/any loop of
  *     moe.py:135-147).  Rows are grouped by expert id ascending; if with_shared != 0 one more
  *     group (id E) holding every token once is appended (the shared expert, moe.py:165).
@@ -145,6 +151,15 @@ int glm_moe_align(const int64_t* topk_idx, const void* topk_w,
                   int32_t* expert_offsets, int32_t* sorted_token, void* sorted_scale,
                   int32_t* pair_pos, int64_t T, int k, int E, int with_shared,
                   glm_stream_t stream);
+
+/* The same bucketing over many workgroups, for prefill sizes (the kernel above is ONE workgroup: 200 us at T = 16384,
+ *     k = 8): count / offsets / scatter launches over chunks of 8192 pairs.  workspace: glm_moe_align_workspace_bytes(),
+ *     int32; its first E words must be ZERO on entry (the caller clears them for every call).  Same contract for the
+ *     outputs; the order of the rows inside a group is unspecified in both.                                  */
+size_t glm_moe_align_workspace_bytes(int64_t T, int k, int E);
+int glm_moe_align_parallel(const int64_t* topk_idx, const void* topk_w, int32_t* expert_offsets,
+                           int32_t* sorted_token, void* sorted_scale, int32_t* pair_pos, int64_t T, int k, int E,
+                           int with_shared, int32_t* workspace, size_t workspace_bytes, glm_stream_t stream);
 
 /* a13 (first half) models/glm4_moe/mlp.py:49-53 for every group at once:
  *     act[r, i] = bf16( bf16(silu(bf16(x[tok(r)]·Wg_gᵀ))) * bf16(x[tok(r)]·Wu_gᵀ) )

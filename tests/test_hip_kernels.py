@@ -324,6 +324,41 @@ def test_router_air_shape(ops):
     assert float((logits != rlogits).float().mean()) < 2e-3, "too many logit rounding flips"
 
 
+@pytest.mark.parametrize("T,H,E,k", [(2048, 4096, 64, 8), (1024, 1024, 128, 8), (1500, 512, 16, 4), (1030, 768, 24, 2)])
+def test_router_prefill_size_gemm_path(ops, T, H, E, k):
+    """From ROUTER_GEMM_MIN_ROWS rows on the logits are a GEMM and glm_router_select does R2..R7: expert sets bit-exact
+    vs the oracle except rows whose bf16 logit itself rounded differently (proven by _check_router), and the fused
+    norm + router + bucketing entry point returns exactly norm -> router -> align."""
+    assert ops.router_by_gemm(T, E)
+    x = rnd(T, H, seed=501)
+    gw = rnd(E, H, seed=502, scale=0.02)
+    bias = (torch.rand(E, generator=torch.Generator().manual_seed(503)) * 0.2 - 0.1).float()
+    logits, rlogits = _check_router(ops, x, gw, bias, k, 1.0, f"router GEMM path T={T}", allow_flip_rows=0.03)
+    assert float((logits != rlogits).float().mean()) < 3e-3, "too many logit rounding flips"
+    res, nw = rnd(T, H, seed=504), (1 + 0.1 * rnd(H, seed=505).float()).to(BF)
+    y, ro, idx, w, al = ops.add_rmsnorm_router_topk(dev(x), dev(res), dev(nw), 1e-5, dev(gw), dev(bias), k, 1.0,
+                                                     align_with_shared=True)
+    y2, ro2 = ops.add_rmsnorm(dev(x), dev(res), dev(nw), 1e-5)
+    idx2, w2 = ops.router_topk(y2, dev(gw), dev(bias), k, 1.0)
+    assert torch.equal(y, y2) and torch.equal(ro, ro2) and torch.equal(idx, idx2) and torch.equal(w, w2)
+    _check_align(*al, idx.cpu(), w.cpu(), E, True)
+    # the selection itself is the decode kernel's: same logits in -> same routing out
+    lg = ops.gemm_bf16(y2, dev(gw), None)
+    idx3, w3 = ops.router_select(lg, dev(bias), k, 1.0)
+    assert torch.equal(idx3, idx2) and torch.equal(w3, w2)
+
+
+def test_router_select_equals_decode_kernel_on_its_logits(ops):
+    """glm_router_select on the logits the token-per-workgroup kernel reports == that kernel's own routing (ties incl.)."""
+    for T, H, E, k, seed in ((37, 1024, 64, 8, 1), (64, 512, 128, 8, 2), (20, 256, 8, 2, 3)):
+        x = rnd(T, H, seed=600 + seed)
+        gw = rnd(E, H, seed=610 + seed, scale=0.05)
+        bias = torch.zeros(E) if seed == 3 else (torch.rand(E, generator=torch.Generator().manual_seed(seed)) * 0.2 - 0.1).float()
+        idx, w, logits = ops.router_topk(dev(x), dev(gw), dev(bias), k, 2.5, return_logits=True)
+        idx2, w2 = ops.router_select(logits, dev(bias), k, 2.5)
+        assert torch.equal(idx, idx2) and torch.equal(w, w2)
+
+
 def _check_align(offs, tok, scale, pos, idx, w, E, shared):
     """moe_align's contract: groups in ascending expert id, every (token, expert) pair exactly once, pair_pos ↔ rows."""
     T, k = idx.shape
@@ -346,6 +381,29 @@ def _check_align(offs, tok, scale, pos, idx, w, E, shared):
         assert int(offs[E + 1]) == T * k + T
         assert tok[T * k:].tolist() == list(range(T))
         assert bool((scale[T * k:].float() == 1.0).all())
+
+
+@pytest.mark.parametrize("T,k,E,shared", [(4096, 8, 64, True), (2100, 8, 128, False), (16384, 1, 4, True), (9000, 2, 16, True)])
+def test_moe_align_parallel(ops, T, k, E, shared):
+    """Prefill-size bucketing (count / offsets / scatter over chunks of 8192 pairs): moe_align's contract, incl. an expert
+    nobody picked, a ragged last chunk and the shared group."""
+    assert T * k >= ops.ALIGN_PARALLEL_MIN_PAIRS
+    g = torch.Generator().manual_seed(T + k + E)
+    pool = max(k, E - 1)  # expert E-1 is never selected
+    idx = torch.stack([torch.randperm(pool, generator=g)[:k].sort()[0] for _ in range(T)]).to(torch.int64)
+    w = (torch.rand(T, k, generator=g) + 0.1).to(BF)
+    offs, tok, scale, pos = ops.moe_align(dev(idx), dev(w), E, shared)
+    offs, tok, scale, pos = [a.cpu() for a in (offs, tok, scale, pos)]
+    counts = torch.bincount(idx.flatten(), minlength=E)
+    assert torch.equal(offs[: E + 1].long(), torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)]))
+    P = T * k
+    assert sorted(pos.tolist()) == list(range(P)), "pair_pos must be a permutation of the routed rows"
+    flat_idx, flat_w = idx.flatten(), w.flatten()
+    rows_expert = torch.bucketize(pos.long(), offs[1: E + 1].long(), right=True)  # group of each pair's row
+    assert torch.equal(rows_expert, flat_idx), "a pair's row must lie in its expert's group"
+    assert torch.equal(tok[pos.long()].long(), torch.arange(P) // k) and torch.equal(scale[pos.long()], flat_w)
+    if shared:
+        assert int(offs[E + 1]) == P + T and tok[P:].tolist() == list(range(T)) and bool((scale[P:].float() == 1.0).all())
 
 
 def test_moe_align(ops):
