@@ -53,9 +53,10 @@ constexpr int LM_BAND = GLM_LM_BAND;  // row blocks per L2 supertile band
 // Tile configurations (the kernel is written once over these):
 //   CfgA 256(n) x 128(m) x 64(k), 3-stage ring, wave tile 64x64  (16 LDS reads + 6 DMA per 32 MFMA)
 //   CfgB 256(n) x 256(m) x 32(k), 4-stage ring, wave tile 64x128 (12 LDS reads + 4 DMA per 32 MFMA)
-template <int BM_, int BK_, int NSTAGE_>
+template <int BM_, int BK_, int NSTAGE_, bool PH8_ = false>
 struct LmCfg {
     static constexpr int BM = BM_, BK = BK_, NSTAGE = NSTAGE_;
+    static constexpr bool PH8 = PH8_;              // quadrant-phase main loop (CfgC)
     static constexpr int RB = BK * 2;              // bytes per tile row
     static constexpr int CPR = RB / 16;            // 16-B chunks per row
     static constexpr int RPI = 1024 / RB;          // rows per DMA instruction
@@ -79,6 +80,12 @@ struct LmCfg {
 using LmCfgA = LmCfg<128, 64, 3>;
 using LmCfgB = LmCfg<256, 32, 4>;
 using LmCfgB5 = LmCfg<256, 32, 5>;  // variant LM_DEEP: prefetch distance 4
+//   CfgC 256(n) x 256(m) x 64(k), TWO 64 KiB buffers, wave tile 64x128, four phases of 16 MFMAs per K tile (variant
+//        LM_PH8).  128-byte tile rows: one DMA instruction moves 8 whole cache lines (CfgB: 16 half lines).  Two
+//        buffers are enough because an operand's slot is refilled as soon as ITS last fragment read has retired, not
+//        when the whole K tile is done: the weight fragments of a K tile are read in phases 0-1, the activation
+//        fragments in phases 0 and 2 (see the main loop).
+using LmCfgC = LmCfg<256, 64, 2, true>;
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
@@ -141,7 +148,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 //   LM_NT     non-temporal epilogue stores (the output is not read again by this kernel).
 constexpr int LM_LEAN = 1, LM_WIDEST = 2, LM_NOSTORE = 4, LM_DMA2 = 8, LM_DMA4 = 16, LM_LDSEPI = 32, LM_DESYNC = 64,
               LM_NT = 128, LM_EPIORD = 256, LM_NOPRIO = 512, LM_LOADPRIO = 1024,  // issue-priority studies
-              LM_DEEP = 2048;  // 5-stage ring (all 160 KiB of LDS): one more K tile of prefetch distance
+              LM_DEEP = 2048,  // 5-stage ring (all 160 KiB of LDS): one more K tile of prefetch distance
+              LM_PH8 = 4096;   // CfgC: BK = 64, two buffers, four 16-MFMA phases per K tile (needs LM_LEAN)
 //   LM_EPIORD the epilogue's global LOADS (per-row scales) are issued before the next tile's ring fill, so that waiting
 //             for them does not drain the fill; and the wait that opens a tile leaves the previous tile's stores in
 //             flight (vmcnt counts in issue order and the fill was issued before them) whenever their number is
@@ -313,6 +321,12 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         for (int i = 0; i < C::X_DMA; ++i) glds16(k0 + xch[i] * 8 < K ? xsrc[i] + k0 : zero, xdst + i * 1024);
     };
     auto fill_ring = [&]() {
+        if constexpr (C::PH8) {
+            // both operands of K tile 0 and the weights of K tile 1 (their slot is the first one the loop refills)
+            static_for<C::DPW>([&](auto jc) { stage_one(0, 0, jc); });
+            if (nk > 1) static_for<C::W_DMA>([&](auto jc) { stage_one(1, 1, jc); });
+            return;
+        }
 #pragma unroll
         for (int d = 0; d < C::DIST; ++d)
             if (d < nk) stage(d, d);
@@ -405,6 +419,126 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();                 // every share of the first DIST tiles landed
+        if constexpr (C::PH8) {
+        // ---- CfgC: four phases per K tile, each = load interval | barrier | 16 MFMAs | barrier; waves 4-7 run one
+        // barrier behind waves 0-3, so the two waves of a SIMD alternate between the two kinds of interval.
+        //   phase   fragment reads (this K tile, buffer b)          DMA issued                         MFMAs
+        //     0     W tiles 0,1 (4) + X tiles 0-3 (8)               X(kt+1) pieces 0,1 -> buffer !b     W01 x X0-3
+        //     1     W tiles 2,3 (4)                                 X(kt+1) pieces 2,3 -> buffer !b     W23 x X0-3
+        //     2     X tiles 4-7 (8)                                 W(kt+2) pieces 0,1 -> buffer b      W23 x X4-7
+        //     3     -                                               W(kt+2) pieces 2,3 -> buffer b      W01 x X4-7
+        //           then the counted wait for this wave's share of K tile kt+1 (W(kt+2) stays in flight)
+        // Every load interval ends with lgkmcnt(0) BEFORE its barrier, so a fragment read has retired when its wave
+        // passes that barrier.  Barrier epochs: waves 0-3 run load interval P (= 4 kt + phase) in epoch 2P, waves 4-7
+        // in epoch 2P+1.
+        //   WAR  W(kt) is last read in load interval 4kt+1 (retired by the end of epoch 8kt+3 at the latest) and its
+        //        slot refilled from load interval 4kt+2 (epoch >= 8kt+4).  X(kt-1) is last read in load interval
+        //        4kt-2 (epoch <= 8kt-3) and its slot refilled from load interval 4kt (epoch >= 8kt).
+        //   RAW  K tile kt+1 is first read in load interval 4kt+4 (epoch >= 8kt+8); every wave waited for its own
+        //        pieces of it at the end of load interval 4kt+3 (epoch <= 8kt+7), i.e. before barrier 8kt+8.
+        static_assert(!C::PH8 || LEAN, "the quadrant-phase loop needs the lean load phase");
+        if (wid >= 4) __builtin_amdgcn_s_barrier();   // the stagger
+        u32x4_t fw[8], fx[8];  // [k-step][W tile 0-3], [k-step][X tile of the current half]
+        auto pin = [&](u32x4_t& r) { asm volatile("" : "+v"(r)); };
+        auto rd_w = [&](unsigned so, auto hc) {
+            constexpr int h = decltype(hc)::value;
+            static_for<C::KS>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value;
+                const unsigned aw = fbw[ks] + so;
+                static_for<2>([&](auto tc) {
+                    constexpr int t = 2 * h + decltype(tc)::value;
+                    constexpr int off = MODE == GEMM_GATEUP ? (t < 2 ? 16 * t : 128 + 16 * (t - 2)) * C::RB : 16 * t * C::RB;
+                    lds_read_b128_o<off>(fw[ks * 4 + t], aw);
+                });
+            });
+        };
+        auto rd_x = [&](unsigned so, auto gc) {
+            constexpr int g = decltype(gc)::value;
+            static_for<C::KS>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value;
+                const unsigned ax = fbx[ks] + so;
+                static_for<4>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    lds_read_b128_o<16 * (4 * g + j) * C::RB>(fx[ks * 4 + j], ax);
+                });
+            });
+        };
+        auto quad = [&](auto hc, auto gc) {
+            constexpr int h = decltype(hc)::value, g = decltype(gc)::value;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[2 * h + tt][4 * g + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_t, fw[ks * 4 + 2 * h + tt]),
+                            __builtin_bit_cast(bf16x8_t, fx[ks * 4 + j]), acc[2 * h + tt][4 * g + j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int b = kt & 1;
+            const unsigned so = b * C::STAGE;
+            const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
+            // ---- phase 0
+            if (has1) {
+                stage_one(b ^ 1, kt + 1, std::integral_constant<int, C::W_DMA + 0>{});
+                stage_one(b ^ 1, kt + 1, std::integral_constant<int, C::W_DMA + 1>{});
+            }
+            rd_w(so, I0{});
+            rd_x(so, I0{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            pin(fw[0]); pin(fw[1]); pin(fw[4]); pin(fw[5]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pin(fx[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            quad(I0{}, I0{});
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 1
+            if (has1) {
+                stage_one(b ^ 1, kt + 1, std::integral_constant<int, C::W_DMA + 2>{});
+                stage_one(b ^ 1, kt + 1, std::integral_constant<int, C::W_DMA + 3>{});
+            }
+            rd_w(so, I1{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            pin(fw[2]); pin(fw[3]); pin(fw[6]); pin(fw[7]);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            quad(I1{}, I0{});
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 2
+            if (has2) {
+                stage_one(b, kt + 2, std::integral_constant<int, 0>{});
+                stage_one(b, kt + 2, std::integral_constant<int, 1>{});
+            }
+            rd_x(so, I1{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pin(fx[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            quad(I1{}, I1{});
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 3
+            if (has2) {
+                stage_one(b, kt + 2, std::integral_constant<int, 2>{});
+                stage_one(b, kt + 2, std::integral_constant<int, 3>{});
+                asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C::W_DMA) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            quad(I0{}, I1{});
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wid < 4) __builtin_amdgcn_s_barrier();  // match the other group's extra barrier
+        } else {
 #if GLM_LM_SCHED == 0
         if (wid >= 4) __builtin_amdgcn_s_barrier();   // the stagger
         int slot = 0;  // ring slot of tile kt
@@ -548,6 +682,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         }
         // waves 4-7 are past every LDS read of this tile here, waves 0-3 finished theirs before the last barrier
 #endif
+        }  // !C::PH8
 
         // per-row scales of the finished tile: requested before the ring fill (waiting for a load issued after the fill
         // would drain the fill first)
@@ -670,6 +805,16 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
 
 int g_largem_variant = -1;  // < 0: the default for the shape
 
+// GLM_LARGEM_VARIANT=<bits> makes a variant the process default (A/B runs of whole test suites)
+int env_variant() {
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("GLM_LARGEM_VARIANT");
+        v = e ? atoi(e) : -1;
+    }
+    return v;
+}
+
 template <int MODE, class C, int VAR>
 int launch_largem_cfg(const GemmParams& p, hipStream_t st) {
     const int cols_per_wg = MODE == GEMM_GATEUP ? 128 : LM_BN;
@@ -717,16 +862,20 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
     const int64_t avg_rows = p.R / (p.G > 0 ? p.G : 1);
     const bool use_b = ch == 2 || (ch == 0 && avg_rows >= 192);
     // the lean load phase addresses x and the group's weights through 32-bit buffer offsets and has no K tail path
-    const int bk = use_b ? LmCfgB::BK : LmCfgA::BK;
+    int var = g_largem_variant >= 0 ? g_largem_variant : env_variant() >= 0 ? env_variant() : GLM_LM_DEFAULT_VAR;
+    const int bk = use_b ? ((var & LM_PH8) ? LmCfgC::BK : LmCfgB::BK) : LmCfgA::BK;
     const int64_t wrows = MODE == GEMM_GATEUP ? 2 * (int64_t)p.N : (int64_t)p.N;
     const bool lean_ok = p.K % bk == 0 && p.R * p.ldx * 2 < (1ll << 31) && wrows * p.ldw * 2 < (1ll << 31) &&
                          p.N % 8 == 0 && p.ldy % 8 == 0 && glm_aligned16(p.y);
-    int var = g_largem_variant >= 0 ? g_largem_variant : GLM_LM_DEFAULT_VAR;
     if (!lean_ok) var = 0;
 #define GLM_LM_CASE(V)                                                                                         \
     case V:                                                                                                    \
         if (use_b && ((V) & LM_DEEP)) return launch_largem_cfg<MODE, LmCfgB5, V>(p, st);                       \
-        return use_b ? launch_largem_cfg<MODE, LmCfgB, V>(p, st) : launch_largem_cfg<MODE, LmCfgA, V>(p, st)
+        if constexpr (((V) & LM_PH8) != 0) {                                                                   \
+            if (use_b) return launch_largem_cfg<MODE, LmCfgC, V>(p, st);                                       \
+            return launch_largem_cfg<MODE, LmCfgA, (V) & ~LM_PH8>(p, st);                                      \
+        } else                                                                                                 \
+            return use_b ? launch_largem_cfg<MODE, LmCfgB, V>(p, st) : launch_largem_cfg<MODE, LmCfgA, V>(p, st)
     switch (var) {
         GLM_LM_CASE(1);
         GLM_LM_CASE(2);
@@ -734,6 +883,7 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
         GLM_LM_CASE(11);   // lean + wide + 2 DMA in the MFMA phase
         GLM_LM_CASE(19);   // lean + wide + 4 DMA in the MFMA phase
         GLM_LM_CASE(2051); // lean + wide + 5-stage ring
+        GLM_LM_CASE(4099); // lean + wide + quadrant phases on two 64-KiB buffers (CfgC)
         GLM_LM_CASE(259);  // lean + wide + epilogue ordering
         GLM_LM_CASE(771);  // ... without the MFMA-phase priority
         GLM_LM_CASE(1283); // ... with the LOAD phase at priority 1
