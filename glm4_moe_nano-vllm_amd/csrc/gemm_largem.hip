@@ -40,7 +40,7 @@ constexpr int LM_BN = 256;    // weight rows per tile (MFMA row axis); 4 waves x
 #define GLM_LM_STAGE_POS 0  // 0: DMA issue before the fragment reads (measured best, +0.8 %), 1: between, 2: after
 #endif
 #ifndef GLM_LM_DEFAULT_VAR
-#define GLM_LM_DEFAULT_VAR 3  // lean load phase + 16-byte stores (bit-identical to 0; tools/largem_ab.py: +4 % / +7 %)
+#define GLM_LM_DEFAULT_VAR -1  // < 0: per mode (launch_largem); a value: that variant for every mode
 #endif
 #ifndef GLM_LM_STUDY
 #define GLM_LM_STUDY 1  // also build the timing-study variants (no-store epilogue)
@@ -48,7 +48,7 @@ constexpr int LM_BN = 256;    // weight rows per tile (MFMA row axis); 4 waves x
 #ifndef GLM_LM_SCHED
 #define GLM_LM_SCHED 0  // 0: two barriers per K tile with waves 4-7 one barrier behind; 1: one barrier per K tile
 #endif
-constexpr int LM_BAND = GLM_LM_BAND;  // row blocks per L2 supertile band
+int g_largem_band = GLM_LM_BAND;  // row blocks per L2 supertile band (glm_debug_largem_band for sweeps)
 
 // Tile configurations (the kernel is written once over these):
 //   CfgA 256(n) x 128(m) x 64(k), 3-stage ring, wave tile 64x64  (16 LDS reads + 6 DMA per 32 MFMA)
@@ -149,7 +149,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 constexpr int LM_LEAN = 1, LM_WIDEST = 2, LM_NOSTORE = 4, LM_DMA2 = 8, LM_DMA4 = 16, LM_LDSEPI = 32, LM_DESYNC = 64,
               LM_NT = 128, LM_EPIORD = 256, LM_NOPRIO = 512, LM_LOADPRIO = 1024,  // issue-priority studies
               LM_DEEP = 2048,  // 5-stage ring (all 160 KiB of LDS): one more K tile of prefetch distance
-              LM_PH8 = 4096;   // CfgC: BK = 64, two buffers, four 16-MFMA phases per K tile (needs LM_LEAN)
+              LM_PH8 = 4096,   // CfgC: BK = 64, two buffers, four 16-MFMA phases per K tile (needs LM_LEAN)
+              LM_P3X = 8192, LM_QW = 16384, LM_RPRE = 32768;  // schedules of that loop (described there)
 //   LM_EPIORD the epilogue's global LOADS (per-row scales) are issued before the next tile's ring fill, so that waiting
 //             for them does not drain the fill; and the wait that opens a tile leaves the previous tile's stores in
 //             flight (vmcnt counts in issue order and the fill was issued before them) whenever their number is
@@ -185,7 +186,7 @@ __device__ __forceinline__ void dma_wait_leave(int tiles) {
 // Between two tiles the next tile's first ring stages are put in flight BEFORE the finished tile's epilogue, so the
 // ring-fill latency and the workgroup relaunch (~6 % of a 256x256x1408 tile) hide behind the epilogue's stores.
 template <int MODE, class C, int VAR>
-__global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, int n_tiles, int total_tiles) {
+__global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, int n_tiles, int total_tiles, int LM_BAND) {
     constexpr bool LEAN = (VAR & LM_LEAN) != 0;
     // DMA instructions of a K tile issued from the MFMA phase (the rest from the load phase)
     constexpr int S2 = !LEAN ? 0 : (VAR & LM_DMA4) ? C::DPW : (VAR & LM_DMA2) ? C::DPW / 2 : 0;
@@ -324,7 +325,13 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         if constexpr (C::PH8) {
             // both operands of K tile 0 and the weights of K tile 1 (their slot is the first one the loop refills)
             static_for<C::DPW>([&](auto jc) { stage_one(0, 0, jc); });
-            if (nk > 1) static_for<C::W_DMA>([&](auto jc) { stage_one(1, 1, jc); });
+            if (nk > 1) {
+                static_for<C::W_DMA>([&](auto jc) { stage_one(1, 1, jc); });
+                if constexpr ((VAR & LM_P3X) != 0) {  // what phase 3 of a K tile "-1" would have issued
+                    stage_one(1, 1, std::integral_constant<int, C::W_DMA + 0>{});
+                    stage_one(1, 1, std::integral_constant<int, C::W_DMA + 1>{});
+                }
+            }
             return;
         }
 #pragma unroll
@@ -437,106 +444,214 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         //   RAW  K tile kt+1 is first read in load interval 4kt+4 (epoch >= 8kt+8); every wave waited for its own
         //        pieces of it at the end of load interval 4kt+3 (epoch <= 8kt+7), i.e. before barrier 8kt+8.
         static_assert(!C::PH8 || LEAN, "the quadrant-phase loop needs the lean load phase");
+        // Variants of the same loop (bit-identical results):
+        //   LM_P3X  X(kt+2) pieces 0,1 are issued in phase 3 of K tile kt (its slot is free from there on) and pieces
+        //           2,3 in phase 1 of kt+1: phase 0, which carries 12 fragment reads, issues no DMA, phase 3, which
+        //           carries no reads, issues 4; the counted wait of phase 3 then leaves 6 in flight.
+        //   LM_QW   a quadrant is all 4 W tiles x 2 X tiles: reads 12 / 4 / 4 / 4 instead of 12 / 4 / 8 / 0 and 16
+        //           fragment registers less; W(kt) is dead after phase 0, X(kt) after phase 3 (excludes LM_P3X).
+        constexpr bool P3X = (VAR & LM_P3X) != 0, QW = (VAR & LM_QW) != 0;
+        static_assert(!(P3X && QW), "LM_P3X refills the X slot while LM_QW still reads it");
         if (wid >= 4) __builtin_amdgcn_s_barrier();   // the stagger
-        u32x4_t fw[8], fx[8];  // [k-step][W tile 0-3], [k-step][X tile of the current half]
+        u32x4_t fw[8], fx[8];  // [k-step][W tile 0-3], [k-step][X tile of the current part]
         auto pin = [&](u32x4_t& r) { asm volatile("" : "+v"(r)); };
-        auto rd_w = [&](unsigned so, auto hc) {
-            constexpr int h = decltype(hc)::value;
+        // W tiles t0 .. t0+NT-1, both k-steps
+        auto rd_w = [&](unsigned so, auto t0c, auto ntc) {
+            constexpr int t0 = decltype(t0c)::value, NT = decltype(ntc)::value;
             static_for<C::KS>([&](auto ksc) {
                 constexpr int ks = decltype(ksc)::value;
                 const unsigned aw = fbw[ks] + so;
-                static_for<2>([&](auto tc) {
-                    constexpr int t = 2 * h + decltype(tc)::value;
+                static_for<NT>([&](auto tc) {
+                    constexpr int t = t0 + decltype(tc)::value;
                     constexpr int off = MODE == GEMM_GATEUP ? (t < 2 ? 16 * t : 128 + 16 * (t - 2)) * C::RB : 16 * t * C::RB;
                     lds_read_b128_o<off>(fw[ks * 4 + t], aw);
                 });
             });
         };
-        auto rd_x = [&](unsigned so, auto gc) {
-            constexpr int g = decltype(gc)::value;
+        // X tiles m0 .. m0+NX-1 into fx[ks * NX + j], both k-steps
+        auto rd_x = [&](unsigned so, auto m0c, auto nxc, auto xbc) {
+            constexpr int mt0 = decltype(m0c)::value, NX = decltype(nxc)::value, XB = decltype(xbc)::value;
             static_for<C::KS>([&](auto ksc) {
                 constexpr int ks = decltype(ksc)::value;
                 const unsigned ax = fbx[ks] + so;
-                static_for<4>([&](auto jc) {
+                static_for<NX>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
-                    lds_read_b128_o<16 * (4 * g + j) * C::RB>(fx[ks * 4 + j], ax);
+                    lds_read_b128_o<16 * (mt0 + j) * C::RB>(fx[XB + ks * NX + j], ax);
                 });
             });
         };
-        auto quad = [&](auto hc, auto gc) {
-            constexpr int h = decltype(hc)::value, g = decltype(gc)::value;
+        // W tiles t0 .. t0+NT-1 x X tiles m0 .. m0+NX-1 (16 MFMAs)
+        auto quad = [&](auto t0c, auto ntc, auto m0c, auto nxc, auto xbc) {
+            constexpr int t0 = decltype(t0c)::value, NT = decltype(ntc)::value;
+            constexpr int mt0 = decltype(m0c)::value, NX = decltype(nxc)::value, XB = decltype(xbc)::value;
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
+                for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[2 * h + tt][4 * g + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8_t, fw[ks * 4 + 2 * h + tt]),
-                            __builtin_bit_cast(bf16x8_t, fx[ks * 4 + j]), acc[2 * h + tt][4 * g + j], 0, 0, 0);
+                    for (int j = 0; j < NX; ++j)
+                        acc[t0 + tt][mt0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_t, fw[ks * 4 + t0 + tt]),
+                            __builtin_bit_cast(bf16x8_t, fx[XB + ks * NX + j]), acc[t0 + tt][mt0 + j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         };
+        auto reads_done = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+        auto close_load = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        };
+        auto dma2 = [&](int slot, int kt_, auto j0c) {
+            constexpr int j0 = decltype(j0c)::value;
+            stage_one(slot, kt_, std::integral_constant<int, j0>{});
+            stage_one(slot, kt_, std::integral_constant<int, j0 + 1>{});
+        };
         using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I4 = std::integral_constant<int, 4>;
+        using I6 = std::integral_constant<int, 6>;
+        using XP0 = std::integral_constant<int, C::W_DMA + 0>;  // X pieces 0,1
+        using XP2 = std::integral_constant<int, C::W_DMA + 2>;  // X pieces 2,3
+        if constexpr ((VAR & LM_RPRE) != 0) {
+        //   LM_RPRE (with LM_QW) the fragment reads of phases 1-3 (two X tiles each) are issued at the START of the
+        //           previous phase's MFMA interval into the other half of fx and retire behind its MFMAs: the load
+        //           intervals of phases 1-3 carry DMA issue only.  X(kt) is then last read in MFMA interval 4kt+2
+        //           (retired by the lgkmcnt(0) before its closing barrier, epoch <= 8kt+6) and refilled from load
+        //           interval 4kt+4 (epoch >= 8kt+8); W(kt) is last read in load interval 4kt as under LM_QW.
+        static_assert(QW, "LM_RPRE is a schedule of the LM_QW quadrants");
+        auto pre_x = [&](unsigned so, auto m0c, auto xbc) {  // issue the reads, keep the MFMAs behind them
+            rd_x(so, m0c, I2{}, xbc);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto post_x = [&](auto xbc) {  // after the MFMAs: the prefetched fragments are in registers
+            constexpr int XB = decltype(xbc)::value;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            pin(fx[XB + 0]); pin(fx[XB + 1]); pin(fx[XB + 2]); pin(fx[XB + 3]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
         for (int kt = 0; kt < nk; ++kt) {
             const int b = kt & 1;
             const unsigned so = b * C::STAGE;
             const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
             // ---- phase 0
-            if (has1) {
-                stage_one(b ^ 1, kt + 1, std::integral_constant<int, C::W_DMA + 0>{});
-                stage_one(b ^ 1, kt + 1, std::integral_constant<int, C::W_DMA + 1>{});
-            }
-            rd_w(so, I0{});
-            rd_x(so, I0{});
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            pin(fw[0]); pin(fw[1]); pin(fw[4]); pin(fw[5]);
+            if (has1) dma2(b ^ 1, kt + 1, XP0{});
+            rd_w(so, I0{}, I4{});
+            rd_x(so, I0{}, I2{}, I0{});
+            reads_done();
 #pragma unroll
-            for (int i = 0; i < 8; ++i) pin(fx[i]);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            quad(I0{}, I0{});
+            for (int i = 0; i < 8; ++i) pin(fw[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pin(fx[i]);
+            close_load();
+            pre_x(so, I2{}, I4{});
+            quad(I0{}, I4{}, I0{}, I2{}, I0{});
+            post_x(I4{});
             __builtin_amdgcn_s_barrier();
             // ---- phase 1
-            if (has1) {
-                stage_one(b ^ 1, kt + 1, std::integral_constant<int, C::W_DMA + 2>{});
-                stage_one(b ^ 1, kt + 1, std::integral_constant<int, C::W_DMA + 3>{});
-            }
-            rd_w(so, I1{});
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            pin(fw[2]); pin(fw[3]); pin(fw[6]); pin(fw[7]);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            quad(I1{}, I0{});
+            if (has1) dma2(b ^ 1, kt + 1, XP2{});
+            close_load();
+            pre_x(so, I4{}, I0{});
+            quad(I0{}, I4{}, I2{}, I2{}, I4{});
+            post_x(I0{});
             __builtin_amdgcn_s_barrier();
             // ---- phase 2
-            if (has2) {
-                stage_one(b, kt + 2, std::integral_constant<int, 0>{});
-                stage_one(b, kt + 2, std::integral_constant<int, 1>{});
-            }
-            rd_x(so, I1{});
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < 8; ++i) pin(fx[i]);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            quad(I1{}, I1{});
+            if (has2) dma2(b, kt + 2, I0{});
+            close_load();
+            pre_x(so, I6{}, I4{});
+            quad(I0{}, I4{}, I4{}, I2{}, I0{});
+            post_x(I4{});
             __builtin_amdgcn_s_barrier();
             // ---- phase 3
             if (has2) {
-                stage_one(b, kt + 2, std::integral_constant<int, 2>{});
-                stage_one(b, kt + 2, std::integral_constant<int, 3>{});
+                dma2(b, kt + 2, I2{});
                 asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C::W_DMA) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            quad(I0{}, I1{});
+            close_load();
+            quad(I0{}, I4{}, I6{}, I2{}, I4{});
             __builtin_amdgcn_s_barrier();
         }
+        } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            const int b = kt & 1;
+            const unsigned so = b * C::STAGE;
+            const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
+            // ---- phase 0
+            if (!P3X && has1) dma2(b ^ 1, kt + 1, XP0{});
+            if constexpr (QW) {
+                rd_w(so, I0{}, I4{});
+                rd_x(so, I0{}, I2{}, I0{});
+                reads_done();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pin(fw[i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pin(fx[i]);
+            } else {
+                rd_w(so, I0{}, I2{});
+                rd_x(so, I0{}, I4{}, I0{});
+                reads_done();
+                pin(fw[0]); pin(fw[1]); pin(fw[4]); pin(fw[5]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pin(fx[i]);
+            }
+            close_load();
+            if constexpr (QW) quad(I0{}, I4{}, I0{}, I2{}, I0{});
+            else quad(I0{}, I2{}, I0{}, I4{}, I0{});
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 1
+            if (has1) dma2(b ^ 1, kt + 1, XP2{});
+            if constexpr (QW) {
+                rd_x(so, I2{}, I2{}, I0{});
+                reads_done();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pin(fx[i]);
+            } else {
+                rd_w(so, I2{}, I2{});
+                reads_done();
+                pin(fw[2]); pin(fw[3]); pin(fw[6]); pin(fw[7]);
+            }
+            close_load();
+            if constexpr (QW) quad(I0{}, I4{}, I2{}, I2{}, I0{});
+            else quad(I2{}, I2{}, I0{}, I4{}, I0{});
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 2
+            if (has2) dma2(b, kt + 2, I0{});
+            if constexpr (QW) {
+                rd_x(so, I4{}, I2{}, I0{});
+                reads_done();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pin(fx[i]);
+            } else {
+                rd_x(so, I4{}, I4{}, I0{});
+                reads_done();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pin(fx[i]);
+            }
+            close_load();
+            if constexpr (QW) quad(I0{}, I4{}, I4{}, I2{}, I0{});
+            else quad(I2{}, I2{}, I4{}, I4{}, I0{});
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 3: the last pieces, then this wave's share of K tile kt+1 must have landed
+            if (has2) {
+                dma2(b, kt + 2, I2{});
+                if constexpr (P3X) dma2(b, kt + 2, XP0{});
+            }
+            if constexpr (QW) {
+                rd_x(so, I6{}, I2{}, I0{});
+                reads_done();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pin(fx[i]);
+            }
+            if (has2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C::W_DMA + (P3X ? 2 : 0)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            close_load();
+            if constexpr (QW) quad(I0{}, I4{}, I6{}, I2{}, I0{});
+            else quad(I0{}, I2{}, I4{}, I4{}, I0{});
+            __builtin_amdgcn_s_barrier();
+        }
+        }  // !LM_RPRE
         if (wid < 4) __builtin_amdgcn_s_barrier();  // match the other group's extra barrier
         } else {
 #if GLM_LM_SCHED == 0
@@ -820,6 +935,7 @@ int launch_largem_cfg(const GemmParams& p, hipStream_t st) {
     const int cols_per_wg = MODE == GEMM_GATEUP ? 128 : LM_BN;
     const int n_tiles = (p.N + cols_per_wg - 1) / cols_per_wg;
     const int64_t combos = p.offs ? (p.R / C::BM + p.G) : (p.R + C::BM - 1) / C::BM;
+    const int LM_BAND = g_largem_band;
     const int64_t total = (combos + LM_BAND - 1) / LM_BAND * LM_BAND * n_tiles;
     if (total <= 0) return GLM_OK;
     GLM_CHECK_ARG(total < (1ll << 31), GLM_ERR_UNSUPPORTED, "gemm_largem: grid too large");
@@ -840,7 +956,7 @@ int launch_largem_cfg(const GemmParams& p, hipStream_t st) {
     if (nwg < 8) nwg = 8;
     const int64_t need = (total + 7) / 8 * 8;
     if (nwg > need) nwg = need;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), C::LDS, st, p, n_tiles, (int)total);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), C::LDS, st, p, n_tiles, (int)total, LM_BAND);
     GLM_CHECK_LAUNCH("gemm_largem");
     return GLM_OK;
 }
@@ -862,7 +978,10 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
     const int64_t avg_rows = p.R / (p.G > 0 ? p.G : 1);
     const bool use_b = ch == 2 || (ch == 0 && avg_rows >= 192);
     // the lean load phase addresses x and the group's weights through 32-bit buffer offsets and has no K tail path
+    // defaults (tools/largem_ab.py, one process, T = 16384): the quadrant-phase loop; long K (gate|up, dense
+    // projections) with the phase-0 DMA moved to phase 3, the down projection with 4 x 2-tile quadrants
     int var = g_largem_variant >= 0 ? g_largem_variant : env_variant() >= 0 ? env_variant() : GLM_LM_DEFAULT_VAR;
+    if (var < 0) var = LM_LEAN | LM_WIDEST | LM_PH8 | (MODE == GEMM_DOWN ? LM_QW : LM_P3X);
     const int bk = use_b ? ((var & LM_PH8) ? LmCfgC::BK : LmCfgB::BK) : LmCfgA::BK;
     const int64_t wrows = MODE == GEMM_GATEUP ? 2 * (int64_t)p.N : (int64_t)p.N;
     const bool lean_ok = p.K % bk == 0 && p.R * p.ldx * 2 < (1ll << 31) && wrows * p.ldw * 2 < (1ll << 31) &&
@@ -877,13 +996,17 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
         } else                                                                                                 \
             return use_b ? launch_largem_cfg<MODE, LmCfgB, V>(p, st) : launch_largem_cfg<MODE, LmCfgA, V>(p, st)
     switch (var) {
+        GLM_LM_CASE(3);
+        GLM_LM_CASE(4099);  // lean + wide + quadrant phases on two 64-KiB buffers (CfgC)
+        GLM_LM_CASE(12291); // ... with the DMA of phase 0 moved to phase 3
+        GLM_LM_CASE(20483); // ... with 4 x 2-tile quadrants
+        GLM_LM_CASE(53251); // ... and the reads of phases 1-3 issued from the previous MFMA interval
+#if GLM_LM_STUDY >= 2  // measured and not kept (profiles/r02/largem_ab_*.json)
         GLM_LM_CASE(1);
         GLM_LM_CASE(2);
-        GLM_LM_CASE(3);
         GLM_LM_CASE(11);   // lean + wide + 2 DMA in the MFMA phase
         GLM_LM_CASE(19);   // lean + wide + 4 DMA in the MFMA phase
         GLM_LM_CASE(2051); // lean + wide + 5-stage ring
-        GLM_LM_CASE(4099); // lean + wide + quadrant phases on two 64-KiB buffers (CfgC)
         GLM_LM_CASE(259);  // lean + wide + epilogue ordering
         GLM_LM_CASE(771);  // ... without the MFMA-phase priority
         GLM_LM_CASE(1283); // ... with the LOAD phase at priority 1
@@ -893,12 +1016,11 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
         GLM_LM_CASE(35);   // lean + wide + LDS-transposed epilogue
         GLM_LM_CASE(43);   // + 2 DMA in the MFMA phase
         GLM_LM_CASE(51);   // + 4 DMA in the MFMA phase
+#endif
 #if GLM_LM_STUDY
         GLM_LM_CASE(4);
         GLM_LM_CASE(7);
-        GLM_LM_CASE(263);
-        GLM_LM_CASE(15);
-        GLM_LM_CASE(23);
+        GLM_LM_CASE(4103);  // quadrant phases, no stores
 #endif
         default:
             GLM_LM_CASE(0);
@@ -917,6 +1039,13 @@ int glm_launch_gemm_largem(int mode, const GemmParams& p, hipStream_t st) {
     if (mode == GEMM_GATEUP) return launch_largem<GEMM_GATEUP>(p, st);
     if (mode == GEMM_DOWN) return launch_largem<GEMM_DOWN>(p, st);
     return launch_largem<GEMM_PLAIN>(p, st);
+}
+
+// sweeps: row blocks per L2 band for the next launches (>= 1); returns the previous value
+extern "C" int glm_debug_largem_band(int b) {
+    const int old = g_largem_band;
+    if (b >= 1) g_largem_band = b;
+    return old;
 }
 
 // A/B studies: kernel variant for the next launches (bit set of LM_LEAN | LM_WIDEST | LM_NOSTORE; < 0 = default)

@@ -320,6 +320,9 @@ int glm_allreduce_oneshot(const void* in, void* out, void* const* peer_bufs, voi
  * process — a bit set of lean load phase (1), 16-byte epilogue stores (2), … (csrc/gemm_largem.hip); < 0 restores the
  * default.  Every variant that stores results is bit-identical to variant 0.  Returns the previous value.          */
 int glm_debug_largem_variant(int variant);
+/* Same purpose: row blocks per L2 band of that kernel's tile order (>= 1; the tile order never changes a result).
+ * Returns the previous value.                                                                                       */
+int glm_debug_largem_band(int band);
 
 #ifdef __cplusplus
 }

@@ -22,16 +22,19 @@ NOSTORE = 4
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="0,1,2,3,4,7")
+    ap.add_argument("--variants", default="0,3,4099")
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--tokens", type=int, default=16384)
+    ap.add_argument("--band", type=int, default=0, help="row blocks per L2 band (0: the library default)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "largem_ab.json"))
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(",")]
     lib = ops.load_library()
     setvar = lib.glm_debug_largem_variant
     setvar.restype = int
+    if args.band > 0:
+        lib.glm_debug_largem_band(args.band)
 
     H, E, k, I, T = 4096, 64, 8, 1408, args.tokens
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -83,7 +86,7 @@ def main():
                 torch.cuda.synchronize()
                 times[name][v].append(a.elapsed_time(b) / args.iters * 1e3)
     setvar(-1)
-    res = {"tokens": T, "rows": R, "parity_vs_variant0": parity, "kernels": {}}
+    res = {"tokens": T, "rows": R, "band": args.band, "parity_vs_variant0": parity, "kernels": {}}
     for name in fns:
         res["kernels"][name] = {}
         for v in variants:
