@@ -31,6 +31,28 @@
 
 namespace {
 
+// 8 OCP e4m3 bytes (two dwords) -> 8 bf16, exact (every e4m3 value, subnormals included, is a bf16 value): gfx950's packed
+// convert takes two bytes per instruction (4 per fragment; cvt_pk_f32_fp8 + cvt_pk_bf16_f32 took 8)
+#ifndef GLM_SM_FP8_CVT
+#define GLM_SM_FP8_CVT 1  // 0: the two-step conversion (A/B)
+#endif
+__device__ __forceinline__ u32x4_t sm_fp8x8_to_bf16x8(unsigned d0, unsigned d1) {
+#if GLM_SM_FP8_CVT
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+    const bf2_t a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d0, 1.0f, false);
+    const bf2_t b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d0, 1.0f, true);
+    const bf2_t c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d1, 1.0f, false);
+    const bf2_t d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d1, 1.0f, true);
+    return u32x4_t{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c),
+                   __builtin_bit_cast(unsigned, d)};
+#else
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(d0, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(d0, true);
+    const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(d1, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(d1, true);
+    return u32x4_t{pack2bf(a[0], a[1]), pack2bf(b[0], b[1]), pack2bf(c[0], c[1]), pack2bf(d[0], d[1])};
+#endif
+}
+
 // 16 B of zeros that out-of-range K lanes load instead of real data (K tails, short K slices)
 __device__ const u32x4_t g_zero_page[4] = {};
 
@@ -216,11 +238,7 @@ __device__ __forceinline__ void smallm_body(const GemmParams& p, char* smem, int
         if (!W8) return __builtin_bit_cast(bf16x8_t, wreg[rt][ks]);
         const u32x4_t w = wreg[rt][ks >> 1];
         const unsigned d0 = w[2 * (ks & 1)], d1 = w[2 * (ks & 1) + 1];
-        typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-        const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(d0, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(d0, true);
-        const f32x2_t c2 = __builtin_amdgcn_cvt_pk_f32_fp8(d1, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(d1, true);
-        const u32x4_t o = {pack2bf(a[0], a[1]), pack2bf(b[0], b[1]), pack2bf(c2[0], c2[1]), pack2bf(d[0], d[1])};
-        return __builtin_bit_cast(bf16x8_t, o);
+        return __builtin_bit_cast(bf16x8_t, sm_fp8x8_to_bf16x8(d0, d1));
     };
 
     f32x4_t acc[RT][MT];
@@ -824,11 +842,7 @@ __device__ __forceinline__ void smallm_body_sx(const GemmParams& p, char* smem, 
                 } else {  // bytes [8 (ks & 1), +8) of piece ks >> 1: exact fp8 -> bf16
                     const u32x4_t w = af[rt][ks >> 1];
                     const unsigned d0 = w[2 * (ks & 1)], d1 = w[2 * (ks & 1) + 1];
-                    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-                    const f32x2_t e0 = __builtin_amdgcn_cvt_pk_f32_fp8(d0, false), e1 = __builtin_amdgcn_cvt_pk_f32_fp8(d0, true);
-                    const f32x2_t e2 = __builtin_amdgcn_cvt_pk_f32_fp8(d1, false), e3 = __builtin_amdgcn_cvt_pk_f32_fp8(d1, true);
-                    const u32x4_t o = {pack2bf(e0[0], e0[1]), pack2bf(e1[0], e1[1]), pack2bf(e2[0], e2[1]), pack2bf(e3[0], e3[1])};
-                    a = __builtin_bit_cast(bf16x8_t, o);
+                    a = __builtin_bit_cast(bf16x8_t, sm_fp8x8_to_bf16x8(d0, d1));
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
