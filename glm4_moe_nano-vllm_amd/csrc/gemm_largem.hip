@@ -150,7 +150,7 @@ constexpr int LM_LEAN = 1, LM_WIDEST = 2, LM_NOSTORE = 4, LM_DMA2 = 8, LM_DMA4 =
               LM_NT = 128, LM_EPIORD = 256, LM_NOPRIO = 512, LM_LOADPRIO = 1024,  // issue-priority studies
               LM_DEEP = 2048,  // 5-stage ring (all 160 KiB of LDS): one more K tile of prefetch distance
               LM_PH8 = 4096,   // CfgC: BK = 64, two buffers, four 16-MFMA phases per K tile (needs LM_LEAN)
-              LM_P3X = 8192, LM_QW = 16384, LM_RPRE = 32768;  // schedules of that loop (described there)
+              LM_P3X = 8192, LM_QW = 16384, LM_RPRE = 32768, LM_RFIRST = 65536, LM_MIR = 131072;  // schedules of that loop (described there)
 //   LM_EPIORD the epilogue's global LOADS (per-row scales) are issued before the next tile's ring fill, so that waiting
 //             for them does not drain the fill; and the wait that opens a tile leaves the previous tile's stores in
 //             flight (vmcnt counts in issue order and the fill was issued before them) whenever their number is
@@ -484,7 +484,8 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         auto quad = [&](auto t0c, auto ntc, auto m0c, auto nxc, auto xbc) {
             constexpr int t0 = decltype(t0c)::value, NT = decltype(ntc)::value;
             constexpr int mt0 = decltype(m0c)::value, NX = decltype(nxc)::value, XB = decltype(xbc)::value;
-            __builtin_amdgcn_s_setprio(1);
+            if constexpr ((VAR & LM_LOADPRIO) != 0) __builtin_amdgcn_s_setprio(0);
+            else if constexpr ((VAR & LM_NOPRIO) == 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
@@ -494,7 +495,8 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                         acc[t0 + tt][mt0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8_t, fw[ks * 4 + t0 + tt]),
                             __builtin_bit_cast(bf16x8_t, fx[XB + ks * NX + j]), acc[t0 + tt][mt0 + j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+            if constexpr ((VAR & LM_LOADPRIO) != 0) __builtin_amdgcn_s_setprio(1);  // the load interval runs at priority 1
+            else if constexpr ((VAR & LM_NOPRIO) == 0) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto reads_done = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
@@ -513,6 +515,81 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         using I6 = std::integral_constant<int, 6>;
         using XP0 = std::integral_constant<int, C::W_DMA + 0>;  // X pieces 0,1
         using XP2 = std::integral_constant<int, C::W_DMA + 2>;  // X pieces 2,3
+        if constexpr ((VAR & LM_MIR) != 0) {
+        //   LM_MIR  2 x 4-tile quadrants in MIRRORED order on alternate K tiles, reads before DMA: even K tiles run
+        //           (W01,X0-3) (W23,X0-3) (W23,X4-7) (W01,X4-7), odd ones (W23,..) (W01,..) (W01,..) (W23,..).  The W half
+        //           that opens K tile kt+1 is the one whose registers the last quadrant of K tile kt does not use, so
+        //           its 4 fragment reads move into load interval 3 of kt: reads per interval 8 / 4 / 8 / 4 instead of
+        //           12 / 4 / 8 / 0.  W(kt+1) (issued in phases 2-3 of kt-1) is waited for at the end of load interval 2
+        //           (vmcnt leaves the 6 younger pieces X(kt+1) 0-3, W(kt+2) 0,1 in flight), i.e. before barrier 8kt+6
+        //           at the latest, and first read in load interval 4kt+3 (epoch >= 8kt+6).
+        static_assert(!P3X && !QW, "LM_MIR is its own schedule");
+        auto ktile = [&](int kt, auto parc) {
+            constexpr int PAR = decltype(parc)::value;
+            using HA = std::integral_constant<int, 2 * PAR>;        // first W tile of the half that opens this K tile
+            using HB = std::integral_constant<int, 2 * (1 - PAR)>;  // ... of the other half
+            const int b = kt & 1;
+            const unsigned so = b * C::STAGE, so_n = (b ^ 1) * C::STAGE;
+            const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
+            auto pin_w = [&](auto hc) {
+                constexpr int t0 = decltype(hc)::value;
+                pin(fw[t0]); pin(fw[t0 + 1]); pin(fw[4 + t0]); pin(fw[4 + t0 + 1]);
+            };
+            // ---- phase 0
+            if (kt == 0) rd_w(so, HA{}, I2{});  // no previous K tile fetched them
+            rd_x(so, I0{}, I4{}, I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (has1) dma2(b ^ 1, kt + 1, XP0{});
+            reads_done();
+            pin_w(HA{});
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pin(fx[i]);
+            close_load();
+            quad(HA{}, I2{}, I0{}, I4{}, I0{});
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 1
+            rd_w(so, HB{}, I2{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (has1) dma2(b ^ 1, kt + 1, XP2{});
+            reads_done();
+            pin_w(HB{});
+            close_load();
+            quad(HB{}, I2{}, I0{}, I4{}, I0{});
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 2
+            rd_x(so, I4{}, I4{}, I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (has2) dma2(b, kt + 2, I0{});
+            reads_done();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pin(fx[i]);
+            // W(kt+1) has landed: younger than it are X(kt+1) 0-3 and, if issued, W(kt+2) 0,1
+            if (has2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C::X_DMA + 2) : "memory");
+            else if (has1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C::X_DMA) : "memory");
+            close_load();
+            quad(HB{}, I2{}, I4{}, I4{}, I0{});
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 3
+            if (has1) rd_w(so_n, HB{}, I2{});  // opens K tile kt+1
+            __builtin_amdgcn_sched_barrier(0);
+            if (has2) {
+                dma2(b, kt + 2, I2{});
+                reads_done();
+                asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C::W_DMA) : "memory");
+            } else {
+                reads_done();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (has1) pin_w(HB{});
+            close_load();
+            quad(HA{}, I2{}, I4{}, I4{}, I0{});
+            __builtin_amdgcn_s_barrier();
+        };
+        for (int kt = 0; kt < nk; kt += 2) {
+            ktile(kt, I0{});
+            if (kt + 1 < nk) ktile(kt + 1, std::integral_constant<int, 1>{});
+        }
+        } else
         if constexpr ((VAR & LM_RPRE) != 0) {
         //   LM_RPRE (with LM_QW) the fragment reads of phases 1-3 (two X tiles each) are issued at the START of the
         //           previous phase's MFMA interval into the other half of fx and retire behind its MFMAs: the load
@@ -574,24 +651,32 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             __builtin_amdgcn_s_barrier();
         }
         } else {
+        //   LM_RFIRST  the fragment reads of a load interval are issued BEFORE its DMA instructions: the ~70-cycle DMA
+        //           issues then run under the LDS round trip of the reads instead of in front of it.
+        constexpr bool RF = (VAR & LM_RFIRST) != 0;
         for (int kt = 0; kt < nk; ++kt) {
             const int b = kt & 1;
             const unsigned so = b * C::STAGE;
             const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
+            auto mid = [&]() { __builtin_amdgcn_sched_barrier(0); };
             // ---- phase 0
-            if (!P3X && has1) dma2(b ^ 1, kt + 1, XP0{});
+            auto dma0 = [&]() { if (!P3X && has1) dma2(b ^ 1, kt + 1, XP0{}); };
+            if (!RF) dma0();
             if constexpr (QW) {
                 rd_w(so, I0{}, I4{});
                 rd_x(so, I0{}, I2{}, I0{});
-                reads_done();
+            } else {
+                rd_w(so, I0{}, I2{});
+                rd_x(so, I0{}, I4{}, I0{});
+            }
+            if (RF) { mid(); dma0(); }
+            reads_done();
+            if constexpr (QW) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) pin(fw[i]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) pin(fx[i]);
             } else {
-                rd_w(so, I0{}, I2{});
-                rd_x(so, I0{}, I4{}, I0{});
-                reads_done();
                 pin(fw[0]); pin(fw[1]); pin(fw[4]); pin(fw[5]);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) pin(fx[i]);
@@ -601,15 +686,16 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             else quad(I0{}, I2{}, I0{}, I4{}, I0{});
             __builtin_amdgcn_s_barrier();
             // ---- phase 1
-            if (has1) dma2(b ^ 1, kt + 1, XP2{});
+            auto dma1 = [&]() { if (has1) dma2(b ^ 1, kt + 1, XP2{}); };
+            if (!RF) dma1();
+            if constexpr (QW) rd_x(so, I2{}, I2{}, I0{});
+            else rd_w(so, I2{}, I2{});
+            if (RF) { mid(); dma1(); }
+            reads_done();
             if constexpr (QW) {
-                rd_x(so, I2{}, I2{}, I0{});
-                reads_done();
 #pragma unroll
                 for (int i = 0; i < 4; ++i) pin(fx[i]);
             } else {
-                rd_w(so, I2{}, I2{});
-                reads_done();
                 pin(fw[2]); pin(fw[3]); pin(fw[6]); pin(fw[7]);
             }
             close_load();
@@ -617,29 +703,29 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             else quad(I2{}, I2{}, I0{}, I4{}, I0{});
             __builtin_amdgcn_s_barrier();
             // ---- phase 2
-            if (has2) dma2(b, kt + 2, I0{});
-            if constexpr (QW) {
-                rd_x(so, I4{}, I2{}, I0{});
-                reads_done();
+            auto dma2_ = [&]() { if (has2) dma2(b, kt + 2, I0{}); };
+            if (!RF) dma2_();
+            if constexpr (QW) rd_x(so, I4{}, I2{}, I0{});
+            else rd_x(so, I4{}, I4{}, I0{});
+            if (RF) { mid(); dma2_(); }
+            reads_done();
 #pragma unroll
-                for (int i = 0; i < 4; ++i) pin(fx[i]);
-            } else {
-                rd_x(so, I4{}, I4{}, I0{});
-                reads_done();
-#pragma unroll
-                for (int i = 0; i < 8; ++i) pin(fx[i]);
-            }
+            for (int i = 0; i < (QW ? 4 : 8); ++i) pin(fx[i]);
             close_load();
             if constexpr (QW) quad(I0{}, I4{}, I4{}, I2{}, I0{});
             else quad(I2{}, I2{}, I4{}, I4{}, I0{});
             __builtin_amdgcn_s_barrier();
             // ---- phase 3: the last pieces, then this wave's share of K tile kt+1 must have landed
-            if (has2) {
-                dma2(b, kt + 2, I2{});
-                if constexpr (P3X) dma2(b, kt + 2, XP0{});
-            }
+            auto dma3 = [&]() {
+                if (has2) {
+                    dma2(b, kt + 2, I2{});
+                    if constexpr (P3X) dma2(b, kt + 2, XP0{});
+                }
+            };
+            if (!RF || !QW) dma3();
             if constexpr (QW) {
                 rd_x(so, I6{}, I2{}, I0{});
+                if (RF) { mid(); dma3(); }
                 reads_done();
 #pragma unroll
                 for (int i = 0; i < 4; ++i) pin(fx[i]);
@@ -978,10 +1064,10 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
     const int64_t avg_rows = p.R / (p.G > 0 ? p.G : 1);
     const bool use_b = ch == 2 || (ch == 0 && avg_rows >= 192);
     // the lean load phase addresses x and the group's weights through 32-bit buffer offsets and has no K tail path
-    // defaults (tools/largem_ab.py, one process, T = 16384): the quadrant-phase loop; long K (gate|up, dense
-    // projections) with the phase-0 DMA moved to phase 3, the down projection with 4 x 2-tile quadrants
+    // default (tools/largem_ab.py, one process, T = 16384): the quadrant-phase loop with 4 x 2-tile quadrants and the
+    // fragment reads of a load interval issued before its DMA
     int var = g_largem_variant >= 0 ? g_largem_variant : env_variant() >= 0 ? env_variant() : GLM_LM_DEFAULT_VAR;
-    if (var < 0) var = LM_LEAN | LM_WIDEST | LM_PH8 | (MODE == GEMM_DOWN ? LM_QW : LM_P3X);
+    if (var < 0) var = LM_LEAN | LM_WIDEST | LM_PH8 | LM_QW | LM_RFIRST;
     const int bk = use_b ? ((var & LM_PH8) ? LmCfgC::BK : LmCfgB::BK) : LmCfgA::BK;
     const int64_t wrows = MODE == GEMM_GATEUP ? 2 * (int64_t)p.N : (int64_t)p.N;
     const bool lean_ok = p.K % bk == 0 && p.R * p.ldx * 2 < (1ll << 31) && wrows * p.ldw * 2 < (1ll << 31) &&
@@ -1001,6 +1087,14 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
         GLM_LM_CASE(12291); // ... with the DMA of phase 0 moved to phase 3
         GLM_LM_CASE(20483); // ... with 4 x 2-tile quadrants
         GLM_LM_CASE(53251); // ... and the reads of phases 1-3 issued from the previous MFMA interval
+        GLM_LM_CASE(69635); // quadrant phases, reads before DMA in every load interval
+        GLM_LM_CASE(77827); // ... with LM_P3X
+        GLM_LM_CASE(86019); // ... with LM_QW
+        GLM_LM_CASE(86531);  // LM_QW | LM_RFIRST without the MFMA-interval priority
+        GLM_LM_CASE(87043);  // ... with the LOAD interval at priority 1
+#if GLM_LM_STUDY >= 2
+        GLM_LM_CASE(135171); // quadrant phases, mirrored quadrant order, reads 8/4/8/4 (no gain: profiles/r02)
+#endif
 #if GLM_LM_STUDY >= 2  // measured and not kept (profiles/r02/largem_ab_*.json)
         GLM_LM_CASE(1);
         GLM_LM_CASE(2);

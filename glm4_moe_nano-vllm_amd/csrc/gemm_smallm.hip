@@ -1095,10 +1095,11 @@ int glm_launch_gemm_smallm_fp8w(int mode, const GemmParams& p, hipStream_t st) {
 #ifndef GLM_SM_FP8_NO_SX
     // 16-row blocks (a 32-row group such as the shared expert at bs=32 re-reads its weights once): 80 KiB per workgroup
     // r02, 12 layers at bs=32 (same box): gate|up 144.7 us (best 135.0) vs 149.0 (142.0) for the VGPR body; down 74.2 vs
-    // 71.3 -> the shared-activation body for gate|up only (-DGLM_SM_FP8_SX_DOWN adds down); 3 stages at one
-    // workgroup per CU measured 165.7 / 91.1
+    // 71.3 with the two-step fp8 -> bf16 conversion; with the packed convert (sm_fp8x8_to_bf16x8) the shared-activation
+    // body wins for both (tools/fp8_bench.py, same box: gate|up 122.5 -> 111.5 us, down 67.5 (VGPR body) -> 60.1 us);
+    // -DGLM_SM_FP8_NO_SX_DOWN keeps the VGPR body for down; 3 stages at one workgroup per CU measured 165.7 / 91.1
     if (p.R > 16 && mode == GEMM_GATEUP) return launch_cfg_sx<GEMM_GATEUP, 4, 2, 1, true>(p, st);
-#ifdef GLM_SM_FP8_SX_DOWN
+#ifndef GLM_SM_FP8_NO_SX_DOWN
     if (p.R > 16 && mode == GEMM_DOWN) return launch_cfg_sx<GEMM_DOWN, 4, 2, 1, true>(p, st);
 #endif
 #endif
