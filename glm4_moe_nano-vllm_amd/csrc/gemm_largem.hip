@@ -654,6 +654,9 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         //   LM_RFIRST  the fragment reads of a load interval are issued BEFORE its DMA instructions: the ~70-cycle DMA
         //           issues then run under the LDS round trip of the reads instead of in front of it.
         constexpr bool RF = (VAR & LM_RFIRST) != 0;
+#if GLM_LM_STAMP
+        unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#endif
         for (int kt = 0; kt < nk; ++kt) {
             const int b = kt & 1;
             const unsigned so = b * C::STAGE;
@@ -661,6 +664,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             auto mid = [&]() { __builtin_amdgcn_sched_barrier(0); };
             // ---- phase 0
             auto dma0 = [&]() { if (!P3X && has1) dma2(b ^ 1, kt + 1, XP0{}); };
+            LM_T(0);
             if (!RF) dma0();
             if constexpr (QW) {
                 rd_w(so, I0{}, I4{});
@@ -670,7 +674,9 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                 rd_x(so, I0{}, I4{}, I0{});
             }
             if (RF) { mid(); dma0(); }
+            LM_T(1);  // 0: phase 0 read + DMA issue
             reads_done();
+            LM_T(2);  // 1: phase 0 LDS wait
             if constexpr (QW) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) pin(fw[i]);
@@ -682,9 +688,12 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                 for (int i = 0; i < 8; ++i) pin(fx[i]);
             }
             close_load();
+            LM_T(3);  // 2: phase 0 barrier a
             if constexpr (QW) quad(I0{}, I4{}, I0{}, I2{}, I0{});
             else quad(I0{}, I2{}, I0{}, I4{}, I0{});
+            LM_T(4);  // 3: phase 0 MFMA issue
             __builtin_amdgcn_s_barrier();
+            LM_T(5);  // 4: phase 0 barrier b
             // ---- phase 1
             auto dma1 = [&]() { if (has1) dma2(b ^ 1, kt + 1, XP2{}); };
             if (!RF) dma1();
@@ -736,7 +745,15 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             if constexpr (QW) quad(I0{}, I4{}, I6{}, I2{}, I0{});
             else quad(I0{}, I2{}, I4{}, I4{}, I0{});
             __builtin_amdgcn_s_barrier();
+            LM_T(6);  // 5: phases 1-3
         }
+#if GLM_LM_STAMP
+        if (blockIdx.x == 8 && lane == 0 && (wid == 0 || wid == 4)) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) g_lm_stamps[wid >> 2][i] = tacc[i];
+            g_lm_stamps[wid >> 2][7] = (unsigned long long)nk;
+        }
+#endif
         }  // !LM_RPRE
         if (wid < 4) __builtin_amdgcn_s_barrier();  // match the other group's extra barrier
         } else {
@@ -1065,9 +1082,9 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
     const bool use_b = ch == 2 || (ch == 0 && avg_rows >= 192);
     // the lean load phase addresses x and the group's weights through 32-bit buffer offsets and has no K tail path
     // default (tools/largem_ab.py, one process, T = 16384): the quadrant-phase loop with 4 x 2-tile quadrants and the
-    // fragment reads of a load interval issued before its DMA
+    // fragment reads of a load interval issued before its DMA, no priority flips (86531: +1 % over 86019)
     int var = g_largem_variant >= 0 ? g_largem_variant : env_variant() >= 0 ? env_variant() : GLM_LM_DEFAULT_VAR;
-    if (var < 0) var = LM_LEAN | LM_WIDEST | LM_PH8 | LM_QW | LM_RFIRST;
+    if (var < 0) var = LM_LEAN | LM_WIDEST | LM_PH8 | LM_QW | LM_RFIRST | LM_NOPRIO;
     const int bk = use_b ? ((var & LM_PH8) ? LmCfgC::BK : LmCfgB::BK) : LmCfgA::BK;
     const int64_t wrows = MODE == GEMM_GATEUP ? 2 * (int64_t)p.N : (int64_t)p.N;
     const bool lean_ok = p.K % bk == 0 && p.R * p.ldx * 2 < (1ll << 31) && wrows * p.ldw * 2 < (1ll << 31) &&

@@ -22,6 +22,9 @@ lib = ops.load_library()
 f = lib.glm_debug_largem_stamps
 f.restype = ctypes.c_int; f.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 names = ["dma issue", "lds read issue", "dma wait", "lds wait", "barrier 1", "mfma issue", "barrier 2"]
+if os.environ.get("GLM_LARGEM_VARIANT", "").strip() in ("", "-1") or int(os.environ["GLM_LARGEM_VARIANT"]) & 4096:
+    # quadrant-phase loop (default): phase 0 in detail, phases 1-3 as one figure
+    names = ["p0 read+dma issue", "p0 lds wait", "p0 barrier a", "p0 mfma", "p0 barrier b", "phases 1-3", "-"]
 def show(tag):
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 16)()
