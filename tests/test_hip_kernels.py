@@ -612,6 +612,52 @@ def test_gemm_bf16_large_m(ops, M, N, K, bias):
     assert_close_bf16(out, O.linear(x, w, b), 1, 0.05, atol=2 ** -9, what=f"gemm(large) {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("K", [64, 128, 192, 320])
+def test_gemm_large_m_quadrant_loop_equals_plain_loop(ops, K):
+    """The default large-M loop (256x256x64 tiles on two LDS buffers, operand slots refilled as soon as their own last
+    fragment read retired; csrc/gemm_largem.hip LM_PH8) against variant 0 of the same kernel (4-stage ring, 256x256x32),
+    bit for bit, at 1, 2, 3 and 5 K tiles (prologue / steady state / drain of the two-buffer schedule), for the plain,
+    gate|up and down epilogues, over ragged groups (one empty, one with a partial last row block)."""
+    lib = ops.load_library()
+    H, I = K, 192
+    counts = [300, 0, 513, 256, 211]                      # average 256 rows per group: the 256-row tile configuration
+    E, R = len(counts) - 1, sum(counts)
+    offs = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32)
+    g = torch.Generator().manual_seed(K)
+    tok = torch.randint(0, 400, (R,), generator=g, dtype=torch.int32)
+    x = rnd(400, H, seed=70 + K)
+    w13 = rnd(E + 1, 2 * I, H, seed=71, scale=H ** -0.5)
+    scale = (torch.rand(R, generator=g) + 0.1).to(BF)
+    act_in = rnd(R, K, seed=72)
+    w2 = rnd(E + 1, 136, K, seed=73, scale=K ** -0.5)      # N = 136: a partial column tile
+    xp, wp = rnd(700, K, seed=74), rnd(264, K, seed=75, scale=K ** -0.5)
+    bias = rnd(264, seed=76)
+
+    def run():
+        a = ops.grouped_gemm_gateup_silu(dev(x), dev(w13), dev(offs), dev(tok), R)
+        y = ops.grouped_gemm_down(dev(act_in), dev(w2), dev(offs), dev(scale), E)
+        z = ops.gemm_bf16(dev(xp), dev(wp), dev(bias))
+        torch.cuda.synchronize()
+        return a.cpu(), y.cpu(), z.cpu()
+
+    old = lib.glm_debug_largem_variant(0)
+    try:
+        ref = run()
+        lib.glm_debug_largem_variant(-1)
+        got = run()
+    finally:
+        lib.glm_debug_largem_variant(old)
+    for name, a, b in zip(("gate|up", "down", "plain"), got, ref):
+        assert torch.equal(a, b), f"{name}: quadrant loop differs from variant 0 at K={K}"
+    # and variant 0 itself against the oracle on two groups
+    W13 = w13
+    for e in (0, 4):
+        rows = slice(int(offs[e]), int(offs[e + 1]))
+        a_ref = O.silu_and_mul(O.linear(x[tok[rows].long()], W13[e]))
+        assert_close_bf16(got[0][rows], a_ref, 3, 0.06, atol=1e-3, what=f"act K={K} group {e}")
+    assert_close_bf16(got[2], O.linear(xp, wp, bias), 1, 0.05, atol=2 ** -9, what=f"plain K={K}")
+
+
 @pytest.mark.parametrize("T,E,k,H,I", [(600, 4, 2, 256, 128), (1024, 8, 2, 128, 352), (300, 2, 1, 512, 64)])
 def test_moe_block_large_t(ops, T, E, k, H, I):
     x = rnd(T, H, seed=91)
