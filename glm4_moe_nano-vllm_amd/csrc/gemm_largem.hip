@@ -98,9 +98,12 @@ __device__ const u32x4_t g_zero_page_lm[4] = {};
 #endif
 #if GLM_LM_STAMP
 __device__ unsigned long long g_lm_stamps[2][8];
+__device__ unsigned long long g_lm_tile_stamps[8];  // workgroup 8, wave 0: cycles per tile switch segment, [7] = tiles
+#define LM_TS(i) do { unsigned long long t_ = __builtin_readcyclecounter(); if (i) ts_acc[(i) - 1] += t_ - ts_prev; ts_prev = t_; } while (0)
 #define LM_T(i) do { if (GLM_LM_STAMP) { unsigned long long t_ = __builtin_readcyclecounter(); if (i) tacc[i - 1] += t_ - tprev; tprev = t_; } } while (0)
 #else
 #define LM_T(i) do {} while (0)
+#define LM_TS(i) do {} while (0)
 #endif
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -395,9 +398,13 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
     }
     setup_sources();
     fill_ring();
+#if GLM_LM_STAMP
+    unsigned long long ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ts_prev = 0;
+#endif
     for (;;) {
         // the tile whose ring is filling is now the tile being computed
         const int grp_c = grp, m0_c = m0, mcnt_c = mcnt, ntile_c = ntile;
+        LM_TS(0);
         f32x4_t acc[4][C::MT];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -426,6 +433,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();                 // every share of the first DIST tiles landed
+        LM_TS(1);  // 0: top-of-tile wait + barrier
         if constexpr (C::PH8) {
         // ---- CfgC: four phases per K tile, each = load interval | barrier | 16 MFMAs | barrier; waves 4-7 run one
         // barrier behind waves 0-3, so the two waves of a SIMD alternate between the two kinds of interval.
@@ -916,11 +924,15 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             for (int mt = 0; mt < C::MT; ++mt) asm volatile("" : "+v"(sc_pre[mt]));  // the loads stay above the fill
         }
         // ---- next tile: every wave is past its last LDS read, so the ring can be refilled right away ----
+        LM_TS(2);  // 1: K loop
         pos += pstep;
         const bool more = find_tile();
+        LM_TS(3);  // 2: tile search
         if (more) {
             setup_sources();
+            LM_TS(4);  // 3: source set-up
             fill_ring();
+            LM_TS(5);  // 4: ring fill issue
         }
 
         // ---- epilogue of the finished tile ----
@@ -1017,6 +1029,14 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                               !((VAR & LM_LDSEPI) != 0 && NOUT == 4);
             pending_stores = full ? LM_STORES_FULL : 0;
         }
+        LM_TS(6);  // 5: epilogue
+#if GLM_LM_STAMP
+        ts_acc[7] += 1;
+        if (!more && blockIdx.x == 8 && tid == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g_lm_tile_stamps[i] = ts_acc[i];
+        }
+#endif
         if (!more) break;
     }
 }
@@ -1082,9 +1102,10 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
     const bool use_b = ch == 2 || (ch == 0 && avg_rows >= 192);
     // the lean load phase addresses x and the group's weights through 32-bit buffer offsets and has no K tail path
     // default (tools/largem_ab.py, one process, T = 16384): the quadrant-phase loop with 4 x 2-tile quadrants and the
-    // fragment reads of a load interval issued before its DMA, no priority flips (86531: +1 % over 86019)
+    // fragment reads of a load interval issued before its DMA, no priority flips (86531: +1 % over 86019), epilogue
+    // ordering (86787: down +1 %, gate|up unchanged)
     int var = g_largem_variant >= 0 ? g_largem_variant : env_variant() >= 0 ? env_variant() : GLM_LM_DEFAULT_VAR;
-    if (var < 0) var = LM_LEAN | LM_WIDEST | LM_PH8 | LM_QW | LM_RFIRST | LM_NOPRIO;
+    if (var < 0) var = LM_LEAN | LM_WIDEST | LM_PH8 | LM_QW | LM_RFIRST | LM_NOPRIO | LM_EPIORD;
     const int bk = use_b ? ((var & LM_PH8) ? LmCfgC::BK : LmCfgB::BK) : LmCfgA::BK;
     const int64_t wrows = MODE == GEMM_GATEUP ? 2 * (int64_t)p.N : (int64_t)p.N;
     const bool lean_ok = p.K % bk == 0 && p.R * p.ldx * 2 < (1ll << 31) && wrows * p.ldw * 2 < (1ll << 31) &&
@@ -1108,6 +1129,7 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
         GLM_LM_CASE(77827); // ... with LM_P3X
         GLM_LM_CASE(86019); // ... with LM_QW
         GLM_LM_CASE(86531);  // LM_QW | LM_RFIRST without the MFMA-interval priority
+        GLM_LM_CASE(86787);  // ... with LM_EPIORD (scale loads above the ring fill, counted wait that leaves the stores in flight)
         GLM_LM_CASE(87043);  // ... with the LOAD interval at priority 1
 #if GLM_LM_STUDY >= 2
         GLM_LM_CASE(135171); // quadrant phases, mirrored quadrant order, reads 8/4/8/4 (no gain: profiles/r02)
@@ -1170,5 +1192,9 @@ extern "C" int glm_debug_largem_variant(int v) {
 // timing study only: per-segment cycle sums of the last tile workgroup 8 ran (waves 0 and 4), [2][8]; [7] = K tiles
 extern "C" int glm_debug_largem_stamps(unsigned long long* out16) {
     return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lm_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+// same: [0..5] = top-of-tile wait, K loop, tile search, source set-up, ring fill issue, epilogue; [7] = tiles
+extern "C" int glm_debug_largem_tile_stamps(unsigned long long* out8) {
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lm_tile_stamps), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
 }
 #endif

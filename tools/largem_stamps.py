@@ -25,8 +25,16 @@ names = ["dma issue", "lds read issue", "dma wait", "lds wait", "barrier 1", "mf
 if os.environ.get("GLM_LARGEM_VARIANT", "").strip() in ("", "-1") or int(os.environ["GLM_LARGEM_VARIANT"]) & 4096:
     # quadrant-phase loop (default): phase 0 in detail, phases 1-3 as one figure
     names = ["p0 read+dma issue", "p0 lds wait", "p0 barrier a", "p0 mfma", "p0 barrier b", "phases 1-3", "-"]
+f2 = getattr(lib, "glm_debug_largem_tile_stamps", None)
+tnames = ["top-of-tile wait", "K loop", "tile search", "source set-up", "ring fill issue", "epilogue"]
 def show(tag):
     torch.cuda.synchronize()
+    if f2 is not None:
+        f2.restype = ctypes.c_int; f2.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+        b8 = (ctypes.c_ulonglong * 8)()
+        if f2(b8) == 0 and b8[7]:
+            print(f"{tag} tile switch (workgroup 8, wave 0, {b8[7]} tiles), cycles per tile: " +
+                  ", ".join(f"{tnames[i]} {b8[i]/b8[7]:.0f}" for i in range(6)))
     buf = (ctypes.c_ulonglong * 16)()
     assert f(buf) == 0
     for g in range(2):
