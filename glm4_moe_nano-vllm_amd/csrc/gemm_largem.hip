@@ -6,10 +6,12 @@
 //   * out^T = W · x^T: weight rows on the MFMA row axis (A), tokens on the column axis (B), so a
 //     lane's 4 accumulator registers are 4 consecutive output columns of one token (8-B stores)
 //     and gate/up sit in the same lanes for the fused SiLU·mul epilogue.
-//   * 8 waves as 4(n) x 2(m); two tile configurations of the same kernel: 256(n) x 256(m) x 32(k)
-//     with a 4-stage LDS ring (wave tile 64x128, 128 accumulator registers; 12 LDS reads + 4 DMA
-//     per 32 MFMAs) for large groups, 256 x 128 x 64 with a 3-stage ring (wave tile 64x64) for
-//     smaller ones.  Measured at T=16384: 942 vs 851 TFLOP/s on the same box.
+//   * 8 waves as 4(n) x 2(m), wave tile 64(n) x 128(m).  Default for large groups (CfgC, r02): 256(n) x 256(m) x 64(k) tiles
+//     on TWO 64-KiB LDS buffers, a K tile = four phases of (fragment reads + 2 DMA | barrier | 16 MFMAs | barrier); an
+//     operand's slot is refilled as soon as its own last fragment read has retired (argument above the loop).  Measured at
+//     T=16384 in one process: 1255 / 1058 TFLOP/s (gate|up / down) against 1081 / 923 for the loop it replaced (CfgB:
+//     256 x 256 x 32, 4-stage ring, two 32-MFMA phases per K tile — still variant 3), all bit-identical.  Smaller groups
+//     (< 192 rows on average): CfgA, 256 x 128 x 64 with a 3-stage ring (wave tile 64x64).
 //   * both operand tiles are staged by LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction);
 //     the LDS image is lane-linear, bank conflicts of the 16-row ds_read_b128 fragment reads are
 //     removed by permuting the SOURCE chunk: chunk' = chunk ^ ((row >> 1) & 7) for 128-B rows,
@@ -19,7 +21,7 @@
 //   * LDS ring with prefetch distance NSTAGE-1, raw s_barriers and COUNTED s_waitcnt vmcnt: the
 //     DMA of the newest tiles stays in flight across the barriers.  Fragment reads are inline asm
 //     (hipcc would drain the DMA before them).
-//   * two phases per K tile (loads | MFMAs) and waves 4-7 staggered one barrier behind waves 0-3,
+//   * load and MFMA intervals alternate and waves 4-7 are staggered one barrier behind waves 0-3,
 //     so the two waves of each SIMD alternate between feeding the matrix pipe and issuing loads
 //     (all 8 waves in lockstep left the pipe idle ~60 % of the cycles: 830 TFLOP/s).
 //   * 1-D grid remapped so that one XCD gets a contiguous run of tiles, ordered in bands of 4 row
