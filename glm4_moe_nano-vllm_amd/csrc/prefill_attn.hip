@@ -21,6 +21,7 @@
 // K/V come either from contiguous [Tk, nkv, hd] tensors or from the paged cache through
 // block_tables (prefix-cache hit, attention.py:86-87).
 #include "common.h"
+#include <type_traits>
 
 // timing-only ablations (results are wrong): 1 no exp, 2 no barrier, 4 no S MFMA, 8 no PV MFMA, 16 no LDS reads,
 // 32 no K/V staging after the first two tiles
@@ -32,6 +33,12 @@
 #endif
 #ifndef GLM_FA_NW
 #define GLM_FA_NW 4
+#endif
+#ifndef GLM_FA_QT
+#define GLM_FA_QT 2   // 16-row query tiles per wave; 4 = 64 rows per wave at ONE wave per SIMD (generic unit loop)
+#endif
+#ifndef GLM_FA_GENERIC
+#define GLM_FA_GENERIC (GLM_FA_QT != 2)  // 1: the unit loop written over FA_QT instead of the hand-unrolled two-tile one
 #endif
 
 // GLM_FA_STAMP=1 (timing study only): wave 0 of workgroup 0 accumulates s_memtime deltas per loop segment
@@ -51,7 +58,7 @@ __device__ unsigned long long g_fa_stamps[16];
 namespace {
 
 constexpr int FA_HD = 128, FA_ROWB = 256;
-constexpr int FA_QT = 2;                   // 16-row query tiles per wave
+constexpr int FA_QT = GLM_FA_QT;           // 16-row query tiles per wave
 constexpr int FA_NW = GLM_FA_NW;           // waves per workgroup
 constexpr int FA_NT = 64 * FA_NW;
 constexpr int FA_BQ = 16 * FA_QT * FA_NW, FA_BK = 64;
@@ -77,11 +84,18 @@ __device__ __forceinline__ void lds_read_tr16_b64(u32x2_t& dst, unsigned addr) {
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(uintptr_t)(const lds_void_t*)p;
 }
+template <int N, class F>
+__device__ __forceinline__ void fa_static_for(F&& f) {
+    if constexpr (N > 0) {
+        fa_static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
 
 // launch bound of 2 waves per SIMD caps the kernel at 256 registers, which makes hipcc pick the VGPR form of the
 // MFMAs: with the default (512) the accumulators live in AGPRs and every slab pays ~40 v_accvgpr copies
 template <bool PAGED>
-__global__ __launch_bounds__(FA_NT, 2) void prefill_attn_kernel(
+__global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
     const int32_t* __restrict__ block_tables, int64_t bt_stride, bf16_t* __restrict__ out, int nh,
@@ -372,6 +386,147 @@ __global__ __launch_bounds__(FA_NT, 2) void prefill_attn_kernel(
     // consume the kernel-argument scalars here: otherwise the wait for their s_load lands at the first use inside
     // the loop as an lgkmcnt(0), which also drains every LDS read that was meant to overlap the softmax
     asm volatile("" ::"s"(scale_log2e), "s"(lk), "s"(off));
+#if GLM_FA_GENERIC
+    // ---- the unit loop over FA_QT query tiles per wave.  A tile has 2 * FA_QT units u = (slab u / FA_QT, query tile
+    // u % FA_QT); step u: S MFMAs of unit u+1 first, then LDS reads / staging, then softmax + PV of unit u.  Register
+    // reuse decides where the reads go: K of slab 1 once S(slab 0, last tile) is issued (step FA_QT-2), V of slab 1 once
+    // PV(slab 0, last tile) is issued (step FA_QT), K of the next tile's slab 0 once S(slab 1, last tile) is issued (step
+    // 2 FA_QT - 2) — behind the tile's barrier, which therefore sits in that step.  With FA_QT = 2 this is the
+    // hand-unrolled schedule below, instruction for instruction.
+    if (ntiles > 0) {
+        f32x4_t sbuf[2][2];  // S of unit u in sbuf[u & 1]
+        stage(0, 0);
+        if (ntiles > 1) {
+            stage(1, 1);
+            if (FA_PPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        FA_READ_K(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
+        s_mfma(sbuf[0], 0);
+        auto live = [&](int kbase, int qt) -> bool {
+            return kbase <= qbase + (16 * FA_QT) * wid + 16 * qt + 15 + off && kbase < lk;
+        };
+        constexpr int NU = 2 * FA_QT;
+#if GLM_FA_QT >= 4 && !defined(GLM_FA_NO_PVPIPE)
+        // One wave per SIMD: nothing else fills the matrix pipe while this wave runs its softmax, so PV runs ONE UNIT
+        // LATE — step u issues S(u+1), the softmax of unit u and the PV MFMAs of unit u-1 with no scheduling fence
+        // between them (the compiler interleaves the independent VALU and MFMA streams).  V of a slab is then read at
+        // the end of the step that issued the last PV of the previous slab and waited for one step later.
+        bf16x8_t pf_prev;
+        bool lv_prev = false;
+        for (int t = 0; t < ntiles; ++t) {
+            const int kb0 = t * FA_BK;
+            const bool more = t + 1 < ntiles;
+            fa_static_for<NU>([&](auto uc) {
+                constexpr int u = decltype(uc)::value, slab = u / FA_QT, qt = u % FA_QT, v = u + 1;
+                constexpr int pq = (u + NU - 1) % NU % FA_QT;  // query tile of the previous unit
+                bf16x8_t pf;
+                if constexpr (v < NU) {
+                    if constexpr (v == FA_QT) asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
+                    if (live(kb0 + 32 * (v / FA_QT), v % FA_QT)) s_mfma(sbuf[v & 1], v % FA_QT);
+                } else if (more) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
+                    if (live(kb0 + FA_BK, 0)) s_mfma(sbuf[0], 0);
+                }
+                if constexpr (u == FA_QT - 2) { FA_READ_K(1); }
+                if constexpr (u == 0) { if (t >= 1 && more) stage_slot((t + 1) & 1, t + 1, 2); }
+                if constexpr (u == 1) { if (t >= 1 && more) stage_slot((t + 1) & 1, t + 1, 3); }
+                if constexpr (u == NU - 2) {
+                    if (more) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        if (t + 2 < ntiles) stage_slot(t & 1, t + 2, 0);
+                    }
+                }
+                if constexpr (u == NU - 1) { if (more && t + 2 < ntiles) stage_slot(t & 1, t + 2, 1); }
+                const bool lv = live(kb0 + 32 * slab, qt);
+                if (lv) pf = softmax(sbuf[u & 1], kb0 + 32 * slab, qt);
+                // V of this unit's predecessor: slab 0 was read at the end of step 0, slab 1 at the end of step FA_QT
+                if constexpr (u == 1 || u == FA_QT + 1) asm volatile("s_waitcnt lgkmcnt(0)" : FA_V_REGS : : "memory");
+                if (lv_prev) pv_mfma(pf_prev, pq);
+                pf_prev = pf;
+                lv_prev = lv;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (u == 0) { FA_READ_V(0); }       // PV of the previous tile's last unit is issued
+                if constexpr (u == FA_QT) { FA_READ_V(1); }   // PV(slab 0, last query tile) is issued
+                if constexpr (u == NU - 2) {
+                    if (more) {  // K of the next tile (kf is free: S(slab 1, last query tile) was issued in this step)
+                        const int flip = (t & 1) ? -FA_STAGE : FA_STAGE;
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) k_abs[ks] += flip;
+                        FA_READ_K(0);
+                    }
+                }
+                if constexpr (u == NU - 1) {
+                    if (more) {  // V addresses flip after the last V read of this tile (step FA_QT) and its use
+                        const int flip = (t & 1) ? -FA_STAGE : FA_STAGE;
+#pragma unroll
+                        for (int dt = 0; dt < 8; ++dt) v_abs[dt] += flip;
+                    }
+                }
+            });
+        }
+        if (lv_prev) pv_mfma(pf_prev, FA_QT - 1);
+    }
+#else
+        constexpr int NU = 2 * FA_QT;
+        for (int t = 0; t < ntiles; ++t) {
+            const int kb0 = t * FA_BK;
+            const bool more = t + 1 < ntiles;
+            fa_static_for<NU>([&](auto uc) {
+                constexpr int u = decltype(uc)::value, slab = u / FA_QT, qt = u % FA_QT, v = u + 1;
+                bf16x8_t pf;
+                // ---- S of the next unit
+                if constexpr (v < NU) {
+                    if constexpr (v == FA_QT) asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");  // K of slab 1
+                    if (live(kb0 + 32 * (v / FA_QT), v % FA_QT)) s_mfma(sbuf[v & 1], v % FA_QT);
+                } else if (more) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");  // K of the next tile's slab 0
+                    if (live(kb0 + FA_BK, 0)) s_mfma(sbuf[0], 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- LDS reads, staging, tile switch
+                if constexpr (u == 0) { FA_READ_V(0); }
+                if constexpr (u == FA_QT - 2) { FA_READ_K(1); }
+                if constexpr (u == FA_QT) { FA_READ_V(1); }
+                if constexpr (u == 0) { if (t >= 1 && more) stage_slot((t + 1) & 1, t + 1, 2); }
+                if constexpr (u == 1) { if (t >= 1 && more) stage_slot((t + 1) & 1, t + 1, 3); }
+                if constexpr (u == NU - 2) {
+                    if constexpr (u == FA_QT) asm volatile("s_waitcnt lgkmcnt(0)" : FA_V_REGS : : "memory");  // the last read
+                    if (more) {
+                        // tile t+1 was issued a whole tile ago; after the barrier every wave is done with this buffer,
+                        // which tile t+2 may then overwrite
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (!(GLM_FA_ABLATE & 2)) __builtin_amdgcn_s_barrier();
+                        if (t + 2 < ntiles) stage_slot(t & 1, t + 2, 0);
+                        const int flip = (t & 1) ? -FA_STAGE : FA_STAGE;
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) k_abs[ks] += flip;
+#pragma unroll
+                        for (int dt = 0; dt < 8; ++dt) v_abs[dt] += flip;
+                        FA_READ_K(0);
+                    }
+                }
+                if constexpr (u == NU - 1) { if (more && t + 2 < ntiles) stage_slot(t & 1, t + 2, 1); }
+                // ---- softmax and PV of this unit
+                const bool lv = live(kb0 + 32 * slab, qt);
+                if (lv) pf = softmax(sbuf[u & 1], kb0 + 32 * slab, qt);
+                if constexpr (u == 0) {
+                    if constexpr (FA_QT == 2) asm volatile("s_waitcnt lgkmcnt(8)" : FA_V_REGS : : "memory");  // K of slab 1 may be in flight
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : FA_V_REGS : : "memory");
+                }
+                if constexpr (u == FA_QT && u != NU - 2) asm volatile("s_waitcnt lgkmcnt(0)" : FA_V_REGS : : "memory");
+                if (lv) pv_mfma(pf, qt);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+    }
+#endif  // PV one unit late
+#else
     if (ntiles > 0) {
         static_assert(FA_QT == 2, "the unit schedule below is written for two query tiles per wave");
         f32x4_t sa[2], sb[2];  // S of the unit being softmaxed / of the next unit
@@ -480,6 +635,7 @@ __global__ __launch_bounds__(FA_NT, 2) void prefill_attn_kernel(
         }
 #endif
     }
+#endif
 #undef FA_READ_K
 #undef FA_READ_V
 #undef FA_K_REGS
