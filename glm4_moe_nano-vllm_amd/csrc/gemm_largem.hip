@@ -155,7 +155,8 @@ constexpr int LM_LEAN = 1, LM_WIDEST = 2, LM_NOSTORE = 4, LM_DMA2 = 8, LM_DMA4 =
               LM_NT = 128, LM_EPIORD = 256, LM_NOPRIO = 512, LM_LOADPRIO = 1024,  // issue-priority studies
               LM_DEEP = 2048,  // 5-stage ring (all 160 KiB of LDS): one more K tile of prefetch distance
               LM_PH8 = 4096,   // CfgC: BK = 64, two buffers, four 16-MFMA phases per K tile (needs LM_LEAN)
-              LM_P3X = 8192, LM_QW = 16384, LM_RPRE = 32768, LM_RFIRST = 65536, LM_MIR = 131072;  // schedules of that loop (described there)
+              LM_P3X = 8192, LM_QW = 16384, LM_RPRE = 32768, LM_RFIRST = 65536, LM_MIR = 131072,  // schedules of that loop (described there)
+              LM_PARK = 262144;  // part of the epilogue's stores deferred into the next tile's K loop through LDS
 //   LM_EPIORD the epilogue's global LOADS (per-row scales) are issued before the next tile's ring fill, so that waiting
 //             for them does not drain the fill; and the wait that opens a tile leaves the previous tile's stores in
 //             flight (vmcnt counts in issue order and the fill was issued before them) whenever their number is
@@ -196,7 +197,12 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
     // DMA instructions of a K tile issued from the MFMA phase (the rest from the load phase)
     constexpr int S2 = !LEAN ? 0 : (VAR & LM_DMA4) ? C::DPW : (VAR & LM_DMA2) ? C::DPW / 2 : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* sh = reinterpret_cast<int*>(smem + C::NSTAGE * C::STAGE - (C::ALIAS_SH ? 16 : 0));
+    // LM_PARK (quadrant-phase loop with 16-byte stores): the last PARK_N store instructions of a tile's epilogue go to the
+    // 32 KiB of LDS the two buffers leave free and leave for HBM one per K tile from the NEXT tile's K loop (right behind
+    // its phase-3 wait), while the store path is otherwise idle.  The tile search then borrows the tail of buffer 1.
+    constexpr bool PARK = C::PH8 && (VAR & LM_PARK) != 0 && (VAR & LM_WIDEST) != 0 && (VAR & LM_NOSTORE) == 0;
+    constexpr int PARK_N = 4;
+    int* sh = reinterpret_cast<int*>(smem + C::NSTAGE * C::STAGE - ((C::ALIAS_SH || PARK) ? 16 : 0));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wid & 3, wm = wid >> 2;
@@ -394,6 +400,19 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
     constexpr int LM_NOUT = MODE == GEMM_GATEUP ? 2 : 4;
     constexpr int LM_STORES_FULL = C::MT * ((VAR & LM_WIDEST) ? LM_NOUT / 2 : LM_NOUT);
     int pending_stores = 0;
+    bool park_pending = false;
+    int park_m0 = 0, park_mcnt = 0, park_ncolw = 0;
+    const unsigned park_addr = lds_addr(smem) + C::NSTAGE * C::STAGE + wid * (PARK_N * 1024) + lane * 16;
+    auto park_flush = [&](int j) {  // parked store j of the previous tile (same lane that parked it)
+        u32x4_t val;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(val) : "v"(park_addr + j * 1024) : "memory");
+        const int sidx = LM_STORES_FULL - PARK_N + j;
+        const int mt = sidx / (LM_NOUT / 2), t = (sidx % (LM_NOUT / 2)) * 2;
+        const int row = wm * (C::BM / 2) + 16 * mt + c;
+        const int n = park_ncolw + 16 * (t + (g4 & 1)) + 8 * (g4 >> 1);
+        if (row < park_mcnt && n < p.N)
+            *reinterpret_cast<u32x4_t*>(p.y + (int64_t)(park_m0 + row) * p.ldy + n) = val;
+    };
     if (!find_tile()) return;
     if constexpr ((VAR & LM_DESYNC) != 0) {
         for (int i = 0; i < (int)(blockIdx.x & 7) * (GLM_LM_DESYNC_CYCLES / 1024); ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 clocks
@@ -430,6 +449,8 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         if constexpr ((VAR & LM_EPIORD) != 0) {
             // pending_stores = store instructions this wave issued after the ring fill (0 when not known exactly)
             if (pending_stores == LM_STORES_FULL) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LM_STORES_FULL) : "memory");
+            else if (PARK && pending_stores == LM_STORES_FULL - PARK_N)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LM_STORES_FULL - PARK_N) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -534,6 +555,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         //           (vmcnt leaves the 6 younger pieces X(kt+1) 0-3, W(kt+2) 0,1 in flight), i.e. before barrier 8kt+6
         //           at the latest, and first read in load interval 4kt+3 (epoch >= 8kt+6).
         static_assert(!P3X && !QW, "LM_MIR is its own schedule");
+        static_assert(!PARK, "LM_PARK is wired into the plain quadrant loop only");
         auto ktile = [&](int kt, auto parc) {
             constexpr int PAR = decltype(parc)::value;
             using HA = std::integral_constant<int, 2 * PAR>;        // first W tile of the half that opens this K tile
@@ -607,6 +629,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         //           (retired by the lgkmcnt(0) before its closing barrier, epoch <= 8kt+6) and refilled from load
         //           interval 4kt+4 (epoch >= 8kt+8); W(kt) is last read in load interval 4kt as under LM_QW.
         static_assert(QW, "LM_RPRE is a schedule of the LM_QW quadrants");
+        static_assert(!PARK, "LM_PARK is wired into the plain quadrant loop only");
         auto pre_x = [&](unsigned so, auto m0c, auto xbc) {  // issue the reads, keep the MFMAs behind them
             rd_x(so, m0c, I2{}, xbc);
             __builtin_amdgcn_sched_barrier(0);
@@ -751,6 +774,10 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             }
             if (has2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C::W_DMA + (P3X ? 2 : 0)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (PARK) {
+                // behind the wait: the store is then older than every DMA piece the next counted waits leave in flight
+                if (park_pending && kt < PARK_N) park_flush(kt);
+            }
             close_load();
             if constexpr (QW) quad(I0{}, I4{}, I6{}, I2{}, I0{});
             else quad(I0{}, I2{}, I4{}, I4{}, I0{});
@@ -942,6 +969,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         constexpr int NOUT = MODE == GEMM_GATEUP ? 2 : 4;  // 16-column output tiles per wave
         const int ncol_w = MODE == GEMM_GATEUP ? ntile_c * 128 + wn * 32 : ntile_c * LM_BN + wn * 64;
         const bool scaled = MODE == GEMM_DOWN && grp_c < p.n_scaled;
+        const bool do_park = PARK && more && nk >= PARK_N;  // the next tile's K loop has a K tile for every parked store
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt) {
             const int row = wm * (C::BM / 2) + 16 * mt + c;
@@ -1011,6 +1039,14 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                     const u32x2_t a = __builtin_amdgcn_permlane16_swap(v[t][0], v[t + 1][0], false, false);
                     const u32x2_t b = __builtin_amdgcn_permlane16_swap(v[t][1], v[t + 1][1], false, false);
                     const int n = ncol_w + 16 * (t + (g4 & 1)) + 8 * (g4 >> 1);
+                    if constexpr (PARK) {
+                        const int sidx = mt * (NOUT / 2) + t / 2;
+                        if (do_park && sidx >= LM_STORES_FULL - PARK_N) {
+                            const u32x4_t o4 = u32x4_t{a[0], b[0], a[1], b[1]};
+                            asm volatile("ds_write_b128 %0, %1" ::"v"(park_addr + (sidx - (LM_STORES_FULL - PARK_N)) * 1024), "v"(o4) : "memory");
+                            continue;
+                        }
+                    }
                     if (row_ok && n < p.N) {
                         const u32x4_t o4 = u32x4_t{a[0], b[0], a[1], b[1]};
                         if constexpr ((VAR & LM_NT) != 0) __builtin_nontemporal_store(o4, reinterpret_cast<u32x4_t*>(yrow + n));
@@ -1029,7 +1065,13 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             // exact only when every store instruction of the wave ran: all rows and columns of the tile exist
             const bool full = mcnt_c == C::BM && ncol_w + (MODE == GEMM_GATEUP ? 32 : 64) <= p.N && !NOSTORE &&
                               !((VAR & LM_LDSEPI) != 0 && NOUT == 4);
-            pending_stores = full ? LM_STORES_FULL : 0;
+            pending_stores = full ? LM_STORES_FULL - (do_park ? PARK_N : 0) : 0;
+        }
+        if constexpr (PARK) {
+            park_pending = do_park;
+            park_m0 = m0_c;
+            park_mcnt = mcnt_c;
+            park_ncolw = ncol_w;
         }
         LM_TS(6);  // 5: epilogue
 #if GLM_LM_STAMP
@@ -1065,7 +1107,8 @@ int launch_largem_cfg(const GemmParams& p, hipStream_t st) {
     if (total <= 0) return GLM_OK;
     GLM_CHECK_ARG(total < (1ll << 31), GLM_ERR_UNSUPPORTED, "gemm_largem: grid too large");
     auto kern = gemm_largem_kernel<MODE, C, VAR>;
-    GLM_SET_MAX_LDS(kern, C::LDS, "gemm_largem");
+    constexpr int LDS_BYTES = (C::PH8 && (VAR & LM_PARK) != 0) ? 160 * 1024 : C::LDS;
+    GLM_SET_MAX_LDS(kern, LDS_BYTES, "gemm_largem");
     // one workgroup per CU (the ring takes most of the LDS), a multiple of 8 so that every XCD gets the same count
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -1081,7 +1124,7 @@ int launch_largem_cfg(const GemmParams& p, hipStream_t st) {
     if (nwg < 8) nwg = 8;
     const int64_t need = (total + 7) / 8 * 8;
     if (nwg > need) nwg = need;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), C::LDS, st, p, n_tiles, (int)total, LM_BAND);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p, n_tiles, (int)total, LM_BAND);
     GLM_CHECK_LAUNCH("gemm_largem");
     return GLM_OK;
 }
@@ -1135,6 +1178,7 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
         GLM_LM_CASE(87043);  // ... with the LOAD interval at priority 1
 #if GLM_LM_STUDY >= 2
         GLM_LM_CASE(135171); // quadrant phases, mirrored quadrant order, reads 8/4/8/4 (no gain: profiles/r02)
+        GLM_LM_CASE(348931); // 86787 with LM_PARK (bit-identical, 1.5-2.5 % slower: profiles/r02/largem_ab_ph8_park.json)
 #endif
 #if GLM_LM_STUDY >= 2  // measured and not kept (profiles/r02/largem_ab_*.json)
         GLM_LM_CASE(1);

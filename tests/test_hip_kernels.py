@@ -612,7 +612,7 @@ def test_gemm_bf16_large_m(ops, M, N, K, bias):
     assert_close_bf16(out, O.linear(x, w, b), 1, 0.05, atol=2 ** -9, what=f"gemm(large) {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("K", [64, 128, 192, 320])
+@pytest.mark.parametrize("K", [64, 128, 192, 320, 512])
 def test_gemm_large_m_quadrant_loop_equals_plain_loop(ops, K):
     """The default large-M loop (256x256x64 tiles on two LDS buffers, operand slots refilled as soon as their own last
     fragment read retired; csrc/gemm_largem.hip LM_PH8) against variant 0 of the same kernel (4-stage ring, 256x256x32),
