@@ -658,6 +658,51 @@ def test_gemm_large_m_quadrant_loop_equals_plain_loop(ops, K):
     assert_close_bf16(got[2], O.linear(xp, wp, bias), 1, 0.05, atol=2 ** -9, what=f"plain K={K}")
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_gemm_large_m_quadrant_loop_random_shapes(ops, seed):
+    """Random ragged groupings (empty groups, single-row groups, partial row blocks and column tiles), random K in whole
+    64-wide tiles: default loop == variant 0, bit for bit, three launches each (a late DMA would show as a rare wrong tile)."""
+    lib = ops.load_library()
+    g = torch.Generator().manual_seed(1000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    K = 64 * ri(1, 9)
+    I = 8 * ri(3, 40)
+    N2 = 8 * ri(5, 70)
+    E = ri(1, 6)
+    counts = [ri(0, 700) if ri(0, 4) else 0 for _ in range(E + 1)]
+    counts[ri(0, E)] += 256 * (E + 1)           # keeps the average at >= 256 rows per group: the 256-row configuration
+    R = sum(counts)
+    offs = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32)
+    T = ri(50, 900)
+    tok = torch.randint(0, T, (R,), generator=g, dtype=torch.int32)
+    x = rnd(T, K, seed=seed + 1)
+    w13 = rnd(E + 1, 2 * I, K, seed=seed + 2, scale=K ** -0.5)
+    scale = (torch.rand(R, generator=g) + 0.1).to(BF)
+    act_in = rnd(R, K, seed=seed + 3)
+    w2 = rnd(E + 1, N2, K, seed=seed + 4, scale=K ** -0.5)
+
+    def run():
+        a = ops.grouped_gemm_gateup_silu(dev(x), dev(w13), dev(offs), dev(tok), R)
+        y = ops.grouped_gemm_down(dev(act_in), dev(w2), dev(offs), dev(scale), E)
+        torch.cuda.synchronize()
+        return a.cpu(), y.cpu()
+
+    old = lib.glm_debug_largem_variant(0)
+    try:
+        ref = run()
+        lib.glm_debug_largem_variant(-1)
+        for _ in range(3):
+            got = run()
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), \
+                f"quadrant loop differs from variant 0 (K={K} I={I} N={N2} counts={counts})"
+    finally:
+        lib.glm_debug_largem_variant(old)
+    e = max(range(E + 1), key=lambda i: counts[i])
+    rows = slice(int(offs[e]), int(offs[e + 1]))
+    a_ref = O.silu_and_mul(O.linear(x[tok[rows].long()], w13[e]))
+    assert_close_bf16(ref[0][rows], a_ref, 3, 0.06, atol=1e-3, what=f"act, random shapes seed {seed}")
+
+
 @pytest.mark.parametrize("T,E,k,H,I", [(600, 4, 2, 256, 128), (1024, 8, 2, 128, 352), (300, 2, 1, 512, 64)])
 def test_moe_block_large_t(ops, T, E, k, H, I):
     x = rnd(T, H, seed=91)

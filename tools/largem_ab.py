@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--tokens", type=int, default=16384)
     ap.add_argument("--band", type=int, default=0, help="row blocks per L2 band (0: the library default)")
+    ap.add_argument("--stress", type=int, default=0,
+                    help="race screen: this many extra launches of every storing variant, each compared bit for bit with variant 0")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "largem_ab.json"))
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(",")]
@@ -66,6 +68,22 @@ def main():
         torch.cuda.synchronize()
         parity[v] = bool(torch.equal(a, act0)) and bool(torch.equal(y, y0))
         print(f"variant {v}: bit-identical to variant 0: {parity[v]}", flush=True)
+    stress = {}
+    if args.stress > 0:
+        # a sync-structure edit must be screened for races over many runs (cdna_hip_programming.md, 8-phase template):
+        # a DMA that lands late or a slot refilled early shows as a rare wrong tile, so every launch is compared in full
+        for v in variants:
+            if v & NOSTORE or v == 0:
+                continue
+            setvar(v)
+            bad = 0
+            for i in range(args.stress):
+                a = ops.grouped_gemm_gateup_silu(x, w13, offs, tok, R)
+                y = ops.grouped_gemm_down(act0, w2, offs, scale, E)
+                if not (torch.equal(a, act0) and torch.equal(y, y0)):
+                    bad += 1
+            stress[v] = {"launches": args.stress, "mismatching_launches": bad}
+            print(f"variant {v}: {args.stress} stress launches, {bad} differ from variant 0", flush=True)
     # warm the clocks on MFMA-bound work, then interleaved rounds
     setvar(0)
     for _ in range(5):
@@ -86,7 +104,7 @@ def main():
                 torch.cuda.synchronize()
                 times[name][v].append(a.elapsed_time(b) / args.iters * 1e3)
     setvar(-1)
-    res = {"tokens": T, "rows": R, "band": args.band, "parity_vs_variant0": parity, "kernels": {}}
+    res = {"tokens": T, "rows": R, "band": args.band, "parity_vs_variant0": parity, "stress": stress, "kernels": {}}
     for name in fns:
         res["kernels"][name] = {}
         for v in variants:
@@ -98,7 +116,7 @@ def main():
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
         json.dump(res, f, indent=1)
-    if not all(parity.values()):
+    if not all(parity.values()) or any(r["mismatching_launches"] for r in stress.values()):
         sys.exit("PARITY FAILURE between variants")
 
 
