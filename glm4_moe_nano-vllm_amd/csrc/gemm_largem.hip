@@ -73,7 +73,7 @@ struct LmCfg {
     // the 16 bytes of the tile search normally follow the ring; a ring that takes the CU's whole LDS (5 x 32 KiB) lends
     // them the tail of its LAST slot, which no DMA targets between the end of a tile's K loop and the next tile's start
     static constexpr bool ALIAS_SH = NSTAGE * STAGE + 16 > 160 * 1024;
-    static constexpr int LDS = ALIAS_SH ? NSTAGE * STAGE : NSTAGE * STAGE + 16;
+    static constexpr int LDS = ALIAS_SH ? NSTAGE * STAGE : NSTAGE * STAGE + 16 + 64 * 16;  // + tile search + tile table
     static constexpr int DIST = NSTAGE - 1;        // prefetch distance in tiles
     static constexpr int NF = KS * (4 + MT);       // fragment registers (u32x4) per tile
     // source-chunk permutation that makes the 16-row ds_read_b128 fragment reads conflict free
@@ -188,10 +188,57 @@ __device__ __forceinline__ void dma_wait_leave(int tiles) {
     else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * DPW) : "memory");  // 5-stage ring: three tiles stay in flight
 }
 
+// glm_locate_block for ANY wave of the workgroup, result in (uniform) registers: (group, first row, rows) of row-block
+// combo `target`, group -1 if there is none.
+__device__ __forceinline__ void lm_locate_wave(const int32_t* __restrict__ offs, int G, int64_t R, int MB, int target, int lane,
+                                               int& g, int& m0, int& cnt) {
+    g = -1;
+    m0 = 0;
+    cnt = 0;
+    if (offs == nullptr) {
+        const int64_t r0 = (int64_t)target * MB;
+        if (r0 < R) {
+            g = 0;
+            m0 = (int)r0;
+            cnt = (int)((R - r0) < MB ? (R - r0) : MB);
+        }
+        return;
+    }
+    int base = 0;
+    for (int b = 0; b < G; b += 64) {
+        const int gi = b + lane;
+        int lo = 0, c = 0;
+        if (gi < G) {
+            lo = offs[gi];
+            c = offs[gi + 1] - lo;
+        }
+        const int nt = (c + MB - 1) / MB;
+        int incl = nt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        const int excl = incl - nt;
+        const bool hit = target >= base + excl && target < base + incl;
+        const unsigned long long m = __ballot(hit);
+        if (m != 0) {
+            const int src = __ffsll((long long)m) - 1;
+            const int r0 = lo + (target - base - excl) * MB;
+            g = __shfl(gi, src, 64);
+            m0 = __shfl(r0, src, 64);
+            cnt = __shfl((lo + c - r0) < MB ? (lo + c - r0) : MB, src, 64);
+            return;
+        }
+        base += __shfl(incl, 63, 64);
+        if (base > target) break;  // uniform
+    }
+}
+
 // Persistent: one workgroup per CU walks its XCD's contiguous run of tiles with a stride of (workgroups per XCD).
 // Between two tiles the next tile's first ring stages are put in flight BEFORE the finished tile's epilogue, so the
 // ring-fill latency and the workgroup relaunch (~6 % of a 256x256x1408 tile) hide behind the epilogue's stores.
-template <int MODE, class C, int VAR>
+template <int MODE, class C, int VAR, bool WSCALE>
 __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, int n_tiles, int total_tiles, int LM_BAND) {
     constexpr bool LEAN = (VAR & LM_LEAN) != 0;
     // DMA instructions of a K tile issued from the MFMA phase (the rest from the load phase)
@@ -223,25 +270,60 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
 
     // tile state: *_c = tile being computed / stored, plain = tile whose operands are being staged
     int grp = -1, m0 = 0, mcnt = 0, ntile = 0;
+    // Tile table: the (group, first row, rows, n-tile) of this workgroup's first TAB_N tile positions, found ONCE at
+    // kernel start by the 8 waves in parallel (a search per tile switch cost ~1.9k cycles of a 80k-cycle down tile: two
+    // workgroup barriers and a dependent chain of L2 round trips) and read back with one LDS load per switch.
+    constexpr bool TAB = !C::ALIAS_SH && !PARK;
+    constexpr int TAB_N = 64;
+    const unsigned tab_addr = lds_addr(smem) + C::NSTAGE * C::STAGE + 16;
+    const int pos0 = pos;
+    if constexpr (TAB) {
+        for (int i = wid; i < TAB_N && pos0 + i * pstep < chunk_len; i += 8) {
+            const int bid = chunk_base + pos0 + i * pstep;
+            const int band = bid / (LM_BAND * n_tiles);
+            const int rem = bid % (LM_BAND * n_tiles);
+            int g_, a_, b_;
+            lm_locate_wave(p.offs, p.G, p.R, C::BM, band * LM_BAND + rem % LM_BAND, lane, g_, a_, b_);
+            if (lane == 0) {
+                const u32x4_t e = {(unsigned)g_, (unsigned)a_, (unsigned)b_, (unsigned)(rem / LM_BAND)};
+                asm volatile("ds_write_b128 %0, %1" ::"v"(tab_addr + i * 16), "v"(e) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    int ti = 0;  // index of `pos` in this workgroup's position list
     // next valid tile at or after `pos` (uniform); leaves pos on it
     auto find_tile = [&]() -> bool {
         while (pos < chunk_len) {
-            const int bid = chunk_base + pos;
-            const int band = bid / (LM_BAND * n_tiles);
-            const int rem = bid % (LM_BAND * n_tiles);
-            const int combo = band * LM_BAND + rem % LM_BAND;
-            glm_locate_block(p.offs, p.G, p.R, C::BM, combo, sh);
-            __syncthreads();
-            const int g_ = sh[0], a_ = sh[1], b_ = sh[2];
-            __syncthreads();  // sh is rewritten by the next search step
+            int g_, a_, b_, nt_;
+            if (TAB && ti < TAB_N) {
+                u32x4_t e;
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(tab_addr + ti * 16) : "memory");
+                g_ = __builtin_amdgcn_readfirstlane((int)e[0]);
+                a_ = __builtin_amdgcn_readfirstlane((int)e[1]);
+                b_ = __builtin_amdgcn_readfirstlane((int)e[2]);
+                nt_ = __builtin_amdgcn_readfirstlane((int)e[3]);
+            } else {
+                const int bid = chunk_base + pos;
+                const int band = bid / (LM_BAND * n_tiles);
+                const int rem = bid % (LM_BAND * n_tiles);
+                const int combo = band * LM_BAND + rem % LM_BAND;
+                glm_locate_block(p.offs, p.G, p.R, C::BM, combo, sh);
+                __syncthreads();
+                g_ = sh[0], a_ = sh[1], b_ = sh[2];
+                nt_ = rem / LM_BAND;
+                __syncthreads();  // sh is rewritten by the next search step
+            }
             if (g_ >= 0) {
                 grp = g_;
                 m0 = a_;
                 mcnt = b_;
-                ntile = rem / LM_BAND;
+                ntile = nt_;
                 return true;
             }
             pos += pstep;
+            ++ti;
         }
         return false;
     };
@@ -955,6 +1037,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         // ---- next tile: every wave is past its last LDS read, so the ring can be refilled right away ----
         LM_TS(2);  // 1: K loop
         pos += pstep;
+        ++ti;
         const bool more = find_tile();
         LM_TS(3);  // 2: tile search
         if (more) {
@@ -986,7 +1069,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                 for (int r = 0; r < 4; ++r) {
                     if (MODE == GEMM_GATEUP) {
                         float ga = acc[t][mt][r], ua = acc[t + 2][mt][r];
-                        if (p.wscale) {  // weights expanded from fp8: per-row scale on the fp32 accumulators (uniform branch)
+                        if constexpr (WSCALE) {  // weights expanded from fp8: per-row scale on the fp32 accumulators (uniform branch)
                             const float* ws = p.wscale + (int64_t)grp_c * p.wscale_gstride;
                             const int n1 = min(ncol_w + 16 * t + 4 * g4 + r, p.N - 1);
                             ga *= ws[n1];
@@ -995,7 +1078,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                         o[r] = rbf(glm_silu(rbf(ga))) * rbf(ua);
                     } else {
                         float a = acc[t][mt][r];
-                        if (p.wscale) a *= p.wscale[(int64_t)grp_c * p.wscale_gstride + min(ncol_w + 16 * t + 4 * g4 + r, p.N - 1)];
+                        if constexpr (WSCALE) a *= p.wscale[(int64_t)grp_c * p.wscale_gstride + min(ncol_w + 16 * t + 4 * g4 + r, p.N - 1)];
                         if (MODE == GEMM_PLAIN && p.bias) a += bf2f(p.bias[min(ncol_w + 16 * t + 4 * g4 + r, p.N - 1)]);
                         if (scaled) a = rbf(a) * sc;
                         o[r] = a;
@@ -1106,7 +1189,9 @@ int launch_largem_cfg(const GemmParams& p, hipStream_t st) {
     const int64_t total = (combos + LM_BAND - 1) / LM_BAND * LM_BAND * n_tiles;
     if (total <= 0) return GLM_OK;
     GLM_CHECK_ARG(total < (1ll << 31), GLM_ERR_UNSUPPORTED, "gemm_largem: grid too large");
-    auto kern = gemm_largem_kernel<MODE, C, VAR>;
+    // the per-row scale of fp8-expanded weights is its own instantiation: as a run-time test it sat inside the epilogue's
+    // element loop (a branch per accumulator register)
+    auto kern = p.wscale ? gemm_largem_kernel<MODE, C, VAR, true> : gemm_largem_kernel<MODE, C, VAR, false>;
     constexpr int LDS_BYTES = (C::PH8 && (VAR & LM_PARK) != 0) ? 160 * 1024 : C::LDS;
     GLM_SET_MAX_LDS(kern, LDS_BYTES, "gemm_largem");
     // one workgroup per CU (the ring takes most of the LDS), a multiple of 8 so that every XCD gets the same count
