@@ -1229,7 +1229,9 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
     // 256-row blocks pay off once a group fills most of one; smaller groups keep the 128-row tile
     const int ch = cfg_choice();
     const int64_t avg_rows = p.R / (p.G > 0 ? p.G : 1);
-    const bool use_b = ch == 2 || (ch == 0 && avg_rows >= 192);
+    // ... and a projection onto <= 128 columns (the router logits at prefill: N = E = 64) is one column tile however the rows
+    // are cut, so its parallelism is its row-block count: 128-row blocks (75.8 -> 55.1 us at T = 16384)
+    const bool use_b = ch == 2 || (ch == 0 && avg_rows >= 192 && !(MODE == GEMM_PLAIN && p.offs == nullptr && p.N <= 128));
     // the lean load phase addresses x and the group's weights through 32-bit buffer offsets and has no K tail path
     // default (tools/largem_ab.py, one process, T = 16384): the quadrant-phase loop with 4 x 2-tile quadrants and the
     // fragment reads of a load interval issued before its DMA, no priority flips (86531: +1 % over 86019), epilogue

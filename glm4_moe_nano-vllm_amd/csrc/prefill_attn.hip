@@ -473,7 +473,6 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
         if (lv_prev) pv_mfma(pf_prev, FA_QT - 1);
     }
 #else
-        constexpr int NU = 2 * FA_QT;
         for (int t = 0; t < ntiles; ++t) {
             const int kb0 = t * FA_BK;
             const bool more = t + 1 < ntiles;
