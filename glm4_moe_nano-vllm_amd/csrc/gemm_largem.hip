@@ -45,7 +45,7 @@ constexpr int LM_BN = 256;    // weight rows per tile (MFMA row axis); 4 waves x
 #define GLM_LM_DEFAULT_VAR -1  // < 0: per mode (launch_largem); a value: that variant for every mode
 #endif
 #ifndef GLM_LM_STUDY
-#define GLM_LM_STUDY 1  // also build the timing-study variants (no-store epilogue)
+#define GLM_LM_STUDY 0  // 1: also build the measured loop variants + glm_debug_largem_* (build.py --variant _study GLM_LM_STUDY=1)
 #endif
 #ifndef GLM_LM_SCHED
 #define GLM_LM_SCHED 0  // 0: two barriers per K tile with waves 4-7 one barrier behind; 1: one barrier per K tile
@@ -1171,13 +1171,10 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
 int g_largem_variant = -1;  // < 0: the default for the shape
 
 // GLM_LARGEM_VARIANT=<bits> makes a variant the process default (A/B runs of whole test suites)
+// (read at every launch, so a test can switch between variant 0 and the product loop inside one process)
 int env_variant() {
-    static int v = -2;
-    if (v == -2) {
-        const char* e = getenv("GLM_LARGEM_VARIANT");
-        v = e ? atoi(e) : -1;
-    }
-    return v;
+    const char* e = getenv("GLM_LARGEM_VARIANT");
+    return e && *e ? atoi(e) : -1;
 }
 
 template <int MODE, class C, int VAR>
@@ -1252,6 +1249,8 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
         } else                                                                                                 \
             return use_b ? launch_largem_cfg<MODE, LmCfgB, V>(p, st) : launch_largem_cfg<MODE, LmCfgA, V>(p, st)
     switch (var) {
+        GLM_LM_CASE(86787);  // THE product loop: quadrant phases (LM_QW | LM_RFIRST | LM_NOPRIO) with LM_EPIORD
+#if GLM_LM_STUDY  // the steps that led there (profiles/r02/largem_ab_*.json); study builds only
         GLM_LM_CASE(3);
         GLM_LM_CASE(4099);  // lean + wide + quadrant phases on two 64-KiB buffers (CfgC)
         GLM_LM_CASE(12291); // ... with the DMA of phase 0 moved to phase 3
@@ -1261,8 +1260,8 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
         GLM_LM_CASE(77827); // ... with LM_P3X
         GLM_LM_CASE(86019); // ... with LM_QW
         GLM_LM_CASE(86531);  // LM_QW | LM_RFIRST without the MFMA-interval priority
-        GLM_LM_CASE(86787);  // ... with LM_EPIORD (scale loads above the ring fill, counted wait that leaves the stores in flight)
         GLM_LM_CASE(87043);  // ... with the LOAD interval at priority 1
+#endif
 #if GLM_LM_STUDY >= 2
         GLM_LM_CASE(135171); // quadrant phases, mirrored quadrant order, reads 8/4/8/4 (no gain: profiles/r02)
         GLM_LM_CASE(348931); // 86787 with LM_PARK (bit-identical, 1.5-2.5 % slower: profiles/r02/largem_ab_ph8_park.json)
@@ -1307,6 +1306,7 @@ int glm_launch_gemm_largem(int mode, const GemmParams& p, hipStream_t st) {
     return launch_largem<GEMM_PLAIN>(p, st);
 }
 
+#if GLM_LM_STUDY  // study builds only (build.py --variant _study GLM_LM_STUDY=1): not part of include/glm4moe_hip.h
 // sweeps: row blocks per L2 band for the next launches (>= 1); returns the previous value
 extern "C" int glm_debug_largem_band(int b) {
     const int old = g_largem_band;
@@ -1320,6 +1320,7 @@ extern "C" int glm_debug_largem_variant(int v) {
     g_largem_variant = v;
     return old;
 }
+#endif
 
 #if GLM_LM_STAMP
 // timing study only: per-segment cycle sums of the last tile workgroup 8 ran (waves 0 and 4), [2][8]; [7] = K tiles

@@ -22,8 +22,6 @@ _lib = None
 _SIGNATURES = {
     "glm_abi_version": (c_int, []),
     "glm_last_error": (c_char_p, []),
-    "glm_debug_largem_variant": (c_int, [c_int]),
-    "glm_debug_largem_band": (c_int, [c_int]),
     "glm_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "glm_add_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                 c_float, c_void_p]),

@@ -316,14 +316,6 @@ int glm_allreduce_oneshot(const void* in, void* out, void* const* peer_bufs, voi
                           int64_t n, int64_t n_max, unsigned epoch, void* local_counter, void* status,
                           glm_stream_t stream);
 
-/* Tuning studies only (tools/largem_ab.py): kernel variant of the LDS-tiled large-M GEMM for the next launches of this
- * process — a bit set of lean load phase (1), 16-byte epilogue stores (2), … (csrc/gemm_largem.hip); < 0 restores the
- * default.  Every variant that stores results is bit-identical to variant 0.  Returns the previous value.          */
-int glm_debug_largem_variant(int variant);
-/* Same purpose: row blocks per L2 band of that kernel's tile order (>= 1; the tile order never changes a result).
- * Returns the previous value.                                                                                       */
-int glm_debug_largem_band(int band);
-
 #ifdef __cplusplus
 }
 #endif

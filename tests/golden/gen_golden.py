@@ -253,6 +253,36 @@ def main():
                 slot_mapping=slots, k_cache_in=kc_in, v_cache_in=vc_in, out=out, res=res,
                 k_rows=kc.view(-1, 256)[slots.long()], v_rows=vc.view(-1, 256)[slots.long()],
                 cos_sin=layer.self_attn.rotary_emb.cos_sin_cache), vars(cfg) | dict(lens=lens))
+        # ---------------- router: exact ties ON the k-th / (k+1)-th boundary (r03) ----------------
+        # Own generator and own file: the nine fixtures above stay byte-identical.  Gate rows come in identical
+        # triples with one correction bias per triple, so every score of the reference comes three times; with k = 8
+        # the sorted scores are a a a b b b c c | c ...: on EVERY row the 8th and the 9th score are exactly equal and
+        # torch.topk (moe.py:39) has to pick two of three equal candidates.  The experts left over (E mod 3) carry a
+        # bias of -10 and are never candidates.  The triples are scattered over the expert ids by a fixed permutation.
+        gen2 = torch.Generator().manual_seed(4321)
+        tens, meta = {}, {}
+        for tag, (E, kk, Hh, Tt, rsf) in {"e64k8": (64, 8, 128, 24, 1.0), "e128k8": (128, 8, 256, 24, 2.5)}.items():
+            cfg = _cfg(hidden_size=Hh, n_routed_experts=E, num_experts_per_tok=kk, routed_scaling_factor=rsf)
+            gate = GlmMoeSelectTopk(cfg)
+            ng = E // 3
+            base = (torch.randn(ng, Hh, generator=gen2) / Hh ** 0.5).to(bf)
+            gbias = torch.rand(ng, generator=gen2) * 0.2 - 0.1
+            perm = torch.randperm(E, generator=gen2)
+            wfull = (torch.randn(E, Hh, generator=gen2) / Hh ** 0.5).to(bf)
+            bfull = torch.full((E,), -10.0)
+            group = torch.full((E,), -1, dtype=torch.int64)
+            for j in range(3 * ng):
+                wfull[perm[j]] = base[j // 3]
+                bfull[perm[j]] = gbias[j // 3]
+                group[perm[j]] = j // 3
+            gate.weight.data.copy_(wfull)
+            gate.e_score_correction_bias.copy_(bfull)
+            xr = torch.randn(Tt, Hh, generator=gen2).to(bf)
+            idx, w = gate(xr)
+            tens |= {f"{tag}.x": xr, f"{tag}.gate_w": gate.weight, f"{tag}.bias": gate.e_score_correction_bias,
+                     f"{tag}.idx": idx, f"{tag}.w": w, f"{tag}.group": group}
+            meta[tag] = dict(E=E, k=kk, H=Hh, T=Tt, rsf=rsf)
+        _save("router_ties", tens, meta)
     print("done")
 
 

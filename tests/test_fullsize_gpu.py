@@ -84,7 +84,8 @@ def _layer_decode_case(ops, tag: str, B: int, ctx: int, layer_idx: int, pad_rows
         _, _, choice = O.router_scores(tr["h_router"], lw.gate_w, lw.gate_bias)
         rows, moved = F.same_set_rows(idx_f[:B].cpu(), tr["idx"], router_margin(choice, gate.top_k), 0.016)
         routing["rows_moved_by_upstream_rounding"] = len(moved)
-        assert len(moved) <= max(1, B // 4), f"{tag}: {len(moved)}/{B} rows routed differently"
+        # observed (profiles/r02/parity_fullsize.jsonl): 0/32, 0/1, 0/64, 1/256 — each a near-tie (margin <= 0.016, checked above)
+        assert len(moved) <= max(1, -(-2 * B // 100)), f"{tag}: {len(moved)}/{B} rows routed differently"
 
     st_out = F.err_stats(out[:B], ref_out, rows)
     st_out32 = F.err_stats(out[:B], out32, rows)
@@ -243,7 +244,8 @@ def _layer_prefill_case(ops, tag: str, seqlens, layer_idx: int, **cfg_over):
         _, _, choice = O.router_scores(tr["h_router"], lw.gate_w, lw.gate_bias)
         rows, moved = F.same_set_rows(idx_f.cpu(), tr["idx"], router_margin(choice, gate.top_k), 0.016)
         routing["rows_moved_by_upstream_rounding"] = len(moved)
-        assert len(moved) <= max(1, T // 8), f"{tag}: {len(moved)}/{T} rows routed differently"
+        # observed: 9/1024 near-ties moved by upstream rounding
+        assert len(moved) <= max(1, -(-2 * T // 100)), f"{tag}: {len(moved)}/{T} rows routed differently"
     st_out = F.err_stats(out, ref_out, rows)
     st_out32 = F.err_stats(out, out32, rows)
     st_ref32 = F.err_stats(ref_out, out32, rows)

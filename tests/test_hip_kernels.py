@@ -29,6 +29,25 @@ def dev(t):
     return t.cuda() if t is not None else None
 
 
+import contextlib
+import os
+
+
+@contextlib.contextmanager
+def largem_variant(v: int):
+    """Loop variant of the large-M GEMM for the launches inside the block (GLM_LARGEM_VARIANT is read at every launch;
+    0 = the plain loop every other variant must equal bit for bit)."""
+    old = os.environ.get("GLM_LARGEM_VARIANT")
+    os.environ["GLM_LARGEM_VARIANT"] = str(v)
+    try:
+        yield
+    finally:
+        if old is None:
+            del os.environ["GLM_LARGEM_VARIANT"]
+        else:
+            os.environ["GLM_LARGEM_VARIANT"] = old
+
+
 def rnd(*shape, seed=0, scale=1.0, dtype=BF):
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(*shape, generator=g) * scale).to(dtype)
@@ -311,6 +330,42 @@ def test_router_golden(ops):
             # rounding boundary (fp32 summation order; _check_router proves that is the cause)
             _check_router(ops, x, gw, bias, m["k"], m["rsf"], f"router golden {tag}",
                           allow_flip_rows=1.0 / x.shape[0])
+
+
+def test_router_boundary_ties_golden(ops):
+    """Exact ties ON the top-k boundary, every row (tests/golden/router_ties, minted from the reference): gate rows come
+    in identical triples, so the 8th and 9th score are equal and two of three equal candidates must be taken.  torch.topk
+    leaves that pick unspecified; the product takes the lowest expert ids.  Checked per row: (1) the selected score
+    multiset and the weight multiset equal the reference's (rows whose bf16 logits equal the oracle's: all but rounding
+    flips of the fp32 summation order, and triples flip together), (2) the set is exactly {everything above the boundary
+    value} + {the lowest ids among the equals}, from the product's own logits — on the rank-computation path (E = 64),
+    the arg-max-round path (E = 128), and on glm_router_select fed with the same logits."""
+    t, meta = load_golden("router_ties")
+    for tag, m in meta.items():
+        x, gw, bias, k, E = t[f"{tag}.x"], t[f"{tag}.gate_w"], t[f"{tag}.bias"], m["k"], m["E"]
+        idx, w, logits = ops.router_topk(dev(x), dev(gw), dev(bias), k, m["rsf"], return_logits=True)
+        idx2, w2 = ops.router_select(logits, dev(bias), k, m["rsf"])
+        assert torch.equal(idx2, idx) and torch.equal(w2, w), f"{tag}: glm_router_select differs from the fused kernel"
+        idx, w, logits = idx.cpu(), w.cpu(), logits.cpu()
+        rlogits, _, rchoice = O.router_scores(x, gw, bias)
+        choice = logits.sigmoid() + bias.unsqueeze(0)      # R2, R3 on the product's own logits
+        n_boundary = n_same_logits = 0
+        for r in range(x.shape[0]):
+            kth = torch.sort(choice[r], descending=True)[0][k - 1]
+            above = [e for e in range(E) if choice[r, e] > kth]
+            tied = [e for e in range(E) if choice[r, e] == kth]
+            n_boundary += len(tied) > k - len(above)
+            want = sorted(above + tied[: k - len(above)])
+            assert idx[r].tolist() == want, f"{tag} row {r}: {idx[r].tolist()} != lowest-id pick {want}"
+            if torch.equal(logits[r], rlogits[r]):
+                n_same_logits += 1
+                got = torch.sort(rchoice[r][idx[r]])[0]
+                exp = torch.sort(rchoice[r][t[f"{tag}.idx"][r]])[0]
+                assert torch.equal(got, exp), f"{tag} row {r}: selected score multiset differs from the reference's"
+                assert torch.equal(torch.sort(w[r].float())[0], torch.sort(t[f"{tag}.w"][r].float())[0]), \
+                    f"{tag} row {r}: weight multiset differs from the reference's"
+        assert n_boundary == x.shape[0], f"{tag}: only {n_boundary} rows tie on the boundary"
+        assert n_same_logits >= x.shape[0] - 2, f"{tag}: {x.shape[0] - n_same_logits} rows with logit rounding flips"
 
 
 def test_router_air_shape(ops):
@@ -640,13 +695,9 @@ def test_gemm_large_m_quadrant_loop_equals_plain_loop(ops, K):
         torch.cuda.synchronize()
         return a.cpu(), y.cpu(), z.cpu()
 
-    old = lib.glm_debug_largem_variant(0)
-    try:
+    with largem_variant(0):
         ref = run()
-        lib.glm_debug_largem_variant(-1)
-        got = run()
-    finally:
-        lib.glm_debug_largem_variant(old)
+    got = run()
     for name, a, b in zip(("gate|up", "down", "plain"), got, ref):
         assert torch.equal(a, b), f"{name}: quadrant loop differs from variant 0 at K={K}"
     # and variant 0 itself against the oracle on two groups
@@ -687,16 +738,12 @@ def test_gemm_large_m_quadrant_loop_random_shapes(ops, seed):
         torch.cuda.synchronize()
         return a.cpu(), y.cpu()
 
-    old = lib.glm_debug_largem_variant(0)
-    try:
+    with largem_variant(0):
         ref = run()
-        lib.glm_debug_largem_variant(-1)
-        for _ in range(3):
-            got = run()
-            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), \
-                f"quadrant loop differs from variant 0 (K={K} I={I} N={N2} counts={counts})"
-    finally:
-        lib.glm_debug_largem_variant(old)
+    for _ in range(3):
+        got = run()
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), \
+            f"quadrant loop differs from variant 0 (K={K} I={I} N={N2} counts={counts})"
     e = max(range(E + 1), key=lambda i: counts[i])
     rows = slice(int(offs[e]), int(offs[e + 1]))
     a_ref = O.silu_and_mul(O.linear(x[tok[rows].long()], w13[e]))

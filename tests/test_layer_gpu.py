@@ -40,7 +40,8 @@ def _routing_rows(layer, t, cfg, captured, h_router_ref):
             keep.append(r)
         else:
             assert float(margin[r]) <= 0.016, f"row {r}: expert set differs with margin {float(margin[r]):.4g}"
-    assert len(keep) >= (2 * got.shape[0]) // 3, "too many routing differences"
+    n = got.shape[0]
+    assert n - len(keep) <= max(1, -(-5 * n // 100)), f"too many routing differences: {n - len(keep)}/{n}"
     return torch.tensor(keep, dtype=torch.long)
 
 
@@ -216,5 +217,5 @@ def test_model_final_norm_variants(tmp_path, without_residual):
     assert not torch.allclose(ref.float(), other.float(), atol=0.05), "the two variants must differ for this to test anything"
     got_idx = captured["idx"].cpu()
     rows = torch.tensor([r for r in range(N) if set(got_idx[r].tolist()) == set(traces[1]["idx"][r].tolist())])
-    assert len(rows) >= (2 * N) // 3, "too many routing differences"
+    assert N - len(rows) <= max(1, -(-5 * N // 100)), f"too many routing differences: {N - len(rows)}/{N}"
     _mixed(h, ref, f"final hidden (without_residual={without_residual})", rows)

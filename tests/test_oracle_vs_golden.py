@@ -37,6 +37,20 @@ def test_router():
         eq(w, t[f"{tag}.w"], f"router[{tag}] w")
 
 
+def test_router_boundary_ties():
+    """r03 fixture: every row has the k-th and the (k+1)-th score exactly equal (gate rows in identical triples); the
+    oracle must reproduce the reference's pick among the equals (same torch.topk) and the weights bit for bit."""
+    t, meta = load_golden("router_ties")
+    for tag, m in meta.items():
+        x, gw, b = t[f"{tag}.x"], t[f"{tag}.gate_w"], t[f"{tag}.bias"]
+        idx, w = O.router(x, gw, b, m["k"], m["rsf"])
+        eq(idx, t[f"{tag}.idx"], f"router_ties[{tag}] idx")
+        eq(w, t[f"{tag}.w"], f"router_ties[{tag}] w")
+        _, _, choice = O.router_scores(x, gw, b)
+        srt = torch.sort(choice, dim=1, descending=True)[0]
+        assert bool((srt[:, m["k"] - 1] == srt[:, m["k"]]).all()), "fixture lost its boundary ties"
+
+
 def test_mlp_and_moe():
     t, _ = load_golden("mlp")
     eq(O.mlp(t["x"], t["w13"], t["w2"]), t["y"], "mlp")

@@ -3,8 +3,16 @@ glm_debug_largem_band switches it between launches of one process."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "glm4_moe_nano-vllm_amd"))
+# the variant / band switches exist only in the study build of the library:
+#     python glm4_moe_nano-vllm_amd/build.py --variant _study GLM_LM_STUDY=1
+_STUDY = os.path.join(ROOT, "glm4_moe_nano-vllm_amd", "lib", "libglm4moe_hip_study.so")
+os.environ.setdefault("GLM4MOE_HIP_LIB", _STUDY)
+if not os.path.exists(os.environ["GLM4MOE_HIP_LIB"]):
+    raise SystemExit("build the study library first: python glm4_moe_nano-vllm_amd/build.py --variant _study GLM_LM_STUDY=1")
+import ctypes
 from nanovllm import hip_ops as ops
 lib = ops.load_library()
+lib.glm_debug_largem_band.restype, lib.glm_debug_largem_band.argtypes = ctypes.c_int, [ctypes.c_int]
 T = 16384
 shapes = {"qkv": (14336, 4096), "o_proj": (4096, 12288)}
 g = torch.Generator(device="cuda").manual_seed(3)

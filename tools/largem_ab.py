@@ -5,6 +5,7 @@ between launches.  Every variant that stores its results is compared bit for bit
     python tools/largem_ab.py [--variants 0,1,2,3,4,7] [--rounds 4] [--iters 5] [--out gpurun_out/largem_ab.json]
 """
 import argparse
+import ctypes
 import json
 import os
 import statistics
@@ -13,6 +14,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "glm4_moe_nano-vllm_amd"))
+# the variant / band switches exist only in the study build of the library:
+#     python glm4_moe_nano-vllm_amd/build.py --variant _study GLM_LM_STUDY=1
+_STUDY = os.path.join(ROOT, "glm4_moe_nano-vllm_amd", "lib", "libglm4moe_hip_study.so")
+os.environ.setdefault("GLM4MOE_HIP_LIB", _STUDY)
+if not os.path.exists(os.environ["GLM4MOE_HIP_LIB"]):
+    raise SystemExit("build the study library first: python glm4_moe_nano-vllm_amd/build.py --variant _study GLM_LM_STUDY=1")
 import torch
 
 from nanovllm import hip_ops as ops
@@ -34,7 +41,8 @@ def main():
     variants = [int(v) for v in args.variants.split(",")]
     lib = ops.load_library()
     setvar = lib.glm_debug_largem_variant
-    setvar.restype = int
+    setvar.restype, setvar.argtypes = ctypes.c_int, [ctypes.c_int]
+    lib.glm_debug_largem_band.restype, lib.glm_debug_largem_band.argtypes = ctypes.c_int, [ctypes.c_int]
     if args.band > 0:
         lib.glm_debug_largem_band(args.band)
 
