@@ -78,6 +78,22 @@ def probe_capture(world: int, timeout_s: int = 180) -> tuple[bool, str | None]:
     return capture_probe.probe(timeout_s=timeout_s, argv=[sys.executable, os.path.abspath(__file__), "--probe-capture"])
 
 
+def spawn_ranks(n: int) -> int:
+    """Launcher side of `python bench.py --gpus N` without a distributed environment: N ranks of this same file as
+    children of `python -m torch.distributed.run` (one rank per GPU, rendezvous on 127.0.0.1, a free port)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,6 +106,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c2", action="store_true", help="skip the second measured entry (BASELINE config 2: bs=1 ctx=1024)")
     ap.add_argument("--kernel-iters", type=int, default=20)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the `extra` measurements after the timed region (fp8 experts, prefill step / attention / dense GEMMs)")
     ap.add_argument("--emulate-tp", type=int, default=1,
                     help="kernel-shape study on ONE GPU: run the per-rank shapes of TP=N (heads, kv heads, expert/MLP "
                          "intermediate size and vocabulary divided by N) without any collective; not a benchmark result")
@@ -107,12 +125,16 @@ def main():
     if args.probe_capture:
         sys.exit(probe_capture_child())
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  It has not touched a GPU (importing
+        # torch does not) and never will: it starts the N ranks as fresh children through torch.distributed.run, lets
+        # rank 0's JSON line through on the inherited stdout and exits with the children's code.
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # rehearsal knobs for a one-GPU box (never set by the driver): all ranks on cuda:0 over gloo exercises this
     # file's N>1 control flow (sharded build, collectives' order, rank-0-only sections) without RCCL
     backend = os.environ.get("GLM_BENCH_BACKEND", "nccl")
@@ -277,9 +299,23 @@ def main():
         extra["c2_bs1_ctx1024"] = measure_c2(model, cfg, kv, dev, L, bs, args.fp8_experts)
         set_context(False, slot_mapping=slot_mapping, context_lens=context_lens, block_tables=block_tables)
 
+    # ---- the other numbers README.md / DESIGN.md quote, on the driver line (rank 0, TP=1, after the timed region):
+    # prefill attention, dense prefill projections, a whole prefill step over 3 layers ----
+    if rank == 0 and world == 1 and not args.no_extras and args.emulate_tp == 1 and not args.fp8_experts:
+        extra.update(measure_extras(model, cfg, hip_ops, dev, L))
+        set_context(False, slot_mapping=slot_mapping, context_lens=context_lens, block_tables=block_tables)
+
     cpu_base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_base = cpu_baseline(model, cfg, kv, block_tables, context_lens, positions, slot_mapping, B, L)
+
+    # ---- fp8 (e4m3, weight-only) experts on the same model, re-quantised in place: LAST, because the bf16 expert
+    # stacks are released by the quantisation ----
+    if rank == 0 and world == 1 and not args.no_extras and args.emulate_tp == 1 and not args.fp8_experts:
+        try:
+            extra["fp8_experts"] = measure_fp8(model, cfg, hip_ops, step, B, ctx, L, args, dev)
+        except Exception as e:  # noqa: BLE001 - an extra never takes the headline line down
+            extra["fp8_experts"] = {"error": repr(e)[:200]}
 
     if rank == 0:
         attach_pmc_traffic(kernels)
@@ -402,7 +438,7 @@ def attach_pmc_traffic(kernels: dict) -> None:
                 rec["traffic_note"] = f"{rel} was taken with other kernel sources ({src['kernel_source_digest']} != {now})"
 
 
-def measure_kernels(model, cfg, ops, B, ctx, world, iters, dev):
+def measure_kernels(model, cfg, ops, B, ctx, world, iters, dev, only_experts=False):
     """Time each hot kernel alone on the current stream with events, rotating over the layers'
     weights so every launch streams cold data (each launch touches >> the 256 MiB L3)."""
     import torch
@@ -434,10 +470,13 @@ def measure_kernels(model, cfg, ops, B, ctx, world, iters, dev):
     res = {}
     # routing shared by the expert GEMMs (router output differs per layer; use layer i's gate)
     prep = []
+    fp8 = getattr(cfg, "expert_weight_dtype", None) == "fp8_e4m3"
     for l in layers:
         idx, w = l.mlp.gate(x)
         offs, tok, scale, pos = ops.moe_align(idx, w, E, True)
-        w13, w2 = l.mlp._stacked()
+        if fp8 and l.mlp._fp8 is None:
+            l.mlp.quantize_experts_fp8()
+        w13, w2 = (None, None) if fp8 else l.mlp._stacked()  # fp8 experts have released their bf16 stacks
         prep.append((offs, tok, scale, pos, w13, w2))
     torch.cuda.synchronize()
     R = B * k + B
@@ -452,12 +491,7 @@ def measure_kernels(model, cfg, ops, B, ctx, world, iters, dev):
 
     acts = [None] * nl
 
-    fp8 = getattr(cfg, "expert_weight_dtype", None) == "fp8_e4m3"
     wb = 1 if fp8 else 2  # bytes per expert weight element
-    if fp8:
-        for l in layers:
-            if l.mlp._fp8 is None:
-                l.mlp.quantize_experts_fp8()
 
     def f_gateup(i):
         p = prep[i % nl]
@@ -480,6 +514,8 @@ def measure_kernels(model, cfg, ops, B, ctx, world, iters, dev):
             ops.grouped_gemm_down(a, p[5], p[0], p[2], E)
     m, md = timeit(f_down, iters)
     rec("grouped_gemm_down", m, md, touched * H * I * wb, f"touched groups x H*I*{wb} B of down weights")
+    if only_experts:
+        return res
 
     attn_layers = [l.self_attn for l in model.model.layers]
     q = torch.randn(B, nh, hd, device=dev).to(torch.bfloat16)
@@ -567,6 +603,116 @@ def measure_prefill_gemm(layer, cfg, ops, world, dev, T=16384, iters=10, warm=5)
     return out
 
 
+def _events_us(fn, iters, warm):
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+def measure_extras(model, cfg, ops, dev, L, T=16384, S=4096):
+    """Prefill side of the same config (T = 16384 = max_num_batched_tokens, 4 prompts x 4096), each entry with its
+    steps, time and FLOP model; random data.  Runs after every decode measurement (the prefill step overwrites KV rows)."""
+    import torch
+    from nanovllm.utils.context import set_context
+    out = {}
+    nh, nkv, hd, H = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.hidden_size
+    Bp = T // S
+    mfma = lambda fl, us: {"ms": round(us / 1e3, 4), "tflops": round(fl / (us * 1e-6) / 1e12, 1),
+                           "mfma_frac": round(fl / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+    try:
+        # (1) varlen causal attention, 4 x 4096 tokens, 96 / 8 heads x 128
+        q = torch.randn(T, nh, hd, device=dev).to(torch.bfloat16)
+        k = torch.randn(T, nkv, hd, device=dev).to(torch.bfloat16)
+        v = torch.randn(T, nkv, hd, device=dev).to(torch.bfloat16)
+        cu = torch.arange(0, T + 1, S, dtype=torch.int32, device=dev)
+        us = _events_us(lambda: ops.varlen_attn_prefill(q, k, v, cu, cu, S, hd ** -0.5), 8, 3)
+        fl = 4.0 * Bp * nh * S * S * hd / 2
+        out["prefill_attn_4x4096"] = dict(mfma(fl, us), steps=8, flops=fl,
+                                          flops_model="4*B*nh*S^2*hd/2: QK^T and PV over the causal half, B=4 S=4096 nh=96 hd=128")
+        del q, k, v
+        # (2) dense prefill projections on the large-M loop
+        a0 = model.model.layers[1].self_attn
+        x = torch.randn(T, H, device=dev).to(torch.bfloat16)
+        us = _events_us(lambda: ops.gemm_bf16(x, a0.qkv_proj.weight.data, a0.qkv_proj.bias.data), 8, 3)
+        fl = 2.0 * T * (nh + 2 * nkv) * hd * H
+        out["dense_prefill_qkv"] = dict(mfma(fl, us), steps=8, flops=fl, flops_model="2*T*N*K, T=16384 N=14336 K=4096 (+bias)")
+        xo = torch.randn(T, nh * hd, device=dev).to(torch.bfloat16)
+        us = _events_us(lambda: ops.gemm_bf16(xo, a0.o_proj.weight.data, None), 8, 3)
+        fl = 2.0 * T * H * nh * hd
+        out["dense_prefill_o"] = dict(mfma(fl, us), steps=8, flops=fl, flops_model="2*T*N*K, T=16384 N=4096 K=12288")
+        del x, xo
+        # (3) a whole prefill step of 16384 tokens through 3 MoE decoder layers (eager; K/V written to the paged cache)
+        layers = [l for l in model.model.layers if hasattr(l.mlp, "gate")][:3]
+        h0 = torch.randn(T, H, device=dev).to(torch.bfloat16)
+        pos = torch.arange(S, device=dev).repeat(Bp)
+        slots = torch.arange(T, dtype=torch.int32, device=dev)
+        set_context(True, cu, cu, S, S, slots, None, None)
+
+        @torch.inference_mode()
+        def pstep():
+            hs, res = h0, None
+            for l in layers:
+                hs, res = l(pos, hs, res, defer_combine=True)
+            return hs
+
+        us = _events_us(pstep, 3, 1)
+        E, kk, I = cfg.n_routed_experts, cfg.num_experts_per_tok, cfg.moe_intermediate_size
+        fl_layer = (2.0 * T * (nh + 2 * nkv) * hd * H + 4.0 * Bp * nh * S * S * hd / 2 + 2.0 * T * H * nh * hd
+                    + 2.0 * T * E * H + 2.0 * T * (kk + 1) * 3 * I * H)
+        ms_layer = us / 1e3 / len(layers)
+        out["prefill_step_16k"] = {"ms_per_layer": round(ms_layer, 4), "layers": len(layers), "steps": 3, "tokens": T,
+                                   "tokens_per_s_at_L": round(T / (ms_layer * 1e-3 * L), 1), "L": L,
+                                   "tflops": round(fl_layer / (ms_layer * 1e-3) / 1e12, 1),
+                                   "mfma_frac": round(fl_layer / (ms_layer * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                   "flops_per_layer": fl_layer,
+                                   "flops_model": "QKV + causal attention + O + router + (k+1) experts x 3*I*H per token, per MoE layer"}
+    except torch.OutOfMemoryError as e:
+        out["extras_error"] = repr(e)[:160]
+    torch.cuda.empty_cache()
+    return out
+
+
+def measure_fp8(model, cfg, ops, step, B, ctx, L, args, dev):
+    """BASELINE config 5 flavour on the headline model: experts re-quantised to OCP fp8 e4m3 (weight-only, per-row
+    scale; the bf16 stacks are released), the same decode step captured again, plus the two expert launches alone."""
+    import torch
+    for l in model.model.layers:
+        if hasattr(l.mlp, "gate"):
+            l.mlp.expert_weight_dtype = "fp8_e4m3"
+            l.mlp.quantize_experts_fp8()
+    cfg.expert_weight_dtype = "fp8_e4m3"
+    torch.cuda.empty_cache()
+    step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    steps = max(5, args.steps // 2)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ks = measure_kernels(model, cfg, ops, B, ctx, 1, max(6, args.kernel_iters // 2), dev, only_experts=True)
+    return {"workload": f"same model and decode step (bs={B} ctx={ctx} L={L}), experts as fp8 e4m3 weight-only",
+            "tokens_per_s": round(B / dt, 2), "ms_per_step": round(dt * 1e3, 4), "ms_per_layer": round(dt * 1e3 / L, 4),
+            "steps": steps, "hip_graph": True,
+            "gateup_hbm_frac": ks["grouped_gemm_gateup_silu"]["frac"], "gateup_us": ks["grouped_gemm_gateup_silu"]["kernel_us_mean"],
+            "down_hbm_frac": ks["grouped_gemm_down"]["frac"], "down_us": ks["grouped_gemm_down"]["kernel_us_mean"],
+            "bytes_model": "touched groups x 3*I*H x 1 B of fp8 weights per launch pair"}
+
+
 def cpu_baseline(model, cfg, kv, block_tables, context_lens, positions, slot_mapping, B, L):
     """The reference's eager algorithm (CPU oracle) for ONE MoE decoder layer at this workload's
     shapes, timed on the host cores; tokens/s is extrapolated to L layers."""
@@ -581,14 +727,8 @@ def cpu_baseline(model, cfg, kv, block_tables, context_lens, positions, slot_map
     layer = next(l for l in model.model.layers if hasattr(l.mlp, "gate"))
     li = list(model.model.layers).index(layer)
     cpu = lambda t: t.detach().to("cpu")
-    w13, w2 = layer.mlp._stacked()
-    E = cfg.n_routed_experts
-    lw = O.LayerWeights(
-        input_ln=cpu(layer.input_layernorm.weight), post_ln=cpu(layer.post_attention_layernorm.weight),
-        qkv_w=cpu(layer.self_attn.qkv_proj.weight), qkv_b=cpu(layer.self_attn.qkv_proj.bias),
-        o_w=cpu(layer.self_attn.o_proj.weight), gate_w=cpu(layer.mlp.gate.weight),
-        gate_bias=cpu(layer.mlp.gate.e_score_correction_bias), w13=cpu(w13[:E]), w2=cpu(w2[:E]),
-        shared_w13=cpu(w13[E]), shared_w2=cpu(w2[E]))
+    from oracle import from_product
+    lw = from_product.layer_weights_from_module(layer)  # the bytes the GPU ran on (fp8 experts: the quantised bytes + scales)
     kc, vc = cpu(kv[0, li]), cpu(kv[1, li])
     c = {k: getattr(cfg, k) for k in ("num_attention_heads", "num_key_value_heads", "head_dim", "rms_norm_eps",
                                       "num_experts_per_tok", "routed_scaling_factor", "partial_rotary_factor")}

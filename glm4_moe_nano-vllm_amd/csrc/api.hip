@@ -2,6 +2,7 @@
 // weight-streaming small-M kernels and the LDS-tiled large-M kernels).
 #include "gemm_internal.h"
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -12,7 +13,7 @@ void glm_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int glm_abi_version(void) { return 7; }
+extern "C" int glm_abi_version(void) { return 8; }
 extern "C" const char* glm_last_error(void) { return g_err; }
 
 namespace {
@@ -36,6 +37,12 @@ int fp8w_large(int mode, GemmParams p, int rows, int cols, void* scratch, size_t
     return glm_launch_gemm_largem(mode, p, st);  // p.wscale stays set
 }
 
+// GLM4MOE_TINYM=0 keeps the small-M kernels at T <= 2 (A/B runs and the bit-identity tests of the fused launches)
+bool tinym_enabled() {
+    const char* e = getenv("GLM4MOE_TINYM");
+    return !(e && e[0] == '0');
+}
+
 int dispatch(int mode, const GemmParams& p, hipStream_t st) {
     if (p.R <= 0) return GLM_OK;
     const int64_t avg = p.R / (p.G > 0 ? p.G : 1);
@@ -56,7 +63,31 @@ extern "C" int glm_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t 
     p.bias = (const bf16_t*)bias;
     p.y = (bf16_t*)y; p.ldy = ldy;
     p.R = M; p.N = N; p.K = K; p.G = 1;
+    if (M >= 1 && M <= glm_tinym_max_rows() && tinym_enabled()) {  // single-sequence decode: the GEMV body
+        const int rc = glm_launch_gemm_tinym(GEMM_PLAIN, p, (int)M, glm_s(stream));
+        if (rc != GLM_ERR_UNSUPPORTED) return rc;
+    }
     return dispatch(GEMM_PLAIN, p, glm_s(stream));
+}
+
+extern "C" int glm_gemm_bf16_combine_norm(const void* y_prev, int64_t ld_yprev, const int32_t* pair_pos, int64_t T, int k,
+                                          int64_t shared_base, const void* residual_in, const void* norm_weight,
+                                          float eps, void* residual_out, void* x_out, const void* w, int64_t ldw,
+                                          const void* bias, void* y, int64_t ldy, int N, int H, glm_stream_t stream) {
+    GLM_CHECK_ARG(y_prev && pair_pos && residual_in && norm_weight && residual_out && w && y, GLM_ERR_INVALID,
+                  "glm_gemm_bf16_combine_norm: null pointer");
+    GLM_CHECK_ARG(T >= 1 && k > 0 && N > 0 && H > 0 && ld_yprev >= H && ldw >= H && ldy >= N, GLM_ERR_INVALID,
+                  "glm_gemm_bf16_combine_norm: bad shape T=%ld k=%d N=%d H=%d", (long)T, k, N, H);
+    GLM_CHECK_ARG(T <= glm_tinym_max_rows(), GLM_ERR_UNSUPPORTED, "glm_gemm_bf16_combine_norm: T=%ld > %d rows", (long)T,
+                  glm_tinym_max_rows());
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.w = (const bf16_t*)w; p.ldw = ldw;
+    p.bias = (const bf16_t*)bias;
+    p.y = (bf16_t*)y; p.ldy = ldy;
+    p.R = T; p.N = N; p.K = H; p.G = 1;
+    return glm_launch_gemm_tinym_combine_norm(p, y_prev, ld_yprev, pair_pos, k, shared_base, residual_in, norm_weight,
+                                              residual_out, x_out, eps, glm_s(stream));
 }
 
 extern "C" int glm_gemm_bf16_partial_slices(int K, int want) { return glm_smallm_partial_slices(K, want); }
@@ -97,6 +128,27 @@ extern "C" int glm_grouped_gemm_gateup_silu(const void* x, int64_t ldx, const vo
     return dispatch(GEMM_GATEUP, p, glm_s(stream));
 }
 
+extern "C" int glm_grouped_gemm_gateup_silu_fewtok(const void* x, int64_t ldx, int64_t T, const void* w13,
+                                                   int64_t w13_group_stride, int64_t w13_row_stride,
+                                                   const int32_t* expert_offsets, const int32_t* sorted_token,
+                                                   void* act, int64_t R, int H, int I, int G, glm_stream_t stream) {
+    GLM_CHECK_ARG(T >= 1 && expert_offsets != nullptr, GLM_ERR_INVALID, "glm_grouped_gemm_gateup_silu_fewtok: bad arguments");
+    if (T <= glm_tinym_max_rows() && tinym_enabled() && x && w13 && act && R > 0 && H > 0 && I > 0 && G >= 1 && ldx >= H &&
+        w13_row_stride >= H) {
+        GemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.x = (const bf16_t*)x; p.ldx = ldx;
+        p.w = (const bf16_t*)w13; p.w_gstride = w13_group_stride; p.ldw = w13_row_stride;
+        p.offs = expert_offsets; p.src = sorted_token;
+        p.y = (bf16_t*)act; p.ldy = I;
+        p.R = R; p.N = I; p.K = H; p.G = G;
+        const int rc = glm_launch_gemm_tinym(GEMM_GATEUP, p, (int)T, glm_s(stream));
+        if (rc != GLM_ERR_UNSUPPORTED) return rc;
+    }
+    return glm_grouped_gemm_gateup_silu(x, ldx, w13, w13_group_stride, w13_row_stride, expert_offsets, sorted_token, act, R,
+                                        H, I, G, stream);
+}
+
 extern "C" int glm_grouped_gemm_down(const void* act, const void* w2, int64_t w2_group_stride,
                                      int64_t w2_row_stride, const int32_t* expert_offsets,
                                      const void* sorted_scale, int n_scaled_groups, void* y,
@@ -118,6 +170,28 @@ extern "C" int glm_grouped_gemm_down(const void* act, const void* w2, int64_t w2
     p.y = (bf16_t*)y; p.ldy = ldy;
     p.R = R; p.N = H; p.K = I; p.G = G;
     return dispatch(GEMM_DOWN, p, glm_s(stream));
+}
+
+extern "C" int glm_grouped_gemm_down_fewtok(const void* act, int64_t T, const void* w2, int64_t w2_group_stride,
+                                            int64_t w2_row_stride, const int32_t* expert_offsets,
+                                            const void* sorted_scale, int n_scaled_groups, void* y, int64_t ldy,
+                                            int64_t R, int H, int I, int G, glm_stream_t stream) {
+    GLM_CHECK_ARG(T >= 1 && expert_offsets != nullptr, GLM_ERR_INVALID, "glm_grouped_gemm_down_fewtok: bad arguments");
+    if (T <= glm_tinym_max_rows() && tinym_enabled() && act && w2 && y && R > 0 && H > 0 && I > 0 && G >= 1 && ldy >= H &&
+        w2_row_stride >= I && (n_scaled_groups == 0 || sorted_scale != nullptr)) {
+        GemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.x = (const bf16_t*)act; p.ldx = I;
+        p.w = (const bf16_t*)w2; p.w_gstride = w2_group_stride; p.ldw = w2_row_stride;
+        p.offs = expert_offsets;
+        p.scale = (const bf16_t*)sorted_scale; p.n_scaled = n_scaled_groups;
+        p.y = (bf16_t*)y; p.ldy = ldy;
+        p.R = R; p.N = H; p.K = I; p.G = G;
+        const int rc = glm_launch_gemm_tinym(GEMM_DOWN, p, (int)T, glm_s(stream));
+        if (rc != GLM_ERR_UNSUPPORTED) return rc;
+    }
+    return glm_grouped_gemm_down(act, w2, w2_group_stride, w2_row_stride, expert_offsets, sorted_scale, n_scaled_groups, y,
+                                 ldy, R, H, I, G, stream);
 }
 
 extern "C" int glm_grouped_gemm_gateup_silu_fp8w(const void* x, int64_t ldx, const void* w13_q,

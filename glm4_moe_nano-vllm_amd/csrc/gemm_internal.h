@@ -36,6 +36,16 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st);
 // K-split partial sums (p.ksplit > 1, p.ypart): one fp32 [R,N] slab per K slice, no bias, no rounding
 int glm_launch_gemm_smallm_partial(const GemmParams& p, hipStream_t st);
 int glm_smallm_partial_slices(int K, int want);  // slices actually used for a requested count (whole 128-wide chunks)
+// single-sequence decode (gemm_tinym.hip): one or two token rows per weight matrix / per expert group, fp32 FMA GEMV with
+// a persistent workgroup per CU.  n_tokens: rows of x (grouped gate|up).  GLM_ERR_UNSUPPORTED = shape not covered (the
+// caller then takes the small-M kernels).
+int glm_tinym_max_rows();
+int glm_launch_gemm_tinym(int mode, const GemmParams& p, int n_tokens, hipStream_t st);
+// ... with the activation rows COMPUTED in the kernel: moe_combine(y_prev) + add-RMSNorm (the previous MoE block's combine
+// and this layer's input norm), p.x ignored; residual_out / x_out (optional) written by one workgroup
+int glm_launch_gemm_tinym_combine_norm(const GemmParams& p, const void* y_prev, int64_t ld_yprev, const int32_t* pair_pos,
+                                       int k, int64_t shared_base, const void* residual_in, const void* norm_w,
+                                       void* residual_out, void* x_out, float eps, hipStream_t st);
 // same, weights stored as OCP fp8 e4m3 (1 byte/element, ldw/w_gstride in elements) + per-row scale
 int glm_launch_gemm_smallm_fp8w(int mode, const GemmParams& p, hipStream_t st);
 // LDS-tiled MFMA kernels for many rows per group (prefill); p.wscale != nullptr: per-weight-row fp32 scale applied to

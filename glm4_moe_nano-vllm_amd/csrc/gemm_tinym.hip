@@ -1,0 +1,407 @@
+// gemm_tinym.hip — weight-streaming GEMV for ONE or TWO token rows per weight matrix: the greedy single-sequence decode of
+// BASELINE config 2 (bs = 1, and the bs = 2 graph bucket).  Same operators as gemm_smallm.hip (a5/a10 dense projections,
+// a12/a13 grouped expert gate|up + SiLU·mul and down), same rounding points, gfx950 only.
+//
+// Why a second body: with one token row the MFMA tile of gemm_smallm is 1/16 used and, worse, its workgroups are short
+// (a wave streams 16-32 weight rows of one 128-wide K chunk at a time through a 2-stage ring): at bs = 1 its launches
+// ran at 4.1-5.5 TB/s (profiles/r02/decode_c2_L46_kernel_stats.csv).  Here the arithmetic is plain fp32 FMA on the vector
+// ALU (8 FMAs per 16 weight bytes and token: 1/4 of the VALU rate the stream needs) and everything is arranged for
+// bytes in flight:
+//   * ONE persistent 512-thread workgroup per CU (256 of them); the weight rows are cut into tiles of 4 rows x all K,
+//     a workgroup owns a contiguous run of tiles, its 8 waves pull tiles from an LDS counter;
+//   * a wave streams a tile in units of 4 rows x SEGS x 1 KiB (lane l of a wave reads 16 B at k = 8 (64 s + l): every
+//     wave-instruction is one whole KiB of one row) with TWO units in registers: the loads of unit i+1 are issued before
+//     the FMAs of unit i, across tile boundaries, so 16-32 KiB per wave stay in flight from the first to the last byte;
+//   * the token rows live in LDS for the whole kernel (fragment read = one conflict-free ds_read_b128 per segment).
+// Optional prologue (PRO_COMBINE): the activation row is not loaded but COMPUTED by every workgroup — MoE combine of the
+// previous layer + the input add-RMSNorm (decode_layer.py:47-49 of the next layer) — behind the workgroup's first weight
+// loads, which removes the combine + norm launch of a T <= 2 decode layer.  Bit-identical to that launch: same code
+// (fused_rows.h), same 512-thread mapping.
+#include "gemm_internal.h"
+#include "fused_rows.h"
+#include <string.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int TM_NT = 512;
+constexpr int TM_NW = TM_NT / 64;
+constexpr int TM_RPW = 4;      // weight rows per tile
+constexpr int TM_MAXG = 320;   // groups a grouped launch may have (list of non-empty groups in LDS)
+
+#ifndef GLM_TM_NT_LOADS
+#define GLM_TM_NT_LOADS 1      // weight loads with the nt hint (read once, by one CU); 0 for A/B runs
+#endif
+
+__device__ __forceinline__ u32x4_t tm_wload(const void* p) {
+    typedef __attribute__((address_space(1))) const u32x4_t gvec_t;
+#if GLM_TM_NT_LOADS
+    return __builtin_nontemporal_load(reinterpret_cast<gvec_t*>((const __attribute__((address_space(1))) void*)p));
+#else
+    return *reinterpret_cast<gvec_t*>((const __attribute__((address_space(1))) void*)p);
+#endif
+}
+
+__device__ const u32x4_t g_tm_zero_page[4] = {};
+
+struct TinyParams {
+    GemmParams g;
+    int n_tokens;             // grouped gate|up: rows of x (= tokens) kept in LDS
+    // PRO_COMBINE: the activation rows are bf16(add_rmsnorm(moe_combine(y_prev), residual)) computed in the kernel
+    const bf16_t* pc_y;       // rows of the previous layer's grouped down projection
+    int64_t pc_ldy;
+    const int32_t* pc_pos;    // pair_pos [T, k]
+    int pc_k;
+    int64_t pc_shared_base;
+    const bf16_t* pc_res_in;  // [T, H]
+    const bf16_t* pc_norm_w;  // [H]
+    bf16_t* pc_res_out;       // [T, H]  (written by workgroup 0)
+    bf16_t* pc_x_out;         // [T, H] or nullptr: the normalised rows, for callers that want them (workgroup 0)
+    float pc_eps;
+};
+
+template <int M>
+__device__ __forceinline__ void tm_fma8(float (&acc)[M], const u32x4_t w, const u32x4_t (&x)[M]) {
+    float wf[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        wf[2 * q] = bflo(w[q]);
+        wf[2 * q + 1] = bfhi(w[q]);
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc[m] = __builtin_fmaf(wf[2 * q], bflo(x[m][q]), acc[m]);
+            acc[m] = __builtin_fmaf(wf[2 * q + 1], bfhi(x[m][q]), acc[m]);
+        }
+    }
+}
+
+// MODE as gemm_smallm; M = token rows per group block (1 or 2); SEGS = 1-KiB segments of a weight row per unit
+template <int MODE, int M, int SEGS, bool PRO>
+__global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) {
+    const GemmParams& p = tp.g;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int sh_grp[TM_MAXG];   // non-empty groups
+    __shared__ int sh_nact;
+    __shared__ int sh_next;           // next tile of this workgroup
+    __shared__ float sh_red[TM_NW];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = p.K;
+    constexpr int KU = SEGS * 512;                 // k elements per unit
+    const int nunits = (K + KU - 1) / KU;
+    const int Kp = nunits * KU;                    // padded row length in LDS (pad = zeros)
+    const int tpg = MODE == GEMM_GATEUP ? p.N / 2 : p.N / TM_RPW;  // tiles per group
+
+    // ---- non-empty groups (grouped modes) ----
+    int nact = 1;
+    if (p.offs != nullptr) {
+        if (wid == 0) {
+            int base = 0;
+            for (int b = 0; b < p.G; b += 64) {
+                const int gi = b + lane;
+                const bool on = gi < p.G && p.offs[gi + 1] > p.offs[gi];
+                const unsigned long long mask = __ballot(on);
+                if (on) sh_grp[base + __popcll(mask & ((1ull << lane) - 1))] = gi;
+                base += __popcll(mask);
+            }
+            if (lane == 0) sh_nact = base;
+        }
+        __syncthreads();
+        nact = sh_nact;
+    }
+    const int64_t total = (int64_t)nact * tpg;
+    const int tb = (int)(total * blockIdx.x / gridDim.x), te = (int)(total * (blockIdx.x + 1) / gridDim.x);
+    if (tid == 0) sh_next = tb + TM_NW;  // waves start with tiles tb + wid
+
+    // ---- per-tile set-up ----
+    struct Tile {
+        const char* wrow[TM_RPW];
+        int grp, ncol, m0, mcnt;
+    };
+    auto set_tile = [&](Tile& t, int tile) {
+        const int slot = tile / tpg, ti = tile - slot * tpg;
+        const int grp = p.offs ? sh_grp[slot] : 0;
+        t.grp = grp;
+        t.m0 = p.offs ? p.offs[grp] : 0;
+        t.mcnt = p.offs ? min(p.offs[grp + 1] - t.m0, M) : (int)min((int64_t)M, p.R);
+        const char* wg = reinterpret_cast<const char*>(p.w + (int64_t)grp * p.w_gstride);
+        if (MODE == GEMM_GATEUP) {  // rows: gate n, gate n+1, up n, up n+1
+            t.ncol = 2 * ti;
+#pragma unroll
+            for (int r = 0; r < TM_RPW; ++r) t.wrow[r] = wg + ((int64_t)((r >> 1) * p.N + t.ncol + (r & 1)) * p.ldw) * 2;
+        } else {
+            t.ncol = TM_RPW * ti;
+#pragma unroll
+            for (int r = 0; r < TM_RPW; ++r) t.wrow[r] = wg + ((int64_t)(t.ncol + r) * p.ldw) * 2;
+        }
+    };
+
+    u32x4_t wbuf[2][SEGS][TM_RPW];
+    const char* zero = reinterpret_cast<const char*>(g_tm_zero_page);
+    auto issue = [&](auto buf_tag, const Tile& t, int u) {
+        constexpr int B = decltype(buf_tag)::value;
+#pragma unroll
+        for (int s = 0; s < SEGS; ++s) {
+            const int k = u * KU + (s * 64 + lane) * 8;
+#pragma unroll
+            for (int r = 0; r < TM_RPW; ++r) wbuf[B][s][r] = tm_wload(k < K ? t.wrow[r] + (int64_t)k * 2 : zero);
+        }
+    };
+
+    // issue state runs one unit ahead of the compute state
+    Tile it, ct;
+    int i_tile = tb + wid, i_u = 0;
+    bool i_live = i_tile < te;
+    if (i_live) {
+        set_tile(it, i_tile);
+        issue(std::integral_constant<int, 0>{}, it, 0);
+    }
+    ct = it;
+    int c_tile = i_tile, c_u = 0;
+    bool c_live = i_live;
+    auto advance_issue = [&]() {  // next (tile, unit) of this wave's stream
+        if (++i_u == nunits) {
+            i_u = 0;
+            int nt = 0;
+            if (lane == 0) nt = __hip_atomic_fetch_add(&sh_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            i_tile = __builtin_amdgcn_readfirstlane(nt);
+            i_live = i_tile < te;
+            if (i_live) set_tile(it, i_tile);
+        }
+    };
+
+    // ---- activation rows into LDS: [rows][Kp] bf16, pad zeroed ----
+    //   PLAIN: rows 0..M-1 = x rows;  GATEUP: row t = token t (T = p.R / ... tokens, all of x);  DOWN: row r = act row r
+    const int xrows = MODE == GEMM_PLAIN ? M : (MODE == GEMM_GATEUP ? tp.n_tokens : (int)p.R);
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);
+    if (PRO) {
+        // combine of the previous MoE block + input add-RMSNorm, token by token, exactly the stand-alone launch's code;
+        // the first unit's weight loads are already in flight
+        for (int t = 0; t < M; ++t) {
+            if (t >= (int)p.R) break;
+            glm_combine_add_rmsnorm_row<1>(tp.pc_y, tp.pc_ldy, tp.pc_pos, tp.pc_k, tp.pc_shared_base, tp.pc_res_in,
+                                           tp.pc_norm_w, blockIdx.x == 0 ? tp.pc_x_out : nullptr,
+                                           blockIdx.x == 0 ? tp.pc_res_out : nullptr, xs + (int64_t)t * Kp, K, tp.pc_eps, t,
+                                           sh_red);
+            __syncthreads();  // sh_red and the position list are reused by the next token
+        }
+        for (int i = tid; i < M * (Kp - K) / 8; i += TM_NT) {
+            const int r = i / ((Kp - K) / 8), c = i % ((Kp - K) / 8);
+            reinterpret_cast<u32x4_t*>(xs + (int64_t)r * Kp + K)[c] = u32x4_t{0, 0, 0, 0};
+        }
+        for (int t = (int)p.R; t < M; ++t)  // a missing second row: zeros
+            for (int i = tid; i < Kp / 8; i += TM_NT) reinterpret_cast<u32x4_t*>(xs + (int64_t)t * Kp)[i] = u32x4_t{0, 0, 0, 0};
+    } else {
+        const int vpr = Kp / 8;
+        for (int i = tid; i < xrows * vpr; i += TM_NT) {
+            const int r = i / vpr, c = i - r * vpr;
+            u32x4_t v = {0, 0, 0, 0};
+            const int64_t srow = MODE == GEMM_PLAIN ? min((int64_t)r, p.R - 1) : r;
+            if (c * 8 < K) v = *reinterpret_cast<const u32x4_t*>(p.x + srow * p.ldx + c * 8);
+            reinterpret_cast<u32x4_t*>(xs)[i] = v;
+        }
+    }
+    __syncthreads();
+
+    float acc[TM_RPW][M];
+#pragma unroll
+    for (int r = 0; r < TM_RPW; ++r)
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
+
+    auto xrow_of = [&](const Tile& t, int m) -> const bf16_t* {
+        const int j = m < t.mcnt ? m : 0;  // a group with fewer rows than M: the extra column is computed and dropped
+        int row;
+        if (MODE == GEMM_PLAIN) row = j;
+        else if (MODE == GEMM_GATEUP) row = p.src ? p.src[t.m0 + j] : t.m0 + j;
+        else row = t.m0 + j;
+        return xs + (int64_t)row * Kp;
+    };
+
+    auto compute = [&](auto buf_tag, const Tile& t, int u, const bf16_t* const (&xr)[M]) {
+        constexpr int B = decltype(buf_tag)::value;
+#pragma unroll
+        for (int s = 0; s < SEGS; ++s) {
+            u32x4_t xv[M];
+#pragma unroll
+            for (int m = 0; m < M; ++m) xv[m] = *reinterpret_cast<const u32x4_t*>(xr[m] + u * KU + (s * 64 + lane) * 8);
+#pragma unroll
+            for (int r = 0; r < TM_RPW; ++r) tm_fma8<M>(acc[r], wbuf[B][s][r], xv);
+        }
+    };
+
+    auto finish = [&](const Tile& t) {
+        // cross-lane sums (every lane ends with the total), then the mode's epilogue from lane 0
+        float o[TM_RPW][M];
+#pragma unroll
+        for (int r = 0; r < TM_RPW; ++r)
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                o[r][m] = wave_sum(acc[r][m]);
+                acc[r][m] = 0.f;
+            }
+        if (lane != 0) return;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            if (m >= t.mcnt) continue;
+            const int64_t row = t.m0 + m;
+            if (MODE == GEMM_GATEUP) {
+                const float a0 = rbf(glm_silu(rbf(o[0][m]))) * rbf(o[2][m]);
+                const float a1 = rbf(glm_silu(rbf(o[1][m]))) * rbf(o[3][m]);
+                *reinterpret_cast<unsigned*>(p.y + row * p.ldy + t.ncol) = pack2bf(a0, a1);
+            } else {
+                float v[TM_RPW];
+                float sc = 1.0f;
+                const bool scaled = MODE == GEMM_DOWN && t.grp < p.n_scaled;
+                if (scaled) sc = bf2f(p.scale[row]);
+#pragma unroll
+                for (int r = 0; r < TM_RPW; ++r) {
+                    float a = o[r][m];
+                    if (MODE == GEMM_PLAIN && p.bias) a += bf2f(p.bias[t.ncol + r]);
+                    if (scaled) a = rbf(a) * sc;
+                    v[r] = a;
+                }
+                *reinterpret_cast<u32x2_t*>(p.y + row * p.ldy + t.ncol) = u32x2_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            }
+        }
+    };
+
+    // ---- the stream: units alternate between the two register buffers ----
+    const bf16_t* xr[M];
+    if (c_live) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) xr[m] = xrow_of(ct, m);
+    }
+    while (c_live) {
+        // buffer 0 holds (c_tile, c_u)
+        advance_issue();
+        if (i_live) issue(std::integral_constant<int, 1>{}, it, i_u);
+        compute(std::integral_constant<int, 0>{}, ct, c_u, xr);
+        if (++c_u == nunits) {
+            finish(ct);
+            c_u = 0;
+            c_tile = i_tile;
+            c_live = i_live;
+            ct = it;
+            if (c_live) {
+#pragma unroll
+                for (int m = 0; m < M; ++m) xr[m] = xrow_of(ct, m);
+            }
+        }
+        if (!c_live) break;
+        // buffer 1 holds (c_tile, c_u)
+        advance_issue();
+        if (i_live) issue(std::integral_constant<int, 0>{}, it, i_u);
+        compute(std::integral_constant<int, 1>{}, ct, c_u, xr);
+        if (++c_u == nunits) {
+            finish(ct);
+            c_u = 0;
+            c_tile = i_tile;
+            c_live = i_live;
+            ct = it;
+            if (c_live) {
+#pragma unroll
+                for (int m = 0; m < M; ++m) xr[m] = xrow_of(ct, m);
+            }
+        }
+    }
+}
+
+int n_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+
+template <int MODE, int M, int SEGS, bool PRO>
+int launch_tiny(const TinyParams& tp, int xrows, hipStream_t st) {
+    const GemmParams& p = tp.g;
+    constexpr int KU = SEGS * 512;
+    const int Kp = (p.K + KU - 1) / KU * KU;
+    // >= 84 KiB of LDS per workgroup: exactly one workgroup per CU, so the 256 of them cover the chip evenly
+    size_t lds = (size_t)xrows * Kp * 2;
+    if (lds < 84 * 1024) lds = 84 * 1024;
+    GLM_CHECK_ARG(lds <= 156 * 1024, GLM_ERR_UNSUPPORTED, "gemm_tinym: %d activation rows of %d do not fit the LDS", xrows, Kp);
+    auto kern = gemm_tinym_kernel<MODE, M, SEGS, PRO>;
+    GLM_SET_MAX_LDS(kern, 156 * 1024, "gemm_tinym");
+    const int64_t tiles = (int64_t)(p.offs ? p.G : 1) * (MODE == GEMM_GATEUP ? p.N / 2 : p.N / TM_RPW);
+    int nwg = n_cus();
+    if (tiles < nwg) nwg = (int)tiles;
+    if (nwg <= 0) return GLM_OK;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(TM_NT), lds, st, tp);
+    GLM_CHECK_LAUNCH("gemm_tinym");
+    return GLM_OK;
+}
+
+bool tiny_shape_ok(int mode, const GemmParams& p) {
+    if (p.K % 8 != 0 || p.ldx % 8 != 0 || p.ldw % 8 != 0 || !glm_aligned16(p.x) || !glm_aligned16(p.w)) return false;
+    if (mode == GEMM_GATEUP) return p.N % 2 == 0 && p.ldy % 2 == 0 && (((uintptr_t)p.y) & 3) == 0;
+    return p.N % TM_RPW == 0 && p.ldy % 4 == 0 && (((uintptr_t)p.y) & 7) == 0;
+}
+
+}  // namespace
+
+// rows per group block this body handles; grouped launches: every group has at most that many rows (T <= 2 tokens)
+int glm_tinym_max_rows() { return 2; }
+
+// n_tokens: grouped gate|up only — rows of x (the tokens) to keep in LDS
+int glm_launch_gemm_tinym(int mode, const GemmParams& p, int n_tokens, hipStream_t st) {
+    if (!tiny_shape_ok(mode, p) || (p.offs != nullptr && p.G > TM_MAXG)) {
+        glm_set_error("gemm_tinym: shape not covered (mode %d K=%d N=%d G=%d)", mode, p.K, p.N, p.G);
+        return GLM_ERR_UNSUPPORTED;
+    }
+    TinyParams tp;
+    memset(&tp, 0, sizeof(tp));
+    tp.g = p;
+    tp.n_tokens = n_tokens;
+    const int M = mode == GEMM_PLAIN ? (int)p.R : n_tokens;
+    GLM_CHECK_ARG(M >= 1 && M <= 2, GLM_ERR_UNSUPPORTED, "gemm_tinym: %d rows per block", M);
+    // units: 4 rows x 4 KiB for long rows (2 KiB with two token rows: registers); a short K (expert down projection, 1408) as ONE unit of 3 KiB rows
+    if (mode == GEMM_PLAIN) {
+        if (M == 1) return launch_tiny<GEMM_PLAIN, 1, 4, false>(tp, 1, st);
+        return launch_tiny<GEMM_PLAIN, 2, 2, false>(tp, 2, st);
+    }
+    if (mode == GEMM_GATEUP) {
+        if (M == 1) return launch_tiny<GEMM_GATEUP, 1, 4, false>(tp, n_tokens, st);
+        return launch_tiny<GEMM_GATEUP, 2, 2, false>(tp, n_tokens, st);
+    }
+    if (p.K <= 1536) {
+        if (M == 1) return launch_tiny<GEMM_DOWN, 1, 3, false>(tp, (int)p.R, st);
+        return launch_tiny<GEMM_DOWN, 2, 3, false>(tp, (int)p.R, st);
+    }
+    if (M == 1) return launch_tiny<GEMM_DOWN, 1, 4, false>(tp, (int)p.R, st);
+    return launch_tiny<GEMM_DOWN, 2, 2, false>(tp, (int)p.R, st);
+}
+
+// QKV projection (+bias) of T <= 2 rows whose input is computed in the kernel: moe_combine of the previous layer's expert
+// rows + add-RMSNorm with `residual_in` (see the file header).  p.x is ignored; p.K = H.
+int glm_launch_gemm_tinym_combine_norm(const GemmParams& p, const void* y_prev, int64_t ld_yprev, const int32_t* pair_pos,
+                                       int k, int64_t shared_base, const void* residual_in, const void* norm_w,
+                                       void* residual_out, void* x_out, float eps, hipStream_t st) {
+    GemmParams q = p;
+    q.x = (const bf16_t*)residual_in;  // any aligned pointer: the shape check wants one
+    q.ldx = p.K;
+    if (!tiny_shape_ok(GEMM_PLAIN, q) || p.K % 8 != 0 || p.K / 8 > TM_NT || p.R < 1 || p.R > 2 || k > GLM_COMBINE_MAX_K ||
+        ld_yprev % 8 != 0 || !glm_aligned16(y_prev) || !glm_aligned16(residual_in) || !glm_aligned16(norm_w) ||
+        !glm_aligned16(residual_out) || (x_out && !glm_aligned16(x_out))) {
+        glm_set_error("gemm_tinym(combine+norm): shape not covered (K=%d N=%d T=%ld k=%d)", p.K, p.N, (long)p.R, k);
+        return GLM_ERR_UNSUPPORTED;
+    }
+    TinyParams tp;
+    memset(&tp, 0, sizeof(tp));
+    tp.g = q;
+    tp.pc_y = (const bf16_t*)y_prev; tp.pc_ldy = ld_yprev; tp.pc_pos = pair_pos; tp.pc_k = k; tp.pc_shared_base = shared_base;
+    tp.pc_res_in = (const bf16_t*)residual_in; tp.pc_norm_w = (const bf16_t*)norm_w; tp.pc_res_out = (bf16_t*)residual_out;
+    tp.pc_x_out = (bf16_t*)x_out; tp.pc_eps = eps;
+    if (p.R == 1) return launch_tiny<GEMM_PLAIN, 1, 4, true>(tp, 1, st);
+    return launch_tiny<GEMM_PLAIN, 2, 2, true>(tp, 2, st);
+}

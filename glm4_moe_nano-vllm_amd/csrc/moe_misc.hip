@@ -5,6 +5,7 @@
 // Compiled with -ffp-contract=off: the rounding points below are the reference's
 // (SURVEY.md §8a R1–R7).
 #include "common.h"
+#include "fused_rows.h"
 #include <string.h>
 
 namespace {
@@ -186,7 +187,13 @@ template <int EPL>
 __device__ __forceinline__ void router_select_wave(const float* lg, const float* bias_l, unsigned* keys_scratch,
                                                    bf16_t* wl_scratch, int lane, int E, int k, float rsf, int64_t t,
                                                    int64_t* __restrict__ topk_idx, bf16_t* __restrict__ topk_w,
-                                                   bf16_t* __restrict__ logits_out, bool write_through) {
+                                                   bf16_t* __restrict__ logits_out, bool write_through,
+                                                   int32_t* a1_offs = nullptr, int32_t* a1_tok = nullptr,
+                                                   bf16_t* a1_scale = nullptr, int32_t* a1_pos = nullptr,
+                                                   int a1_shared = 0) {
+    // a1_*: single-token launch (T = 1) that also wants glm_moe_align's structure: with one token the bucketing IS the
+    // selection — sorted row j = the j-th selected expert (ascending id), so this wave writes expert_offsets /
+    // sorted_token / sorted_scale / pair_pos itself and the launch needs neither the global ticket nor the bucketing pass.
     // wave 0: R2..R7.  lane owns experts lane + 64*i.
     float sc[EPL], ch[EPL];
     bool sel[EPL];
@@ -289,8 +296,10 @@ __device__ __forceinline__ void router_select_wave(const float* lg, const float*
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
         const unsigned long long m = __ballot(sel[i]);
+        const int before = base + __popcll(m & ((1ull << lane) - 1ull));  // selected experts with a smaller id
+        if (a1_offs && lane + 64 * i < E) a1_offs[lane + 64 * i] = before;
         if (sel[i]) {
-            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            const int pos = before;
             if (pos < k) {
                 const bf16_t wv = f2bf(rbf(sc[i] / den) * rsf);  // R6 then R7
                 if (wt) {
@@ -300,11 +309,24 @@ __device__ __forceinline__ void router_select_wave(const float* lg, const float*
                     topk_idx[t * k + pos] = lane + 64 * i;
                     topk_w[t * k + pos] = wv;
                 }
+                if (a1_offs) {
+                    a1_tok[pos] = 0;
+                    a1_scale[pos] = wv;
+                    a1_pos[pos] = pos;
+                }
             }
         }
         base += __popcll(m);
     }
     if (wt && lane < (k >> 1)) st_sc1_u32(topk_w + t * k + 2 * lane, reinterpret_cast<const unsigned*>(wl)[lane]);
+    if (a1_offs && lane == 0) {
+        a1_offs[E] = base;  // == k: start of the shared group
+        if (a1_shared) {
+            a1_offs[E + 1] = base + 1;
+            a1_tok[base] = 0;
+            a1_scale[base] = 0x3F80;  // bf16 1.0
+        }
+    }
 }
 
 // workgroup barrier that orders LDS traffic only (no wait for vector-memory operations in flight)
@@ -598,13 +620,19 @@ __global__ __launch_bounds__(ROUTER_NT) void router_topk_kernel(
     RT_MARK(6);  // all logits of the token in LDS
     const bool fuse_align = pre.al_offsets != nullptr;  // uniform (kernel argument)
     if (wid != 0 && !fuse_align) return;
+    const bool align_here = fuse_align && gridDim.x == 1;  // one token: the selecting wave buckets (see router_select_wave)
     if (wid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the bias DMA has landed
-        router_select_wave<EPL>(lg, bias_l, reinterpret_cast<unsigned*>(smem), reinterpret_cast<bf16_t*>(lg), lane, E, k,
-                                rsf, t, topk_idx, topk_w, logits_out, fuse_align);
+        if (align_here)
+            router_select_wave<EPL>(lg, bias_l, reinterpret_cast<unsigned*>(smem), reinterpret_cast<bf16_t*>(lg), lane, E, k,
+                                    rsf, t, topk_idx, topk_w, logits_out, false, pre.al_offsets, pre.al_token, pre.al_scale,
+                                    pre.al_pos, pre.al_with_shared);
+        else
+            router_select_wave<EPL>(lg, bias_l, reinterpret_cast<unsigned*>(smem), reinterpret_cast<bf16_t*>(lg), lane, E, k,
+                                    rsf, t, topk_idx, topk_w, logits_out, fuse_align);
     }  // wave 0
     RT_MARK(7);  // selection stored
-    if (!fuse_align) return;
+    if (!fuse_align || align_here) return;
 
     // ---- last-arriving workgroup: token -> expert bucketing over ALL tokens' routing (glm_moe_align) ----
     // Hand-off (cdna_hip_programming.md Guideline 16, counter form): wave 0 is the only wave that stored routing data;
@@ -868,102 +896,14 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const bf16_t* __restri
 // Combine fused with the NEXT layer's input add-RMSNorm (decode_layer.py:47-49 of layer i+1): one 512-thread workgroup
 // per token.  x = the combine result rounded to bf16 exactly as moe_combine_kernel writes it, then
 // s = x + residual, residual_out = bf16(s), y = bf16(bf16(s*rstd)*w) as rmsnorm_vec_kernel<ADD>.
-constexpr int CN_NT = 512;
+constexpr int CN_NT = GLM_CN_NT;
 template <int VPT>
 __global__ __launch_bounds__(CN_NT) void moe_combine_add_rmsnorm_kernel(
     const bf16_t* __restrict__ y, int64_t ldy, const int32_t* __restrict__ pair_pos, int k, int64_t shared_base,
     const bf16_t* res_in, const bf16_t* __restrict__ w, bf16_t* out, bf16_t* res_out, int H, float eps) {
-    __shared__ int pos[COMBINE_MAX_K];
-    __shared__ int npos;
     __shared__ float red[CN_NT / 64];
-    const int64_t t = blockIdx.x;
-    if (threadIdx.x == 0) {
-        int n = 0;
-        for (int j = 0; j < k; ++j) {
-            const int p = pair_pos[t * k + j];
-            if (p < 0) continue;
-            int i = n++;
-            while (i > 0 && pos[i - 1] > p) {
-                pos[i] = pos[i - 1];
-                --i;
-            }
-            pos[i] = p;
-        }
-        npos = n;
-    }
-    __syncthreads();
-    const int n = npos;
-    const int nvec = H >> 3;
-    float s[VPT][8];
-    float ss = 0.f;
-#pragma unroll
-    for (int v = 0; v < VPT; ++v) {
-        const int c = threadIdx.x + v * CN_NT;
-        if (c < nvec) {
-            float acc[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-            // the rounding chain is serial, the row loads are not: 8 rows are in flight at a time (clamped re-reads of
-            // the last row fill the batch), together with the shared row and the residual
-            u32x4_t sv = {0, 0, 0, 0};
-            if (shared_base >= 0) sv = reinterpret_cast<const u32x4_t*>(y + (shared_base + t) * ldy)[c];
-            const u32x4_t rv = reinterpret_cast<const u32x4_t*>(res_in + t * H)[c];
-            for (int j0 = 0; j0 < n; j0 += 8) {
-                u32x4_t vv[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    vv[j] = reinterpret_cast<const u32x4_t*>(y + (int64_t)pos[min(j0 + j, n - 1)] * ldy)[c];
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (j0 + j < n) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            acc[2 * q] = rbf(acc[2 * q] + bflo(vv[j][q]));
-                            acc[2 * q + 1] = rbf(acc[2 * q + 1] + bfhi(vv[j][q]));
-                        }
-                    }
-            }
-            if (shared_base >= 0) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc[2 * q] = acc[2 * q] + bflo(sv[q]);
-                    acc[2 * q + 1] = acc[2 * q + 1] + bfhi(sv[q]);
-                }
-            }
-            u32x4_t ov;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                s[v][2 * q] = rbf(acc[2 * q]) + bflo(rv[q]);          // rbf: the combine's own output rounding
-                s[v][2 * q + 1] = rbf(acc[2 * q + 1]) + bfhi(rv[q]);
-                ov[q] = pack2bf(s[v][2 * q], s[v][2 * q + 1]);
-            }
-            reinterpret_cast<u32x4_t*>(res_out + t * H)[c] = ov;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ss += s[v][i] * s[v][i];
-        }
-    }
-    ss = wave_sum(ss);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
-    __syncthreads();
-    float tot = 0.f;
-#pragma unroll
-    for (int i = 0; i < CN_NT / 64; ++i) tot += red[i];
-    const float rstd = 1.0f / sqrtf(tot / (float)H + eps);
-#pragma unroll
-    for (int v = 0; v < VPT; ++v) {
-        const int c = threadIdx.x + v * CN_NT;
-        if (c < nvec) {
-            const u32x4_t wv = reinterpret_cast<const u32x4_t*>(w)[c];
-            u32x4_t o;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float a = rbf(s[v][2 * i] * rstd) * bflo(wv[i]);
-                const float b = rbf(s[v][2 * i + 1] * rstd) * bfhi(wv[i]);
-                o[i] = pack2bf(a, b);
-            }
-            reinterpret_cast<u32x4_t*>(out + t * H)[c] = o;
-        }
-    }
+    // the row function is shared with the T <= 2 QKV launch that runs it as its prologue (gemm_tinym.hip)
+    glm_combine_add_rmsnorm_row<VPT>(y, ldy, pair_pos, k, shared_base, res_in, w, out, res_out, nullptr, H, eps, blockIdx.x, red);
 }
 
 }  // namespace

@@ -1,12 +1,16 @@
 """One-shot all-reduce over directly mapped peer buffers (csrc/oneshot_allreduce.hip) — OPT-IN (GLM_ONESHOT_ALLREDUCE=1).
 
 RCCL (`dist.all_reduce`) is the default and the only path measured on more than one GPU.  This module maps every rank's
-comm buffer and flag array into every peer (PyTorch's CUDA-IPC storage sharing, dmabuf on this ROCm), after which an
-all-reduce of a [T, H] bf16 tensor is ONE kernel per rank: publish, signal the 7 peers, wait for their signals, sum all
-buffers in rank order.  Anything that goes wrong while setting it up leaves the TP group on RCCL.
+receive buffer and flag array into every peer (PyTorch's CUDA-IPC storage sharing, dmabuf on this ROCm), after which an
+all-reduce of a [T, H] bf16 tensor is ONE kernel per rank: push the rows into every peer's receive slot, signal the
+peers, wait for their signals, sum the contributions out of local memory in rank order.  The call counter (epoch) lives
+in DEVICE memory and is advanced by the kernel, so captured calls stay correct under HIP-graph replay.  Anything that
+goes wrong while setting it up leaves the TP group on RCCL; a wait that expires at run time poisons the output with NaNs
+and sets a status word that `check()` turns into an exception at the engine's next synchronisation point.
 
-Tested: world = 1; two "ranks" on two streams of one device (tests/test_hip_kernels.py); two PROCESSES sharing one
-device over CUDA-IPC (tools/oneshot_allreduce_2proc.py on the GPU box).  Not yet run across xGMI."""
+Tested: world = 1; two "ranks" on two streams of one device, one of them delayed (tests/test_hip_kernels.py); two
+PROCESSES sharing one device over CUDA-IPC, eager and under graph replay with an odd number of calls per graph
+(tools/oneshot_allreduce_2proc.py on the GPU box).  Not yet run across xGMI."""
 from __future__ import annotations
 
 import ctypes
@@ -25,12 +29,13 @@ class OneShotAllReduce:
     def __init__(self, n_max: int, device, rank: int, world: int):
         assert n_max % 8 == 0 and 1 <= world <= N_FLAGS
         self.n_max, self.device, self.rank, self.world = n_max, device, rank, world
-        self.buf = torch.zeros(2 * n_max, dtype=torch.bfloat16, device=device)
+        # receive buffer [2 slots][world senders][n_max]; flags[q] = last epoch complete from rank q; state = epoch,
+        # arrive, done, status (all advanced by the kernel)
+        self.buf = torch.zeros(2 * world * n_max, dtype=torch.bfloat16, device=device)
         self.flags = torch.zeros(N_FLAGS, dtype=torch.int32, device=device)
-        self.local = torch.zeros(4, dtype=torch.int32, device=device)   # [0] arrival counter, [1] status
+        self.state = torch.zeros(4, dtype=torch.int32, device=device)
         self.peer_bufs = [self.buf] * world      # replaced by connect()
         self.peer_flags = [self.flags] * world
-        self.epoch = 0
         self._keep = []
 
     # ---- wiring -------------------------------------------------------------------------------------------------
@@ -51,7 +56,7 @@ class OneShotAllReduce:
                 bufs.append(self.buf)
                 flags.append(self.flags)
             else:
-                bufs.append(self._open(h[0], torch.bfloat16, 2 * self.n_max, self.device))
+                bufs.append(self._open(h[0], torch.bfloat16, 2 * self.world * self.n_max, self.device))
                 flags.append(self._open(h[1], torch.int32, N_FLAGS, self.device))
         self.peer_bufs, self.peer_flags = bufs, flags
 
@@ -85,21 +90,32 @@ class OneShotAllReduce:
 
     # ---- the collective -----------------------------------------------------------------------------------------
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
-        """In-place sum over the ranks (bf16, numel <= n_max, multiple of 8, contiguous)."""
+        """In-place sum over the ranks (bf16, numel <= n_max, multiple of 8, contiguous).  Graph-capturable: nothing
+        about the call is a host-side counter."""
         assert t.dtype == torch.bfloat16 and t.is_contiguous() and t.numel() % 8 == 0 and t.numel() <= self.n_max
-        self.epoch += 1
         P = ctypes.c_void_p * self.world
         pb = P(*[b.data_ptr() for b in self.peer_bufs])
         pf = P(*[f.data_ptr() for f in self.peer_flags])
         rc = hip_ops.load_library().glm_allreduce_oneshot(
-            t.data_ptr(), t.data_ptr(), pb, pf, self.rank, self.world, t.numel(), self.n_max, self.epoch,
-            self.local.data_ptr(), self.local[1:].data_ptr(), torch.cuda.current_stream().cuda_stream)
+            t.data_ptr(), t.data_ptr(), pb, pf, self.rank, self.world, t.numel(), self.n_max, self.state.data_ptr(),
+            torch.cuda.current_stream().cuda_stream)
         hip_ops._check(rc, "glm_allreduce_oneshot")
         return t
 
     def status(self) -> int:
         """0 = every wait completed; k + 1 = some call gave up waiting for rank k (synchronises)."""
-        return int(self.local[1].item())
+        return int(self.state[3].item())
+
+    def epoch(self) -> int:
+        """Completed calls so far (synchronises)."""
+        return int(self.state[0].item())
+
+    def check(self) -> None:
+        """Raise if a call gave up waiting (its output was poisoned with NaNs).  Call at a point that synchronises anyway."""
+        st = self.status()
+        if st:
+            raise RuntimeError(f"one-shot all-reduce: rank {self.rank} gave up waiting for rank {st - 1}; "
+                               "the outputs of that call are NaN")
 
 
 def enabled() -> bool:

@@ -17,6 +17,12 @@ class TPGroup:
         self._group = group
 
     @property
+    def process_group(self):
+        """The torch.distributed group behind this coordinator (None = the world): collectives other than the
+        all-reduce (the expert-parallel all-to-all) run on the same group."""
+        return self._group
+
+    @property
     def world_size(self) -> int:
         return dist.get_world_size(self._group) if dist.is_available() and dist.is_initialized() else 1
 
@@ -45,6 +51,12 @@ class TPGroup:
                 return None
         return self._oneshot
 
+    def check(self) -> None:
+        """Surface a failed one-shot all-reduce (bounded wait expired: outputs poisoned) as an exception.  Cheap no-op
+        on RCCL; the engine calls it where it synchronises anyway (after reading the sampled tokens)."""
+        if self._oneshot:
+            self._oneshot.check()
+
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
         if self.world_size > 1:
             fast = self._oneshot_for(t)
@@ -70,10 +82,13 @@ def set_tp_group(group) -> None:
 class _SingleRank:
     """What the reference's stub always answers (parallel_state.py:1-9): used while building modules that must NOT be
     tensor-parallel although the process group is (the experts of an expert-parallel MoE block)."""
-    world_size, rank = 1, 0
+    world_size, rank, process_group = 1, 0, None
 
     def all_reduce(self, t):
         return t
+
+    def check(self):
+        pass
 
 
 class unsharded:

@@ -105,7 +105,8 @@ class ModelRunner:
     def reserve_workspaces(self):
         """Persistent scratch that must exist before the KV cache takes the rest of the memory: the split-KV partials
         of the decode attention, sized for every batch size up to max_num_seqs (a few MB: no splits at all once
-        batch x kv-heads covers the chip)."""
+        batch x kv-heads covers the chip), and the router launch's workspace.  Both are keyed by device, so the graphs
+        captured later (on torch's capture stream) use exactly these buffers; growing one during a capture raises."""
         from nanovllm import hip_ops
         cfg, hf = self.config, self.config.hf_config
         nh = hf.num_attention_heads // self.world_size
@@ -114,6 +115,8 @@ class ModelRunner:
         if hf.head_dim == 128:
             hip_ops.reserve_attn_workspace(self.device, min(cfg.max_num_seqs, 512), nh, nkv, hf.head_dim,
                                            self.block_size, max_blocks)
+        if getattr(hf, "n_routed_experts", None):  # arrival counters + logits scratch of the fused norm + router launch
+            hip_ops.reserve_router_workspace(self.device, min(cfg.max_num_seqs, 512), hf.n_routed_experts)
 
     def allocate_kv_cache(self):
         cfg, hf = self.config, self.config.hf_config
@@ -197,6 +200,11 @@ class ModelRunner:
         temps = self._dev([s.temperature for s in seqs], torch.float32) if self.rank == 0 else None
         logits = self.run_model(input_ids, positions, is_prefill)
         tokens = self.sampler(logits, temps).tolist() if self.rank == 0 else None
+        if self.world_size > 1:
+            # a one-shot all-reduce that gave up waiting poisoned its output and set a status word: surface it here, where
+            # rank 0 has just synchronised on the tokens anyway (no-op on RCCL)
+            from nanovllm.distributed.parallel_state import get_tp_group
+            get_tp_group().check()
         reset_context()
         return tokens
 

@@ -76,6 +76,13 @@ _SIGNATURES = {
                                 c_int64, c_void_p]),
     "glm_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                               c_int64, c_int, c_int, c_void_p]),
+    "glm_grouped_gemm_gateup_silu_fewtok": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                                                    c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "glm_grouped_gemm_down_fewtok": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int,
+                                             c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "glm_gemm_bf16_combine_norm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p,
+                                           c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                           c_int, c_int, c_void_p]),
     "glm_gemm_bf16_partial_slices": (c_int, [c_int, c_int]),
     "glm_gemm_bf16_partial": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
                                       c_int, c_void_p]),
@@ -87,8 +94,9 @@ _SIGNATURES = {
                                                   c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                                   c_int, c_void_p, c_size_t, c_void_p]),
     "glm_router_workspace_bytes": (c_size_t, [c_int64, c_int]),
-    "glm_allreduce_oneshot": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, ctypes.c_uint,
-                                      c_void_p, c_void_p, c_void_p]),
+    "glm_allreduce_oneshot_buffer_elems": (c_size_t, [c_int, c_int64]),
+    "glm_allreduce_oneshot": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p,
+                                      c_void_p]),
     "glm_gather_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "glm_scatter_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "glm_moe_combine_scaled": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,
@@ -272,25 +280,36 @@ def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------------
 # attention
-# Split-KV scratch of the decode attention: ONE grow-only buffer per (device, stream), sized for the split count the
-# launch really uses (none at all once B * nkv >= 256).  A replaced buffer stays referenced: HIP graphs captured earlier
-# hold its address.  reserve_attn_workspace() lets the runner size it for max_num_seqs BEFORE the KV cache takes the
-# rest of the memory.
+# Split-KV scratch of the decode attention: ONE grow-only buffer per device, sized for the split count the launch
+# really uses (none at all once B * nkv >= 256).  Keyed by device only: launches of one engine on one device are stream
+# ordered (eager step, then capture on torch's side stream, then replays), and a per-stream key would make every graph
+# capture miss the buffer reserve_attn_workspace() laid down on the default stream.  A replaced buffer stays referenced:
+# HIP graphs captured earlier hold its address.  reserve_attn_workspace() lets the runner size it for max_num_seqs
+# BEFORE the KV cache takes the rest of the memory; growing inside a stream capture is an error (the allocation and
+# its memset would land in that graph's private pool).
 _attn_ws: dict = {}
 _attn_ws_retired: list = []
+
+
+def _grow_only(table: dict, retired: list, device, need: int, what: str) -> torch.Tensor:
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ws = table.get(key)
+    if ws is None or ws.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(f"{what}: {need} bytes needed while a HIP graph is being captured, {0 if ws is None else ws.numel()} "
+                               "reserved — run one eager step (or the reserve_* call) at this size before capturing")
+        if ws is not None:
+            retired.append(ws)
+        ws = torch.zeros(need, dtype=torch.uint8, device=device)  # zeros: the head of it holds arrival counters
+        table[key] = ws
+    return ws
 
 
 def _attn_workspace(device, need: int) -> torch.Tensor | None:
     if need <= 0:
         return None
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _attn_ws.get(key)
-    if ws is None or ws.numel() < need:
-        if ws is not None:
-            _attn_ws_retired.append(ws)
-        ws = torch.zeros(need, dtype=torch.uint8, device=device)  # zeros: the head of it holds arrival counters
-        _attn_ws[key] = ws
-    return ws
+    return _grow_only(_attn_ws, _attn_ws_retired, device, need, "decode attention split-KV scratch")
 
 
 def attn_workspace_bytes(B: int, nh: int, nkv: int, hd: int, block_size: int, bt_stride: int, num_splits: int = 0,
@@ -444,17 +463,17 @@ _router_ws_retired: list = []
 
 def _router_workspace(device, T: int, E: int) -> torch.Tensor:
     """Workspace of the fused router + align launch (arrival counters, zero-initialised and restored by the kernel, then
-    the T x E logits scratch): one grow-only buffer per (device, stream); a replaced buffer stays referenced because
-    HIP graphs captured earlier hold its address."""
-    need = load_library().glm_router_workspace_bytes(T, E)
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _router_ws.get(key)
-    if ws is None or ws.numel() < need:
-        if ws is not None:
-            _router_ws_retired.append(ws)
-        ws = torch.zeros(need, dtype=torch.uint8, device=device)
-        _router_ws[key] = ws
-    return ws
+    the T x E logits scratch): one grow-only buffer per device (see _grow_only); a replaced buffer stays referenced
+    because HIP graphs captured earlier hold its address."""
+    return _grow_only(_router_ws, _router_ws_retired, device, load_library().glm_router_workspace_bytes(T, E),
+                      "router workspace")
+
+
+def reserve_router_workspace(device, max_tokens: int, E: int) -> int:
+    """Size the router workspace for every batch size up to max_tokens (the runner calls this before graph capture)."""
+    need = load_library().glm_router_workspace_bytes(max_tokens, E)
+    _grow_only(_router_ws, _router_ws_retired, device, need, "router workspace")
+    return need
 
 
 def add_rmsnorm_router_topk(x, residual: torch.Tensor, norm_weight: torch.Tensor, eps: float,
@@ -537,13 +556,23 @@ def moe_align(topk_idx: torch.Tensor, topk_w: torch.Tensor, E: int, with_shared:
     return offs, tok, scale, pos
 
 
-def grouped_gemm_gateup_silu(x, w13, expert_offsets, sorted_token, R: int) -> torch.Tensor:
-    """x [T,H]; w13 [G, 2I, H] -> act [R, I]."""
+TINYM_MAX_ROWS = 2  # token rows the single-sequence GEMV body takes (csrc/gemm_tinym.hip)
+
+
+def grouped_gemm_gateup_silu(x, w13, expert_offsets, sorted_token, R: int, max_rows_per_group: int | None = None) -> torch.Tensor:
+    """x [T,H]; w13 [G, 2I, H] -> act [R, I].  max_rows_per_group: an upper bound the caller knows (T for a top-k routing
+    with the shared group); with T <= 2 it selects the single-sequence GEMV body."""
     _bf16(x, "x"); _bf16(w13, "w13")
     G, I2, H = w13.shape
     I = I2 // 2
     assert w13.stride(2) == 1  # rows may be padded (stride(1) >= H), groups strided
     act = torch.empty((R, I), dtype=x.dtype, device=x.device)
+    if x.shape[0] <= TINYM_MAX_ROWS and max_rows_per_group is not None and max_rows_per_group <= x.shape[0]:
+        # single-sequence decode: the GEMV body (the caller vouches that no group holds more rows than there are tokens)
+        _check(load_library().glm_grouped_gemm_gateup_silu_fewtok(
+            _p(x), x.stride(0), x.shape[0], _p(w13), w13.stride(0), w13.stride(1), _p(expert_offsets), _p(sorted_token),
+            _p(act), R, H, I, G, _stream()), "glm_grouped_gemm_gateup_silu_fewtok")
+        return act
     _check(load_library().glm_grouped_gemm_gateup_silu(_p(x), x.stride(0), _p(w13), w13.stride(0),
                                                        w13.stride(1),
                                                        _p(expert_offsets), _p(sorted_token),
@@ -552,13 +581,19 @@ def grouped_gemm_gateup_silu(x, w13, expert_offsets, sorted_token, R: int) -> to
     return act
 
 
-def grouped_gemm_down(act, w2, expert_offsets, sorted_scale, n_scaled_groups: int) -> torch.Tensor:
+def grouped_gemm_down(act, w2, expert_offsets, sorted_scale, n_scaled_groups: int,
+                      max_rows_per_group: int | None = None) -> torch.Tensor:
     """act [R,I]; w2 [G, H, I] -> y [R, H]."""
     _bf16(act, "act"); _bf16(w2, "w2")
     G, H, I = w2.shape
     R = act.shape[0]
     assert w2.stride(2) == 1 and act.is_contiguous()
     y = torch.empty((R, H), dtype=act.dtype, device=act.device)
+    if max_rows_per_group is not None and max_rows_per_group <= TINYM_MAX_ROWS:
+        _check(load_library().glm_grouped_gemm_down_fewtok(_p(act), max_rows_per_group, _p(w2), w2.stride(0), w2.stride(1),
+                                                           _p(expert_offsets), _p(sorted_scale), n_scaled_groups, _p(y), H,
+                                                           R, H, I, G, _stream()), "glm_grouped_gemm_down_fewtok")
+        return y
     _check(load_library().glm_grouped_gemm_down(_p(act), _p(w2), w2.stride(0), w2.stride(1),
                                                 _p(expert_offsets),
                                                 _p(sorted_scale), n_scaled_groups, _p(y), H, R, H,
@@ -699,6 +734,28 @@ def moe_combine_add_rmsnorm(dc: DeferredCombine, residual: torch.Tensor, weight:
                                                       dc.shared_base, _p(r2), _p(weight), _p(out), _p(ro), eps,
                                                       _stream()), "glm_moe_combine_add_rmsnorm")
     return out.view(residual.shape), ro.view(residual.shape)
+
+
+def combine_add_rmsnorm_gemm(dc: DeferredCombine, residual: torch.Tensor, norm_weight: torch.Tensor, eps: float,
+                             w: torch.Tensor, bias: torch.Tensor | None):
+    """T <= 2: moe_combine + add_rmsnorm(combined, residual) + (x @ w.T + bias) in ONE launch (glm_gemm_bf16_combine_norm).
+    Returns (y [T, N], residual_out [T, H]); the normalised hidden state itself is never written."""
+    _bf16(residual, "residual"); _bf16(norm_weight, "norm_weight"); _bf16(w, "w")
+    H = dc.y.shape[1]
+    N = w.shape[0]
+    r2 = residual.reshape(-1, H).contiguous()
+    assert r2.shape[0] == dc.T and w.shape[1] == H and w.stride(1) == 1
+    y = torch.empty((dc.T, N), dtype=r2.dtype, device=r2.device)
+    ro = torch.empty_like(r2)
+    _check(load_library().glm_gemm_bf16_combine_norm(_p(dc.y), dc.y.stride(0), _p(dc.pair_pos), dc.T, dc.k, dc.shared_base,
+                                                     _p(r2), _p(norm_weight), eps, _p(ro), None, _p(w), w.stride(0),
+                                                     _p(bias), _p(y), N, N, H, _stream()), "glm_gemm_bf16_combine_norm")
+    return y, ro.view(residual.shape)
+
+
+def can_combine_norm_gemm(dc, H: int) -> bool:
+    return (isinstance(dc, DeferredCombine) and dc.T <= TINYM_MAX_ROWS and H % 8 == 0 and H <= 4096
+            and os.environ.get("GLM4MOE_TINYM", "1") != "0" and os.environ.get("GLM4MOE_FUSE_COMBINE_QKV", "1") != "0")
 
 
 class PartialSum:

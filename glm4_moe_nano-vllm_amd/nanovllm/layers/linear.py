@@ -140,8 +140,15 @@ class RowParallelLinear(LinearBase):
     partial_min_k = 8192
     partial_slices = 8
 
+    @staticmethod
+    def _partial_rows(m: int) -> bool:
+        import os
+        lo = hip_ops.TINYM_MAX_ROWS if os.environ.get("GLM4MOE_TINYM", "1") != "0" else 0
+        return lo < m <= 32
+
     def forward(self, x: torch.Tensor, defer_reduce: bool = False):
-        if (defer_reduce and self.tp_size == 1 and self.bias is None and x.dim() == 2 and x.shape[0] <= 32
+        # (not at T <= 2: the single-sequence GEMV body streams the whole reduction per row and needs no K split)
+        if (defer_reduce and self.tp_size == 1 and self.bias is None and x.dim() == 2 and self._partial_rows(x.shape[0])
                 and x.shape[1] >= self.partial_min_k and x.shape[1] >= 2 * self.weight.shape[0]
                 and x.shape[1] % 8 == 0 and x.stride(1) == 1):
             return hip_ops.gemm_bf16_partial(x, self.weight.data, self.partial_slices)

@@ -68,19 +68,25 @@ class Glm4MoeAttention(nn.Module):
         return (self.head_dim % 8 == 0 and lph >= 2 and lph <= 64 and (lph & (lph - 1)) == 0
                 and self.rotary_emb.rotary_dim % 16 == 0)
 
-    def forward(self, hidden_states: torch.Tensor, positions: torch.Tensor, defer_o_reduce: bool = False):
+    def forward(self, hidden_states: torch.Tensor | None, positions: torch.Tensor, defer_o_reduce: bool = False,
+                qkv: torch.Tensor | None = None):
         """defer_o_reduce: the caller feeds the result straight into RMSNorm.forward(x, residual) and accepts a
-        hip_ops.PartialSum (K-slice partial sums of o_proj, reduced inside that add-RMSNorm kernel)."""
+        hip_ops.PartialSum (K-slice partial sums of o_proj, reduced inside that add-RMSNorm kernel).
+        qkv: the QKV projection of this layer's normalised input, already computed by the caller (the T <= 2 launch that
+        fuses combine + input norm + projection); hidden_states is then unused (may be None)."""
         ctx = get_context()
         attn = self.attn
         has_cache = attn.k_cache.numel() > 0 and attn.v_cache.numel() > 0
+        two_d = qkv.dim() == 2 if qkv is not None else hidden_states.dim() == 2
         if (self.fuse_decode_attention and not ctx.is_prefill and has_cache and not self.use_qk_norm
-                and self.head_dim == 128 and self.rotary_emb.rotary_dim == 64 and hidden_states.dim() == 2
+                and self.head_dim == 128 and self.rotary_emb.rotary_dim == 64 and two_d
                 and self.num_heads // self.num_kv_heads <= 16 and attn.k_cache.shape[1] % 32 == 0):
             # decode: rotary, K/V cache store and paged attention in one launch, straight from the QKV rows — or, at
             # decode batch sizes, from the QKV projection's K-slice partial sums (reduced + biased on load)
             bias = None
-            if self.defer_qkv_reduce and self.qkv_proj.can_defer_reduce(hidden_states):
+            if qkv is not None:
+                pass
+            elif self.defer_qkv_reduce and self.qkv_proj.can_defer_reduce(hidden_states):
                 qkv = self.qkv_proj.forward_partial(hidden_states)
                 bias = self.qkv_proj.bias.data if self.qkv_proj.bias is not None else None
             else:
@@ -90,7 +96,8 @@ class Glm4MoeAttention(nn.Module):
                 self.rotary_emb.rotary_dim, ctx.slot_mapping, attn.k_cache, attn.v_cache, ctx.context_lens,
                 ctx.block_tables, attn.scale, qkv_bias=bias)
             return self.o_proj(o.reshape(o.shape[0], -1), defer_reduce=defer_o_reduce)
-        qkv = self.qkv_proj(hidden_states)
+        if qkv is None:
+            qkv = self.qkv_proj(hidden_states)
         if self._fusable():
             need_kv = ctx.is_prefill and ctx.block_tables is None
             q, k, v = hip_ops.qkv_split_norm_rope_store(

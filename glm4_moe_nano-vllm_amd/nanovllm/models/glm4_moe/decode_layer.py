@@ -48,12 +48,21 @@ class Glm4MoeDecoderLayer(nn.Module):
                 defer_combine: bool = False):
         """defer_combine: the caller passes the returned hidden state straight to the next layer (or to an
         RMSNorm.forward(x, residual)) and accepts a hip_ops.DeferredCombine instead of a tensor."""
-        if residual is None:
+        qkv = None
+        if residual is not None and hip_ops.can_combine_norm_gemm(hidden_states, residual.shape[-1]):
+            # T <= 2 (single-sequence decode): the previous layer's MoE combine, this layer's input add-RMSNorm and the
+            # QKV projection in ONE launch — every workgroup of the GEMV recomputes the tiny combine + norm behind its
+            # first weight loads; bit-identical to the separate launches
+            ln, qp = self.input_layernorm, self.self_attn.qkv_proj
+            qkv, residual = hip_ops.combine_add_rmsnorm_gemm(hidden_states, residual, ln.weight.data, ln.eps, qp.weight.data,
+                                                             qp.bias.data if qp.bias is not None else None)
+            hidden_states = None
+        elif residual is None:
             hidden_states, residual = self.input_layernorm(hidden_states), hidden_states
         else:
             hidden_states, residual = self.input_layernorm(hidden_states, residual)
         # o_proj may hand over K-slice partial sums; the add-RMSNorm right below reduces them (decode batches)
-        hidden_states = self.self_attn(hidden_states, positions, defer_o_reduce=True)
+        hidden_states = self.self_attn(hidden_states, positions, defer_o_reduce=True, qkv=qkv)
         gate = getattr(self.mlp, "gate", None)
         if self.fuse_norm_router and gate is not None and residual.shape[-1] <= 8192:
             # post-attention add-RMSNorm and the router of the same token in one launch

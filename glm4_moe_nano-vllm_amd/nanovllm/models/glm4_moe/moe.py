@@ -77,6 +77,9 @@ class Glm4MoeMoE(nn.Module):
         # per-row scale); quantised lazily from the loaded bf16 weights at the first forward
         self.expert_weight_dtype = getattr(config, "expert_weight_dtype", None)
         self._fp8 = None
+        self._bf16_freed = False
+        if self.ep_size > 1 and self.expert_weight_dtype is not None:
+            raise NotImplementedError("expert parallelism runs the bf16 expert stacks; fp8 experts + EP is not built")
 
     # ---- stacked expert storage ---------------------------------------------------------
     def _mlps(self):
@@ -96,17 +99,30 @@ class Glm4MoeMoE(nn.Module):
         self._w13, self._w2 = w13, w2
 
     def _stacked(self):
+        if self._bf16_freed:
+            raise RuntimeError("the bf16 expert stacks were released after fp8 quantisation "
+                               "(config.keep_bf16_experts = True keeps them)")
         first = self.experts[0].gate_up_proj.weight
         if self._w13 is None or first.data_ptr() != self._w13.data_ptr():
             self._stack(copy=True)  # parameters were moved/replaced (e.g. .to(device)): re-tie
         return self._w13, self._w2
 
-    def quantize_experts_fp8(self) -> None:
-        """(Re)build the fp8 copies of the stacked expert weights from the current bf16 values."""
+    def quantize_experts_fp8(self, free_bf16: bool | None = None) -> None:
+        """(Re)build the fp8 copies of the stacked expert weights from the current bf16 values.  Unless
+        `config.keep_bf16_experts` is set, the bf16 stacks are then RELEASED (the per-expert parameters become empty
+        tensors): fp8 experts are there to halve the expert memory, not to add 50 % to it."""
         w13, w2 = self._stacked()
         w13_q, w13_s = hip_ops.quantize_fp8_rowwise(w13)
         w2_q, w2_s = hip_ops.quantize_fp8_rowwise(w2)
         self._fp8 = (w13_q, w13_s, w2_q, w2_s)
+        if free_bf16 is None:
+            free_bf16 = not bool(getattr(self.config, "keep_bf16_experts", False))
+        if free_bf16:
+            for m in self._mlps():
+                m.gate_up_proj.weight.data = w13.new_empty(0)
+                m.down_proj.weight.data = w2.new_empty(0)
+            self._w13 = self._w2 = None
+            self._bf16_freed = True
 
     # ---- weights ------------------------------------------------------------------------
     def load_weights(self, path: str, prefix: str):
@@ -121,6 +137,8 @@ class Glm4MoeMoE(nn.Module):
         for expert, gid in zip(self.experts, self.expert_ids):
             expert.load_weights(path, f"{prefix}.experts.{gid}")
         self.shared_experts.load_weights(path, f"{prefix}.shared_experts")
+        if self.expert_weight_dtype == "fp8_e4m3":  # per layer, right after loading: the bf16 peak is ONE layer's stack
+            self.quantize_experts_fp8()
 
     def _ep_experts(self, ops=hip_ops, rank: int | None = None):
         w13, w2 = self._stacked()
@@ -139,10 +157,10 @@ class Glm4MoeMoE(nn.Module):
         h = hidden_states.view(-1, shape[-1])
         T = h.shape[0]
         E, k = self.config.n_routed_experts, self.config.num_experts_per_tok
-        w13, w2 = self._stacked()
         topk_idx, topk_w = self.gate(h, precomputed=routing)
         if self.ep_size > 1:
-            return EP.run(self._ep_experts().forward(h, topk_idx, topk_w)).view(shape)
+            # `aligned` (a bucketing of ALL tokens over ALL experts) is of no use here: every rank buckets its own slice
+            return EP.run(self._ep_experts().forward(h, topk_idx, topk_w), group=get_tp_group().process_group).view(shape)
         offs, tok, scale, pos = aligned if aligned is not None else hip_ops.moe_align(topk_idx, topk_w, E, True)
         R = T * k + T
         if self.expert_weight_dtype == "fp8_e4m3":
@@ -152,8 +170,11 @@ class Glm4MoeMoE(nn.Module):
             act = hip_ops.grouped_gemm_gateup_silu_fp8w(h, w13_q, w13_s, offs, tok, R)
             y = hip_ops.grouped_gemm_down_fp8w(act, w2_q, w2_s, offs, scale, E)
         else:
-            act = hip_ops.grouped_gemm_gateup_silu(h, w13, offs, tok, R)
-            y = hip_ops.grouped_gemm_down(act, w2, offs, scale, E)
+            w13, w2 = self._stacked()
+            # a token's k experts are distinct and the shared group holds T rows: no group exceeds T rows (T <= 2 selects
+            # the single-sequence GEMV body)
+            act = hip_ops.grouped_gemm_gateup_silu(h, w13, offs, tok, R, max_rows_per_group=T)
+            y = hip_ops.grouped_gemm_down(act, w2, offs, scale, E, max_rows_per_group=T)
         if defer_combine and get_tp_group().world_size == 1 and shape[-1] % 8 == 0 and shape[-1] <= 16384:
             return hip_ops.DeferredCombine(y, pos, T, k, T * k, shape)
         out = hip_ops.moe_combine(y, pos, T, k, T * k)

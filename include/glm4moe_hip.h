@@ -217,10 +217,35 @@ int glm_moe_combine(const void* y, int64_t ldy, const int32_t* pair_pos, void* o
                     int64_t T, int k, int H, int64_t shared_base, glm_stream_t stream);
 
 /* a5/a10 layers/linear.py:53,75,152  y = bf16(x·Wᵀ + b): x [M,K] (ldx), W [N,K] (row pitch ldw),
- *     bias [N] bf16 or NULL, y [M,N] (ldy).  Picks the weight-streaming small-M kernel or the
- *     LDS-tiled MFMA kernel from M.                                                         */
+ *     bias [N] bf16 or NULL, y [M,N] (ldy).  Picks the kernel from M: the GEMV body
+ *     of single-sequence decode (M <= 2), the weight-streaming small-M kernel, or the LDS-tiled MFMA kernel.                                                         */
 int glm_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
                   void* y, int64_t ldy, int64_t M, int N, int K, glm_stream_t stream);
+
+/* Single-sequence decode (BASELINE config 2: greedy bs = 1; T <= 2 token rows), r03.
+ * a13 at T <= 2: the same operators as glm_grouped_gemm_gateup_silu / glm_grouped_gemm_down (same arguments, same
+ *     rounding points) on the GEMV body — one persistent workgroup per CU, fp32 FMA, weights streamed 16-32 KiB deep per
+ *     wave.  T = number of token rows of x; PRECONDITION: no group holds more than T rows (true for a top-k routing: a
+ *     token's experts are distinct, the shared group holds T rows).  Shapes the body does not cover fall through to the
+ *     entry points above.                                                                                             */
+int glm_grouped_gemm_gateup_silu_fewtok(const void* x, int64_t ldx, int64_t T, const void* w13,
+                                        int64_t w13_group_stride, int64_t w13_row_stride,
+                                        const int32_t* expert_offsets, const int32_t* sorted_token,
+                                        void* act, int64_t R, int H, int I, int G, glm_stream_t stream);
+int glm_grouped_gemm_down_fewtok(const void* act, int64_t T, const void* w2, int64_t w2_group_stride,
+                                 int64_t w2_row_stride, const int32_t* expert_offsets, const void* sorted_scale,
+                                 int n_scaled_groups, void* y, int64_t ldy, int64_t R, int H, int I, int G,
+                                 glm_stream_t stream);
+/* a3 + a5 of layer i+1 with a12 of layer i, T <= 2 (decode_layer.py:47-49 + attention_new.py qkv_proj + moe.py:133-171):
+ *     c = glm_moe_combine(y_prev, pair_pos, shared_base);  s = f32(c) + f32(residual_in);  residual_out = bf16(s);
+ *     xn = bf16(bf16(s * rstd(s)) * norm_weight);  y = bf16(xn·Wᵀ + bias)
+ *     in ONE launch: every workgroup of the GEMV recomputes the (tiny) combine + norm behind its first weight loads,
+ *     workgroup 0 writes residual_out (and x_out = xn when not NULL).  Bit-identical to
+ *     glm_moe_combine_add_rmsnorm followed by glm_gemm_bf16.  GLM_ERR_UNSUPPORTED when T > 2 or H > 4096.             */
+int glm_gemm_bf16_combine_norm(const void* y_prev, int64_t ld_yprev, const int32_t* pair_pos, int64_t T, int k,
+                               int64_t shared_base, const void* residual_in, const void* norm_weight, float eps,
+                               void* residual_out, void* x_out, const void* w, int64_t ldw, const void* bias,
+                               void* y, int64_t ldy, int N, int H, glm_stream_t stream);
 
 /* a10+a3 fused pair for decode batches (M <= 32), no reference counterpart as an API: the row-parallel o_proj
  *     (layers/linear.py:152, K = nh*hd >> N) is computed as `nslices` K-slice partial sums by separate workgroups,
@@ -305,16 +330,19 @@ int glm_moe_combine_scaled(const void* y, int64_t ldy, const int32_t* pair_pos, 
                            glm_stream_t stream);
 
 /* N3  one-shot all-reduce(sum) of a small bf16 tensor over directly mapped peer buffers (the RowParallel all-reduce,
- *     layers/linear.py:153-154, as ONE hop over all xGMI links instead of a ring).  Every rank owns a comm buffer of
- *     2 * n_max bf16 (two halves used by epoch parity) and 8 uint32 flags, both mapped into every peer (hipIpc);
- *     peer_bufs / peer_flags are HOST arrays of `world` device pointers as seen by THIS process (entry `rank` = own).
- *     epoch: 1, 2, 3, … identical on all ranks, one per call.  local_counter (uint32, zero before the first call) and
- *     status (uint32, zero = ok; k+1 = gave up waiting for rank k) live in this rank's memory.  Sums are formed in
- *     ascending rank order in fp32 and rounded once: bit-identical on every rank.  Spins are bounded.  NOT the default
- *     path: RCCL is; this entry has run with world = 1 and with two ranks emulated on one device only.             */
+ *     layers/linear.py:153-154, as ONE hop over all xGMI links instead of a ring), PUSH form.  Every rank owns a receive
+ *     buffer of glm_allreduce_oneshot_buffer_elems(world, n_max) = 2 * world * n_max bf16 ([2 slots][sender][n_max]) and
+ *     8 uint32 flags, both mapped into every peer (hipIpc) and ZERO before the first call; peer_bufs / peer_flags are HOST
+ *     arrays of `world` device pointers as seen by THIS process (entry `rank` = own).  state: 4 uint32 in this rank's
+ *     device memory, zero before the first call: [0] epoch (completed calls — advanced by the kernel, so calls captured in
+ *     a HIP graph stay correct under replay), [1]/[2] internal counters, [3] status (0 = ok; q+1 = a call gave up waiting
+ *     for rank q: that call's output is NaN).  Every rank must issue the same sequence of calls.  The sum is formed in
+ *     ascending rank order in fp32 and rounded once: bit-identical on every rank.  Spins are bounded.  out may alias in.
+ *     NOT the default path: RCCL is; this entry has run with world = 1, with two ranks on two streams of one device and
+ *     with two processes on one device (eager and under graph replay) only.                                          */
+size_t glm_allreduce_oneshot_buffer_elems(int world, int64_t n_max);
 int glm_allreduce_oneshot(const void* in, void* out, void* const* peer_bufs, void* const* peer_flags, int rank, int world,
-                          int64_t n, int64_t n_max, unsigned epoch, void* local_counter, void* status,
-                          glm_stream_t stream);
+                          int64_t n, int64_t n_max, void* state, glm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -31,13 +31,15 @@ def layer_weights_from_module(layer, n_routed_experts: int | None = None) -> O.L
               k_norm=_cpu(att.k_norm.weight) if getattr(att, "use_qk_norm", False) else None)
     mlp = layer.mlp
     if hasattr(mlp, "gate"):
-        w13, w2 = mlp._stacked()
+        fp8 = getattr(mlp, "expert_weight_dtype", None) == "fp8_e4m3"
+        if fp8 and mlp._fp8 is None:
+            mlp.quantize_experts_fp8()
         E = n_routed_experts or len(mlp.experts)
-        kw.update(gate_w=_cpu(mlp.gate.weight), gate_bias=_cpu(mlp.gate.e_score_correction_bias),
-                  w13=_cpu(w13[:E]), w2=_cpu(w2[:E]), shared_w13=_cpu(w13[E]), shared_w2=_cpu(w2[E]))
+        kw.update(gate_w=_cpu(mlp.gate.weight), gate_bias=_cpu(mlp.gate.e_score_correction_bias))
+        if not getattr(mlp, "_bf16_freed", False):  # fp8 experts release their bf16 stacks; the oracle then uses `fp8` only
+            w13, w2 = mlp._stacked()
+            kw.update(w13=_cpu(w13[:E]), w2=_cpu(w2[:E]), shared_w13=_cpu(w13[E]), shared_w2=_cpu(w2[E]))
         if getattr(mlp, "expert_weight_dtype", None) == "fp8_e4m3":
-            if mlp._fp8 is None:
-                mlp.quantize_experts_fp8()
             q13, s13, q2, s2 = mlp._fp8  # uint8 views with a padded pitch -> contiguous float8 on the CPU
             f8 = lambda q: q.cpu().contiguous().view(torch.float8_e4m3fn)
             kw["fp8"] = (f8(q13), s13.cpu(), f8(q2), s2.cpu())

@@ -39,7 +39,7 @@ def test_binding_table_matches_header(lib_path):
     from nanovllm import hip_ops
     assert sorted(hip_ops.EXPORTED_SYMBOLS) == declared_symbols()
     lib = hip_ops.load_library(lib_path)
-    assert lib.glm_abi_version() == 7
+    assert lib.glm_abi_version() == 8
 
 
 def test_host_only_entry_points(lib_path):

@@ -579,6 +579,85 @@ def test_gemm_bf16_small_m(ops, M, N, K, bias):
     assert_close_bf16(out, ref, 1, 0.05, atol=2 ** -9, what=f"gemm {M}x{N}x{K}")
 
 
+# ---- single-sequence decode: the GEMV body (csrc/gemm_tinym.hip), T <= 2 -----------------------------------------------
+@pytest.mark.parametrize("M,N,K,bias", [
+    (1, 14336, 4096, True), (2, 14336, 4096, True), (1, 4096, 12288, False), (2, 4096, 12288, False),
+    (1, 4096, 1408, False), (2, 64, 136, True), (1, 151552 // 4, 4096, False), (2, 2052, 2056, True), (1, 8, 8, False)])
+def test_gemm_tinym_dense(ops, monkeypatch, M, N, K, bias):
+    """glm_gemm_bf16 at M <= 2 runs the GEMV body: vs the oracle (<= 1 bf16 ulp: fp32 summation order) and vs the small-M
+    MFMA kernel the same call takes with GLM4MOE_TINYM=0 (two fp32 evaluations of the same sum: <= 1 ulp apart)."""
+    x = rnd(M, K, seed=271)
+    w = rnd(N, K, seed=272, scale=K ** -0.5)
+    b = rnd(N, seed=273) if bias else None
+    ref = O.linear(x, w, b)
+    out = ops.gemm_bf16(dev(x), dev(w), dev(b))
+    assert_close_bf16(out, ref, 1, 0.05, atol=2 ** -9, what=f"tinym gemm {M}x{N}x{K}")
+    monkeypatch.setenv("GLM4MOE_TINYM", "0")
+    old = ops.gemm_bf16(dev(x), dev(w), dev(b))
+    assert_close_bf16(out, old, 1, 0.05, atol=2 ** -9, what=f"tinym vs small-M {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("T,E,k,H,I", [(1, 64, 8, 4096, 1408), (2, 64, 8, 4096, 1408), (2, 8, 2, 256, 96), (1, 128, 8, 512, 176)])
+def test_grouped_gemms_tinym(ops, monkeypatch, T, E, k, H, I):
+    """Grouped gate|up + SiLU.mul and down at T <= 2 (the few-token entry points): every row against the oracle's expert
+    arithmetic, and against the small-M kernels of the same call with GLM4MOE_TINYM=0."""
+    x = rnd(T, H, seed=281)
+    gw = rnd(E, H, seed=282, scale=H ** -0.5)
+    bias = (torch.rand(E, generator=torch.Generator().manual_seed(283)) * 0.2 - 0.1).float()
+    w13 = rnd(E + 1, 2 * I, H, seed=284, scale=H ** -0.5)
+    w2 = rnd(E + 1, H, I, seed=285, scale=I ** -0.5)
+    idx, w = ops.router_topk(dev(x), dev(gw), dev(bias), k, 1.0)
+    offs, tok, scale, pos = ops.moe_align(idx, w, E, True)
+    R = T * k + T
+    w13d, w2d = dev(w13), dev(w2)
+    act = ops.grouped_gemm_gateup_silu(dev(x), w13d, offs, tok, R, max_rows_per_group=T)
+    y = ops.grouped_gemm_down(act, w2d, offs, scale, E, max_rows_per_group=T)
+    monkeypatch.setenv("GLM4MOE_TINYM", "0")
+    act0 = ops.grouped_gemm_gateup_silu(dev(x), w13d, offs, tok, R, max_rows_per_group=T)
+    y0 = ops.grouped_gemm_down(act, w2d, offs, scale, E, max_rows_per_group=T)   # same input rows as the GEMV body's
+    torch.cuda.synchronize()
+    assert_close_bf16(act, act0, 3, 0.06, atol=2 ** -7, what="tinym act vs small-M")
+    assert_close_bf16(y, y0, 1, 0.05, atol=2 ** -9, what="tinym y vs small-M")
+    offs_c, tok_c, sc_c = offs.cpu(), tok.cpu(), scale.cpu()
+    for g in range(E + 1):
+        rows = slice(int(offs_c[g]), int(offs_c[g + 1]))
+        if rows.stop == rows.start:
+            continue
+        a_ref = O.silu_and_mul(O.linear(x[tok_c[rows].long()], w13[g]))
+        assert_close_bf16(act[rows].cpu(), a_ref, 3, 0.06, atol=2 ** -7, what=f"tinym act group {g}")
+        y_ref = O.linear(act[rows].cpu(), w2[g])
+        if g < E:
+            y_ref = (y_ref.float() * sc_c[rows].float().unsqueeze(1)).to(BF)
+        assert_close_bf16(y[rows].cpu(), y_ref, 1, 0.05, atol=2 ** -9, what=f"tinym y group {g}")
+
+
+@pytest.mark.parametrize("T,k,H,N,bias,drop", [(1, 8, 4096, 14336, True, False), (2, 8, 4096, 14336, True, False),
+                                               (2, 4, 1024, 264, False, True), (1, 2, 256, 64, True, False)])
+def test_combine_norm_qkv_one_launch(ops, T, k, H, N, bias, drop):
+    """glm_gemm_bf16_combine_norm == glm_moe_combine_add_rmsnorm followed by glm_gemm_bf16, bit for bit (T <= 2)."""
+    from nanovllm.hip_ops import DeferredCombine
+    R = T * k + T
+    y = rnd(R, H, seed=291, scale=2.0)
+    g = torch.Generator().manual_seed(292)
+    pos = torch.randperm(T * k, generator=g).view(T, k).to(torch.int32)
+    if drop:
+        pos[0, 1] = -1
+    res = rnd(T, H, seed=293)
+    nw = rnd(H, seed=294) * 0.1 + 1.0
+    w = rnd(N, H, seed=295, scale=H ** -0.5)
+    b = rnd(N, seed=296) if bias else None
+    yd, pd = dev(y), dev(pos.flatten().contiguous())
+    dc = DeferredCombine(yd, pd, T, k, T * k, (T, H))
+    xn, r0 = ops.moe_combine_add_rmsnorm(dc, dev(res), dev(nw), 1e-5)
+    q0 = ops.gemm_bf16(xn, dev(w), dev(b))
+    assert ops.can_combine_norm_gemm(dc, H)
+    for rep in range(3):  # a late weight prefetch or a race on the LDS row would show as a rare mismatch
+        q1, r1 = ops.combine_add_rmsnorm_gemm(dc, dev(res), dev(nw), 1e-5, dev(w), dev(b))
+        assert torch.equal(r0, r1), "residual_out differs"
+        assert torch.equal(q0, q1), "projection differs from norm launch + GEMV launch"
+    assert_close_bf16(q1, O.linear(xn.cpu(), w, b), 1, 0.05, atol=2 ** -9, what="fused qkv vs oracle")
+
+
 @pytest.mark.parametrize("M,N,K,want", [(32, 4096, 12288, 8), (5, 256, 1024, 3), (1, 64, 136, 2), (17, 512, 4096, 64)])
 def test_gemm_partial_and_fused_add_rmsnorm(ops, M, N, K, want):
     """K-slice partial sums + the add-RMSNorm that reduces them == linear -> add_rms_forward of the oracle."""
@@ -605,7 +684,10 @@ def test_gemm_partial_and_fused_add_rmsnorm(ops, M, N, K, want):
 
 
 @pytest.mark.parametrize("T,H,E,k,partial", [(32, 4096, 64, 8, False), (32, 4096, 64, 8, True), (5, 512, 16, 4, False),
-                                              (3, 8192, 128, 8, True), (130, 1024, 8, 2, False)])
+                                              (3, 8192, 128, 8, True), (130, 1024, 8, 2, False),
+                                              # one token: the selecting wave buckets, no ticket / bucketing pass (r03)
+                                              (1, 4096, 64, 8, False), (1, 4096, 64, 8, True), (1, 512, 16, 4, False),
+                                              (1, 2048, 128, 8, False), (1, 1024, 72, 3, False)])
 def test_fused_add_rmsnorm_router(ops, T, H, E, k, partial):
     """One launch == add_rmsnorm (or its partial-sum form) followed by router_topk, bit for bit."""
     g = torch.Generator().manual_seed(T + H + E)
@@ -970,10 +1052,13 @@ def test_in_launch_handoffs_under_repetition(ops):
 # ------------------------------------------------------------------------------------------
 # N3: one-shot all-reduce (opt-in; RCCL is the default path)
 def test_oneshot_allreduce_world1_and_two_streams(ops):
+    """Push-form one-shot all-reduce with the epoch in device memory.  world = 1; then two ranks emulated on ONE device
+    (each "rank" is a stream, the peer pointers are the other rank's buffers): 7 calls (odd: both slots are reused out
+    of phase), alternately one rank delayed by a long-running kernel in front of its call, so the early rank has to wait
+    for the late one's flag — and the late one finds a flag that is already there."""
     from nanovllm.distributed.oneshot_allreduce import OneShotAllReduce
     dev0 = torch.device("cuda", 0)
     n = 32 * 4096
-    # world = 1: the degenerate path (publish, signal self, sum of one buffer)
     ar = OneShotAllReduce(n, dev0, 0, 1)
     x = dev(rnd(32, 4096, seed=1101))
     ref = x.clone()
@@ -981,21 +1066,53 @@ def test_oneshot_allreduce_world1_and_two_streams(ops):
         y = x.clone()
         ar.all_reduce(y)
         assert torch.equal(y, ref)
-    assert ar.status() == 0
-    # two ranks emulated on ONE device: each "rank" is a stream, the peer pointers are the other rank's buffers.
-    # Both kernels must be resident together (64 workgroups each); every spin in the kernel is bounded.
+    assert ar.status() == 0 and ar.epoch() == 3
     a0, a1 = OneShotAllReduce(n, dev0, 0, 2), OneShotAllReduce(n, dev0, 1, 2)
     for a in (a0, a1):
         a.peer_bufs, a.peer_flags = [a0.buf, a1.buf], [a0.flags, a1.flags]
     s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
-    for rep in range(6):
+    big = torch.randn(4096, 4096, device=dev0)
+    for rep in range(7):
         x0, x1 = dev(rnd(32, 4096, seed=1200 + rep)), dev(rnd(32, 4096, seed=1300 + rep))
         exp = (x0.float() + x1.float()).to(BF)
         torch.cuda.synchronize()
+        with torch.cuda.stream(s0):
+            if rep % 3 == 1:
+                (big @ big).sum()   # rank 0 arrives late
+            a0.all_reduce(x0)
+        with torch.cuda.stream(s1):
+            if rep % 3 == 2:
+                (big @ big).sum()   # rank 1 arrives late
+            a1.all_reduce(x1)
+        torch.cuda.synchronize()
+        assert a0.status() == 0 and a1.status() == 0, "a rank gave up waiting (the two kernels did not overlap?)"
+        assert torch.equal(x0, exp) and torch.equal(x1, exp), f"rep {rep}"
+    assert a0.epoch() == 7 and a1.epoch() == 7
+    # smaller tensors reuse the same slots
+    for rep in range(3):
+        x0, x1 = dev(rnd(2, 4096, seed=1400 + rep)), dev(rnd(2, 4096, seed=1500 + rep))
+        exp = (x0.float() + x1.float()).to(BF)
         with torch.cuda.stream(s0):
             a0.all_reduce(x0)
         with torch.cuda.stream(s1):
             a1.all_reduce(x1)
         torch.cuda.synchronize()
-        assert a0.status() == 0 and a1.status() == 0, "a rank gave up waiting (the two kernels did not overlap?)"
-        assert torch.equal(x0, exp) and torch.equal(x1, exp), f"rep {rep}"
+        assert torch.equal(x0, exp) and torch.equal(x1, exp)
+
+
+def test_oneshot_allreduce_missing_peer_is_loud(ops):
+    """A peer that never arrives: the bounded wait expires, the output is NaN (never stale data), status names the rank,
+    check() raises — and the epoch still advances so a later call pairs up again."""
+    from nanovllm.distributed.oneshot_allreduce import OneShotAllReduce
+    dev0 = torch.device("cuda", 0)
+    n = 8 * 1024
+    a0, a1 = OneShotAllReduce(n, dev0, 0, 2), OneShotAllReduce(n, dev0, 1, 2)
+    for a in (a0, a1):
+        a.peer_bufs, a.peer_flags = [a0.buf, a1.buf], [a0.flags, a1.flags]
+    x0 = dev(rnd(8, 1024, seed=1600))
+    a0.all_reduce(x0)          # rank 1 never calls
+    torch.cuda.synchronize()
+    assert a0.status() == 2 and bool(torch.isnan(x0.float()).all())
+    with pytest.raises(RuntimeError, match="gave up waiting for rank 1"):
+        a0.check()
+    assert a0.epoch() == 1

@@ -169,6 +169,10 @@ def test_moe_module_fp8_experts():
     ref = O.moe_fp8w(t["x"], cfg["num_experts_per_tok"], captured["idx"].cpu(), captured["w"].cpu(),
                      q13[:E], s13[:E], q2[:E], s2[:E], q13[E], s13[E], q2[E], s2[E])
     _mixed(out, ref, "fp8-expert MoE module")
+    # the bf16 stacks are gone once the fp8 copies exist (0.5x expert memory, not 1.5x)
+    assert moe._w13 is None and moe._w2 is None and moe.experts[0].gate_up_proj.weight.numel() == 0
+    with pytest.raises(RuntimeError, match="released"):
+        moe._stacked()
     # and close to the bf16 golden within fp8 quantisation error
     rel = float((out.cpu().float() - t["y"].float()).norm() / t["y"].float().norm())
     assert rel < 0.08, rel
