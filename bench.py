@@ -113,8 +113,8 @@ def main():
                          "intermediate size and vocabulary divided by N) without any collective; not a benchmark result")
     ap.add_argument("--expert-parallel", action="store_true",
                     help="BASELINE config 4 flavour: the experts are partitioned over the ranks (E/N each, full intermediate "
-                         "size) and token rows travel by all-to-all-v; attention stays tensor-parallel.  Eager launches "
-                         "(the split sizes are host integers).  The headline run is the default (TP only)")
+                         "size) and token rows travel by an all-to-all of fixed-capacity slots planned on the device "
+                         "(graph-capturable); attention stays tensor-parallel.  The headline run is the default (TP only)")
     ap.add_argument("--probe-capture", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--graph-body-only", action="store_true",
                     help="debug: at 1 GPU, capture only the layer stack and run the lm_head eagerly (the TP>1 arrangement)")
@@ -177,8 +177,7 @@ def main():
     if args.fp8_experts:
         cfg.expert_weight_dtype = "fp8_e4m3"
     if args.expert_parallel and world > 1:
-        cfg.expert_parallel_size = world
-        args.no_graph = True
+        cfg.expert_parallel_size = world  # fixed-capacity dispatch (no host read): captured like the TP step
     torch.set_default_dtype(torch.bfloat16)
     t0 = time.time()
     with torch.device(dev):

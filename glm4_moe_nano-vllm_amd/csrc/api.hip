@@ -45,7 +45,7 @@ bool tinym_enabled() {
 
 int dispatch(int mode, const GemmParams& p, hipStream_t st) {
     if (p.R <= 0) return GLM_OK;
-    const int64_t avg = p.R / (p.G > 0 ? p.G : 1);
+    const int64_t avg = (p.R_hint > 0 ? p.R_hint : p.R) / (p.G > 0 ? p.G : 1);
     if (avg >= LARGEM_MIN_AVG_ROWS) return glm_launch_gemm_largem(mode, p, st);
     return glm_launch_gemm_smallm(mode, p, st);
 }
@@ -63,7 +63,10 @@ extern "C" int glm_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t 
     p.bias = (const bf16_t*)bias;
     p.y = (bf16_t*)y; p.ldy = ldy;
     p.R = M; p.N = N; p.K = K; p.G = 1;
-    if (M >= 1 && M <= glm_tinym_max_rows() && tinym_enabled()) {  // single-sequence decode: the GEMV body
+    // single-sequence decode: the GEMV body.  Two rows keep the small-M MFMA kernels (tools/tinym_probe.py, r03: QKV 26.0
+    // vs 21.8 us, grouped down 41.4 vs 34.7 us at T = 2 — the FMA stream of two rows needs half the bytes in flight per
+    // register); the fused combine + norm + QKV launch below takes T = 2 too, where it still saves a whole launch.
+    if (M == 1 && tinym_enabled()) {
         const int rc = glm_launch_gemm_tinym(GEMM_PLAIN, p, (int)M, glm_s(stream));
         if (rc != GLM_ERR_UNSUPPORTED) return rc;
     }
@@ -133,7 +136,7 @@ extern "C" int glm_grouped_gemm_gateup_silu_fewtok(const void* x, int64_t ldx, i
                                                    const int32_t* expert_offsets, const int32_t* sorted_token,
                                                    void* act, int64_t R, int H, int I, int G, glm_stream_t stream) {
     GLM_CHECK_ARG(T >= 1 && expert_offsets != nullptr, GLM_ERR_INVALID, "glm_grouped_gemm_gateup_silu_fewtok: bad arguments");
-    if (T <= glm_tinym_max_rows() && tinym_enabled() && x && w13 && act && R > 0 && H > 0 && I > 0 && G >= 1 && ldx >= H &&
+    if (T == 1 && tinym_enabled() && x && w13 && act && R > 0 && H > 0 && I > 0 && G >= 1 && ldx >= H &&
         w13_row_stride >= H) {
         GemmParams p;
         memset(&p, 0, sizeof(p));
@@ -177,7 +180,7 @@ extern "C" int glm_grouped_gemm_down_fewtok(const void* act, int64_t T, const vo
                                             const void* sorted_scale, int n_scaled_groups, void* y, int64_t ldy,
                                             int64_t R, int H, int I, int G, glm_stream_t stream) {
     GLM_CHECK_ARG(T >= 1 && expert_offsets != nullptr, GLM_ERR_INVALID, "glm_grouped_gemm_down_fewtok: bad arguments");
-    if (T <= glm_tinym_max_rows() && tinym_enabled() && act && w2 && y && R > 0 && H > 0 && I > 0 && G >= 1 && ldy >= H &&
+    if (T == 1 && tinym_enabled() && act && w2 && y && R > 0 && H > 0 && I > 0 && G >= 1 && ldy >= H &&
         w2_row_stride >= I && (n_scaled_groups == 0 || sorted_scale != nullptr)) {
         GemmParams p;
         memset(&p, 0, sizeof(p));
@@ -192,6 +195,47 @@ extern "C" int glm_grouped_gemm_down_fewtok(const void* act, int64_t T, const vo
     }
     return glm_grouped_gemm_down(act, w2, w2_group_stride, w2_row_stride, expert_offsets, sorted_scale, n_scaled_groups, y,
                                  ldy, R, H, I, G, stream);
+}
+
+// Fixed-capacity expert-parallel buffers (glm_ep_plan): the row arrays are sized for the worst case, expert_offsets say
+// how many rows are real.  R_cap sizes the grid (surplus workgroups find no block and leave), R_expected picks the kernel
+// configuration the real row count would get.
+extern "C" int glm_grouped_gemm_gateup_silu_cap(const void* x, int64_t ldx, const void* w13, int64_t w13_group_stride,
+                                                int64_t w13_row_stride, const int32_t* expert_offsets,
+                                                const int32_t* sorted_token, void* act, int64_t R_cap, int64_t R_expected,
+                                                int H, int I, int G, glm_stream_t stream) {
+    GLM_CHECK_ARG(x && w13 && act && expert_offsets, GLM_ERR_INVALID, "glm_grouped_gemm_gateup_silu_cap: null pointer");
+    GLM_CHECK_ARG(R_cap >= 0 && R_expected >= 0 && H > 0 && I > 0 && G >= 1 && ldx >= H && w13_row_stride >= H &&
+                      (G == 1 || w13_group_stride >= (int64_t)2 * I * w13_row_stride),
+                  GLM_ERR_INVALID, "glm_grouped_gemm_gateup_silu_cap: bad shape");
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)x; p.ldx = ldx;
+    p.w = (const bf16_t*)w13; p.w_gstride = w13_group_stride; p.ldw = w13_row_stride;
+    p.offs = expert_offsets; p.src = sorted_token;
+    p.y = (bf16_t*)act; p.ldy = I;
+    p.R = R_cap; p.R_hint = R_expected > 0 ? R_expected : 1; p.N = I; p.K = H; p.G = G;
+    return dispatch(GEMM_GATEUP, p, glm_s(stream));
+}
+
+extern "C" int glm_grouped_gemm_down_cap(const void* act, const void* w2, int64_t w2_group_stride, int64_t w2_row_stride,
+                                         const int32_t* expert_offsets, const void* sorted_scale, int n_scaled_groups,
+                                         void* y, int64_t ldy, int64_t R_cap, int64_t R_expected, int H, int I, int G,
+                                         glm_stream_t stream) {
+    GLM_CHECK_ARG(act && w2 && y && expert_offsets, GLM_ERR_INVALID, "glm_grouped_gemm_down_cap: null pointer");
+    GLM_CHECK_ARG(R_cap >= 0 && R_expected >= 0 && H > 0 && I > 0 && G >= 1 && ldy >= H && w2_row_stride >= I &&
+                      (G == 1 || w2_group_stride >= (int64_t)H * w2_row_stride) &&
+                      (n_scaled_groups == 0 || sorted_scale != nullptr),
+                  GLM_ERR_INVALID, "glm_grouped_gemm_down_cap: bad shape");
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)act; p.ldx = I;
+    p.w = (const bf16_t*)w2; p.w_gstride = w2_group_stride; p.ldw = w2_row_stride;
+    p.offs = expert_offsets;
+    p.scale = (const bf16_t*)sorted_scale; p.n_scaled = n_scaled_groups;
+    p.y = (bf16_t*)y; p.ldy = ldy;
+    p.R = R_cap; p.R_hint = R_expected > 0 ? R_expected : 1; p.N = H; p.K = I; p.G = G;
+    return dispatch(GEMM_DOWN, p, glm_s(stream));
 }
 
 extern "C" int glm_grouped_gemm_gateup_silu_fp8w(const void* x, int64_t ldx, const void* w13_q,

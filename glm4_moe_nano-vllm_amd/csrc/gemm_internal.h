@@ -22,7 +22,9 @@ struct GemmParams {
     const bf16_t* bias;   // [N] (GEMM_PLAIN) or nullptr
     bf16_t* y;            // [R, N] rows at y + r*ldy
     int64_t ldy;
-    int64_t R;            // total rows (all groups)
+    int64_t R;            // total rows (all groups); with offs: an UPPER BOUND is enough (it sizes the grid, offs decide)
+    int64_t R_hint;       // 0, or the row count to pick the kernel configuration by when R is a loose bound (fixed-capacity
+                          // expert-parallel buffers: R = capacity, R_hint = the expected rows)
     int N;                // output columns (GATEUP: I = act columns; W then has 2I rows)
     int K;
     int G;                // number of groups

@@ -1225,7 +1225,7 @@ template <int MODE>
 int launch_largem(const GemmParams& p, hipStream_t st) {
     // 256-row blocks pay off once a group fills most of one; smaller groups keep the 128-row tile
     const int ch = cfg_choice();
-    const int64_t avg_rows = p.R / (p.G > 0 ? p.G : 1);
+    const int64_t avg_rows = (p.R_hint > 0 ? p.R_hint : p.R) / (p.G > 0 ? p.G : 1);
     // ... and a projection onto <= 128 columns (the router logits at prefill: N = E = 64) is one column tile however the rows
     // are cut, so its parallelism is its row-block count: 128-row blocks (75.8 -> 55.1 us at T = 16384)
     const bool use_b = ch == 2 || (ch == 0 && avg_rows >= 192 && !(MODE == GEMM_PLAIN && p.offs == nullptr && p.N <= 128));

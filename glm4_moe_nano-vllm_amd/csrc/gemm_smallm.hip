@@ -962,6 +962,7 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
                   GLM_ERR_UNSUPPORTED,
                   "gemm_smallm: needs K%%8==0, N%%4==0, ldx/ldw%%8==0, ldy%%4==0, 16B-aligned x/W (K=%d N=%d)",
                   p.K, p.N);
+    const int64_t Rs = p.R_hint > 0 ? p.R_hint : p.R;  // the configuration is chosen by the expected rows, the grid by p.R
     // grouped experts: 32-row blocks (at decode batch sizes only the shared expert ever fills one;
     // a group with more rows re-reads its weights once per extra block)
     // (waves, K-split waves, row tiles per wave, max 16-row activation tiles).  Same-box sweep at the C3 decode shape
@@ -989,7 +990,7 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
 #define GLM_SM_DMA_MIN_ROWS 17  // total rows from which the grouped projections take the LDS-DMA body
 #endif
 #ifdef GLM_SM_DMA_GATEUP
-    if (mode == GEMM_GATEUP && p.R >= GLM_SM_DMA_MIN_ROWS) return launch_cfg_dma<GEMM_GATEUP, GLM_SM_DMA_GATEUP>(p, st);
+    if (mode == GEMM_GATEUP && Rs >= GLM_SM_DMA_MIN_ROWS) return launch_cfg_dma<GEMM_GATEUP, GLM_SM_DMA_GATEUP>(p, st);
 #endif
 #if !defined(GLM_SM_NO_DMA) && !defined(GLM_SM_DMA_DOWN)
 #define GLM_SM_DMA_DOWN 1, 1, 2, 2  // one-wave workgroups (32 KiB of LDS each): 122 -> 115 us; 4,1,2,2 and 2,1,2,2: 116-117
@@ -1001,7 +1002,7 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
 #ifndef GLM_SM_DMA_DOWN_DENSE
 #define GLM_SM_DMA_DOWN_DENSE 4, 4, 1, 2
 #endif
-    if (mode == GEMM_DOWN && p.G == 1 && p.R >= GLM_SM_DMA_MIN_ROWS && p.K >= 4096) return launch_cfg_dma<GEMM_DOWN, GLM_SM_DMA_DOWN_DENSE>(p, st);
+    if (mode == GEMM_DOWN && p.G == 1 && Rs >= GLM_SM_DMA_MIN_ROWS && p.K >= 4096) return launch_cfg_dma<GEMM_DOWN, GLM_SM_DMA_DOWN_DENSE>(p, st);
 #endif
     // a K of one or two chunks (TP=8 shard: 176) leaves the ring nothing to overlap: 37 vs 31 us for the VGPR body
     // few rows per group (bs=32: 4.4 on average): 16-row blocks in two-wave workgroups — 24 KiB of LDS per wave, six waves
@@ -1010,9 +1011,9 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
 #ifndef GLM_SM_DMA_DOWN_FEWROWS
 #define GLM_SM_DMA_DOWN_FEWROWS 2, 1, 2, 1
 #endif
-    if (mode == GEMM_DOWN && p.R >= GLM_SM_DMA_MIN_ROWS && p.K >= 512 && p.G > 1 && p.R <= 6 * (int64_t)p.G)
+    if (mode == GEMM_DOWN && Rs >= GLM_SM_DMA_MIN_ROWS && p.K >= 512 && p.G > 1 && Rs <= 6 * (int64_t)p.G)
         return launch_cfg_dma<GEMM_DOWN, GLM_SM_DMA_DOWN_FEWROWS>(p, st);
-    if (mode == GEMM_DOWN && p.R >= GLM_SM_DMA_MIN_ROWS && p.K >= 512) return launch_cfg_dma<GEMM_DOWN, GLM_SM_DMA_DOWN>(p, st);
+    if (mode == GEMM_DOWN && Rs >= GLM_SM_DMA_MIN_ROWS && p.K >= 512) return launch_cfg_dma<GEMM_DOWN, GLM_SM_DMA_DOWN>(p, st);
 #endif
 #ifndef GLM_SM_CFG_GATEUP_R16
 #define GLM_SM_CFG_GATEUP_R16 4, 1, 2, 2
@@ -1020,8 +1021,8 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st) {
 #ifndef GLM_SM_CFG_DOWN_R16
 #define GLM_SM_CFG_DOWN_R16 2, 1, 2, 2  // single sequence (9 groups): 25.7 us (4,2,1,2: 27.8; 4,1,1,2: 25.9; 8,1,1,2: 30.3; r02 sweep)
 #endif
-    if (mode == GEMM_GATEUP && p.R <= 16) return launch_cfg<GEMM_GATEUP, GLM_SM_CFG_GATEUP_R16>(p, st);
-    if (mode == GEMM_DOWN && p.R <= 16) return launch_cfg<GEMM_DOWN, GLM_SM_CFG_DOWN_R16>(p, st);
+    if (mode == GEMM_GATEUP && Rs <= 16) return launch_cfg<GEMM_GATEUP, GLM_SM_CFG_GATEUP_R16>(p, st);
+    if (mode == GEMM_DOWN && Rs <= 16) return launch_cfg<GEMM_DOWN, GLM_SM_CFG_DOWN_R16>(p, st);
     if (mode == GEMM_GATEUP) return launch_cfg<GEMM_GATEUP, GLM_SM_CFG_GATEUP>(p, st);
     if (mode == GEMM_DOWN) return launch_cfg<GEMM_DOWN, GLM_SM_CFG_DOWN>(p, st);
     // dense projection: choose the K-split so that the grid covers the chip

@@ -1,5 +1,5 @@
-// gemm_tinym.hip — weight-streaming GEMV for ONE or TWO token rows per weight matrix: the greedy single-sequence decode of
-// BASELINE config 2 (bs = 1, and the bs = 2 graph bucket).  Same operators as gemm_smallm.hip (a5/a10 dense projections,
+// gemm_tinym.hip — weight-streaming GEMV for ONE token row per weight matrix (two in the fused QKV launch): the greedy
+// single-sequence decode of BASELINE config 2 (bs = 1).  Same operators as gemm_smallm.hip (a5/a10 dense projections,
 // a12/a13 grouped expert gate|up + SiLU·mul and down), same rounding points, gfx950 only.
 //
 // Why a second body: with one token row the MFMA tile of gemm_smallm is 1/16 used and, worse, its workgroups are short
@@ -350,10 +350,10 @@ bool tiny_shape_ok(int mode, const GemmParams& p) {
 
 }  // namespace
 
-// rows per group block this body handles; grouped launches: every group has at most that many rows (T <= 2 tokens)
+// rows the fused combine + norm + projection launch takes (the plain and grouped launches take ONE row: api.hip)
 int glm_tinym_max_rows() { return 2; }
 
-// n_tokens: grouped gate|up only — rows of x (the tokens) to keep in LDS
+// One token row per weight matrix / per expert group (T = 1).  n_tokens: rows of x (grouped gate|up), must be 1.
 int glm_launch_gemm_tinym(int mode, const GemmParams& p, int n_tokens, hipStream_t st) {
     if (!tiny_shape_ok(mode, p) || (p.offs != nullptr && p.G > TM_MAXG)) {
         glm_set_error("gemm_tinym: shape not covered (mode %d K=%d N=%d G=%d)", mode, p.K, p.N, p.G);
@@ -364,22 +364,12 @@ int glm_launch_gemm_tinym(int mode, const GemmParams& p, int n_tokens, hipStream
     tp.g = p;
     tp.n_tokens = n_tokens;
     const int M = mode == GEMM_PLAIN ? (int)p.R : n_tokens;
-    GLM_CHECK_ARG(M >= 1 && M <= 2, GLM_ERR_UNSUPPORTED, "gemm_tinym: %d rows per block", M);
-    // units: 4 rows x 4 KiB for long rows (2 KiB with two token rows: registers); a short K (expert down projection, 1408) as ONE unit of 3 KiB rows
-    if (mode == GEMM_PLAIN) {
-        if (M == 1) return launch_tiny<GEMM_PLAIN, 1, 4, false>(tp, 1, st);
-        return launch_tiny<GEMM_PLAIN, 2, 2, false>(tp, 2, st);
-    }
-    if (mode == GEMM_GATEUP) {
-        if (M == 1) return launch_tiny<GEMM_GATEUP, 1, 4, false>(tp, n_tokens, st);
-        return launch_tiny<GEMM_GATEUP, 2, 2, false>(tp, n_tokens, st);
-    }
-    if (p.K <= 1536) {
-        if (M == 1) return launch_tiny<GEMM_DOWN, 1, 3, false>(tp, (int)p.R, st);
-        return launch_tiny<GEMM_DOWN, 2, 3, false>(tp, (int)p.R, st);
-    }
-    if (M == 1) return launch_tiny<GEMM_DOWN, 1, 4, false>(tp, (int)p.R, st);
-    return launch_tiny<GEMM_DOWN, 2, 2, false>(tp, (int)p.R, st);
+    GLM_CHECK_ARG(M == 1, GLM_ERR_UNSUPPORTED, "gemm_tinym: %d rows per block", M);
+    // units: 4 rows x 4 KiB for long rows; a short K (expert down projection, 1408) as ONE unit of 3-KiB rows
+    if (mode == GEMM_PLAIN) return launch_tiny<GEMM_PLAIN, 1, 4, false>(tp, 1, st);
+    if (mode == GEMM_GATEUP) return launch_tiny<GEMM_GATEUP, 1, 4, false>(tp, n_tokens, st);
+    if (p.K <= 1536) return launch_tiny<GEMM_DOWN, 1, 3, false>(tp, (int)p.R, st);
+    return launch_tiny<GEMM_DOWN, 1, 4, false>(tp, (int)p.R, st);
 }
 
 // QKV projection (+bias) of T <= 2 rows whose input is computed in the kernel: moe_combine of the previous layer's expert

@@ -1210,6 +1210,126 @@ extern "C" int glm_scatter_rows(const void* src, int64_t ld_src, void* dst, int6
     return permute_rows(src, ld_src, dst, ld_dst, idx, n, cols, true, stream, "glm_scatter_rows");
 }
 
+// ------------------------------------------------------------------------------------------
+// Expert-parallel dispatch plan with FIXED-capacity slots (N3 / BASELINE config 4, graph-capturable): everything the
+// all-to-all needs, computed on the device from the replicated routing — no count exchange, no host read.
+//   ranks: rank r owns experts [r El, (r+1) El), El = E / ep, and the token slice [r per, min(T, (r+1) per)), per = ceil(T/ep).
+//   send buffer of a rank: [ep destinations][cap rows]; the rows for destination d sit at the head of slot d in
+//   (expert ascending, then pair index ascending) order.  The all-to-all moves whole slots (equal splits), so the
+//   receive buffer is [ep sources][cap rows] with source s's rows for MY experts at the head of slot s, in that order.
+// One 1024-thread workgroup (the routing of a decode step is a few thousand pairs):
+//   send_gather[ep*cap]  row of the FULL hidden-state matrix to copy into each send slot row, -1 = unused
+//   slot_scale [ep*cap]  routing weight of the pair in that slot row (bf16; unused rows untouched)
+//   pair_slot  [Tl*k]    slot row of pair (t - lo, j): where its expert output comes back to after the return trip
+//   recv_offs  [El+1]    rows per local expert over all sources (prefix sums): expert_offsets of the grouped GEMMs
+//   recv_gidx  [ep*cap]  receive-buffer row of expert-ordered row i (sorted_token of gate|up, scatter index on the way
+//                        back), -1 beyond recv_offs[El]
+//   overflow   [1]       max over (source, destination) of the row count when it exceeds cap, else 0 (cap = Tl *
+//                        min(k, El) can never overflow; a smaller cap is the caller's bet)
+namespace {
+constexpr int EP_MAX_PAIRS = 32768;
+constexpr int EP_MAX_BINS = 2048;  // ep * E
+__global__ __launch_bounds__(1024) void ep_plan_kernel(const int64_t* __restrict__ topk_idx, const bf16_t* __restrict__ topk_w,
+                                                       int T, int k, int E, int ep, int rank, int cap,
+                                                       int32_t* __restrict__ send_gather, bf16_t* __restrict__ slot_scale,
+                                                       int32_t* __restrict__ pair_slot, int32_t* __restrict__ recv_offs,
+                                                       int32_t* __restrict__ recv_gidx, int32_t* __restrict__ overflow) {
+    __shared__ int cnt[EP_MAX_BINS];        // [source][expert] pair counts
+    __shared__ unsigned short eidx[EP_MAX_PAIRS / 2];  // my slice's expert ids (<= 16384 pairs per slice)
+    __shared__ int ovf;
+    const int tid = threadIdx.x;
+    const int El = E / ep, per = (T + ep - 1) / ep;
+    const int lo = min(T, rank * per), hi = min(T, lo + per), Tl = hi - lo;
+    for (int i = tid; i < ep * E; i += 1024) cnt[i] = 0;
+    for (int i = tid; i < ep * cap; i += 1024) {
+        send_gather[i] = -1;
+        recv_gidx[i] = -1;
+    }
+    if (tid == 0) ovf = 0;
+    __syncthreads();
+    const int P = T * k;
+    for (int p = tid; p < P; p += 1024) {
+        const int e = (int)topk_idx[p];
+        const int t = p / k;
+        if (e >= 0 && e < E) atomicAdd(&cnt[(t / per) * E + e], 1);
+        if (t >= lo && t < hi) eidx[p - lo * k] = (unsigned short)(e >= 0 && e < E ? e : 0xffff);
+    }
+    __syncthreads();
+    // ---- send side: thread e walks my slice's pairs in order and hands out the rows of expert e ----
+    if (tid < E) {
+        const int e = tid, d = e / El;
+        int base = 0;
+        for (int e2 = d * El; e2 < e; ++e2) base += cnt[rank * E + e2];
+        int n = 0;
+        for (int p = 0; p < Tl * k; ++p) {
+            if (eidx[p] != e) continue;
+            const int within = base + n++;
+            if (within < cap) {
+                const int slot = d * cap + within;
+                send_gather[slot] = lo + p / k;
+                slot_scale[slot] = topk_w[(int64_t)lo * k + p];
+                pair_slot[p] = slot;
+            } else {
+                pair_slot[p] = -1;  // dropped (only with a capacity below the worst case); overflow reports it
+            }
+        }
+    }
+    // pairs with an invalid expert id never get a slot
+    for (int p = tid; p < Tl * k; p += 1024)
+        if (eidx[p] == 0xffff) pair_slot[p] = -1;
+    // ---- capacity check: rows of every (source, destination) pair ----
+    for (int i = tid; i < ep * ep; i += 1024) {
+        const int s = i / ep, d = i % ep;
+        int n = 0;
+        for (int e2 = d * El; e2 < (d + 1) * El; ++e2) n += cnt[s * E + e2];
+        if (n > cap) atomicMax(&ovf, n);
+    }
+    // ---- receive side: rows of (source s, local expert el) that fit = what the sender really put into its slot ----
+    __shared__ int within_t[1024], fit_t[1024];  // [s * El + el]
+    if (tid < ep * El) {
+        const int s = tid / El, el = tid % El;
+        int within = 0;
+        for (int e3 = 0; e3 < el; ++e3) within += cnt[s * E + rank * El + e3];
+        within_t[tid] = within;
+        fit_t[tid] = max(0, min(cnt[s * E + rank * El + el], cap - within));
+    }
+    __syncthreads();
+    // thread el lists, source by source, where its rows land in the receive buffer (expert-major order)
+    if (tid < El) {
+        int start = 0;  // rows of the local experts before this one, over all sources
+        for (int e2 = 0; e2 < tid; ++e2)
+            for (int s = 0; s < ep; ++s) start += fit_t[s * El + e2];
+        recv_offs[tid] = start;
+        int row = start;
+        for (int s = 0; s < ep; ++s) {
+            const int n = fit_t[s * El + tid], w0 = within_t[s * El + tid];
+            for (int i = 0; i < n; ++i) recv_gidx[row++] = s * cap + w0 + i;
+        }
+        if (tid == El - 1) recv_offs[El] = row;
+    }
+    __syncthreads();
+    if (tid == 0) overflow[0] = ovf;
+}
+}  // namespace
+
+extern "C" int glm_ep_plan(const int64_t* topk_idx, const void* topk_w, int64_t T, int k, int E, int ep, int rank, int cap,
+                           int32_t* send_gather, void* slot_scale, int32_t* pair_slot, int32_t* recv_offs,
+                           int32_t* recv_gidx, int32_t* overflow, glm_stream_t stream) {
+    GLM_CHECK_ARG(topk_idx && topk_w && send_gather && slot_scale && pair_slot && recv_offs && recv_gidx && overflow,
+                  GLM_ERR_INVALID, "glm_ep_plan: null pointer");
+    GLM_CHECK_ARG(T >= 1 && k >= 1 && E >= 1 && ep >= 1 && rank >= 0 && rank < ep && E % ep == 0 && cap >= 1,
+                  GLM_ERR_INVALID, "glm_ep_plan: bad arguments (T=%ld k=%d E=%d ep=%d rank=%d cap=%d)", (long)T, k, E, ep, rank, cap);
+    const int64_t per = (T + ep - 1) / ep;
+    GLM_CHECK_ARG(E <= 1024 && (int64_t)ep * E <= EP_MAX_BINS && T * k <= 0x7fffffff && per * k <= EP_MAX_PAIRS / 2 &&
+                      (int64_t)ep * cap <= 0x7fffffff,
+                  GLM_ERR_UNSUPPORTED, "glm_ep_plan: needs ep*E <= %d and ceil(T/ep)*k <= %d (decode-sized steps)", EP_MAX_BINS,
+                  EP_MAX_PAIRS / 2);
+    hipLaunchKernelGGL(ep_plan_kernel, dim3(1), dim3(1024), 0, glm_s(stream), topk_idx, (const bf16_t*)topk_w, (int)T, k, E, ep,
+                       rank, cap, send_gather, (bf16_t*)slot_scale, pair_slot, recv_offs, recv_gidx, overflow);
+    GLM_CHECK_LAUNCH("glm_ep_plan");
+    return GLM_OK;
+}
+
 extern "C" int glm_moe_combine_add_rmsnorm(const void* y, int64_t ldy, const int32_t* pair_pos, int64_t T, int k, int H,
                                            int64_t shared_base, const void* residual_in, const void* weight,
                                            void* out, void* residual_out, float eps, glm_stream_t stream) {

@@ -23,10 +23,21 @@ Layout, ep ranks (= the TP group):
 
 The forward is written as a GENERATOR that yields at every collective.  `run` drives it with torch.distributed (RCCL,
 or gloo in the CPU tests); `run_emulated` drives the generators of several logical ranks in lockstep inside one process
-(the one-GPU rehearsal and the "EP=2 == TP=1" test).  The split sizes of the all-to-all-v are host integers, so this
-path syncs once per MoE block and runs eagerly; a graph-capturable fixed-capacity variant is future work.
+(the one-GPU rehearsal and the "EP=2 == TP=1" test).
+
+Two dispatch forms, same arithmetic, same results:
+  * FIXED CAPACITY (r03; the default at decode sizes, graph-capturable): the routing is replicated, so every rank can
+    compute the whole exchange plan on the device (glm_ep_plan: send slots, receive-side expert offsets and gather list)
+    — no count all-gather, no host read.  The all-to-all moves equal, capacity-sized slots ([ep][cap] rows, cap = rows
+    per token slice x min(k, experts per rank): the worst case, overflow impossible); the grouped GEMMs run over the
+    capacity-sized receive buffer with expert_offsets saying which rows are real.  Three collectives per MoE block
+    (all-to-all, all-to-all, all-gather), all with static shapes.
+  * VARIABLE SPLITS (`forward_varlen`, prefill-sized steps and GLM_EP_FIXED=0): all-to-all-v with exact row counts; the
+    split sizes are host integers, so this form reads the count matrix once per MoE block and runs eagerly.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.distributed as dist
@@ -49,9 +60,53 @@ class EPExperts:
         self.El = n_experts // ep_size
         self.w13, self.w2, self.shared = w13, w2, shared
 
+    FIXED_MAX_SLICE_PAIRS = 16384  # glm_ep_plan keeps a token slice's pairs in LDS
+
+    def capacity(self, T: int) -> int:
+        """Rows per (source, destination) slot that can never overflow: every token of a slice sends at most
+        min(k, experts per rank) rows to one rank."""
+        per = (T + self.ep - 1) // self.ep
+        return max(1, per * min(self.k, self.El))
+
     def forward(self, h: torch.Tensor, topk_idx: torch.Tensor, topk_w: torch.Tensor):
         """Generator.  h [T, H] (replicated), routing of ALL T tokens (replicated, identical on every rank).
         Yields (op, payload...) tuples at the collectives, finally returns the full [T, H] output."""
+        T = h.shape[0]
+        per = (T + self.ep - 1) // self.ep
+        fixed = (hasattr(self.ops, "ep_plan") and os.environ.get("GLM_EP_FIXED", "1") != "0"
+                 and per * self.k <= self.FIXED_MAX_SLICE_PAIRS and self.ep * self.E <= 2048)
+        return (yield from (self.forward_fixed if fixed else self.forward_varlen)(h, topk_idx, topk_w))
+
+    def forward_fixed(self, h: torch.Tensor, topk_idx: torch.Tensor, topk_w: torch.Tensor):
+        """Fixed-capacity dispatch: no host synchronisation anywhere (HIP-graph capturable with captured collectives)."""
+        ops, ep, E, El, k = self.ops, self.ep, self.E, self.El, self.k
+        T, H = h.shape
+        lo, hi = token_slice(T, ep, self.rank)
+        Tl = hi - lo
+        cap = self.capacity(T)
+        send_gather, slot_scale, pair_slot, recv_offs, recv_gidx, _overflow = ops.ep_plan(
+            topk_idx.contiguous(), topk_w.contiguous(), E, ep, self.rank, cap)
+        # 1. my pairs' rows into their slots (unused slot rows stay uninitialised: nobody reads them)
+        send = ops.gather_rows(h, send_gather)                                  # [ep * cap, H]
+        recv = yield ("all_to_all_fixed", send, cap)                            # slot s = the rows rank s sent me
+        # 2. my experts over the received rows, in expert order through the gather list; rows beyond recv_offs[El] are
+        #    not touched.  The kernel configuration is chosen for the expected row count (T k / ep), not for the capacity.
+        expected = max(1, (T * k + ep - 1) // ep)
+        act = ops.grouped_gemm_gateup_silu_cap(recv, self.w13, recv_offs, recv_gidx, ep * cap, expected)
+        y = ops.grouped_gemm_down_cap(act, self.w2, recv_offs, expected)        # unscaled: the weight is applied at home
+        back = ops.scatter_rows(y, recv_gidx, ep * cap, no_init=True)           # expert order -> arrival slots
+        ret = yield ("all_to_all_fixed", back, cap)                             # slot d = my rows back from rank d
+        # 3. routing weights, ascending-expert combine, shared expert; then everyone gets every slice
+        if Tl > 0:
+            out_l = ops.moe_combine_scaled(ret, pair_slot, slot_scale, self.shared(h[lo:hi]), Tl, k)
+        else:
+            out_l = h.new_zeros((0, H))
+        sizes = [token_slice(T, ep, r)[1] - token_slice(T, ep, r)[0] for r in range(ep)]
+        out = yield ("all_gather_rows", out_l, sizes)
+        return out
+
+    def forward_varlen(self, h: torch.Tensor, topk_idx: torch.Tensor, topk_w: torch.Tensor):
+        """Variable-split dispatch (exact row counts; one host read of the count matrix per MoE block, eager only)."""
         ops, ep, E, El, k = self.ops, self.ep, self.E, self.El, self.k
         T, H = h.shape
         lo, hi = token_slice(T, ep, self.rank)
@@ -124,6 +179,11 @@ def run(gen, group=None):
                 res = torch.empty((int(sum(out_splits)), t.shape[1]), dtype=t.dtype, device=t.device)
                 dist.all_to_all_single(res, t, out_splits, in_splits, group=group)
                 res = res.to(dev)
+            elif op == "all_to_all_fixed":  # equal, capacity-sized slots: static shapes, no split lists
+                t = stage(req[1].contiguous())
+                res = torch.empty_like(t)
+                dist.all_to_all_single(res, t, group=group)
+                res = res.to(dev)
             elif op == "all_gather_rows":
                 _, t, sizes = req
                 per, world = max(sizes), len(sizes)  # slices are equal except the last: pad to one fixed-size gather
@@ -161,6 +221,9 @@ def run_emulated(gens: list):
                     pieces.append(t[start:start + in_splits[dst]])
                     assert in_splits[dst] == reqs[dst][3][src], "split bookkeeping disagrees between ranks"
                 res.append(torch.cat(pieces, dim=0))
+        elif op == "all_to_all_fixed":
+            cap = reqs[0][2]
+            res = [torch.cat([reqs[src][1][dst * cap:(dst + 1) * cap] for src in range(n)], dim=0) for dst in range(n)]
         elif op == "all_gather_rows":
             cat = torch.cat([r[1] for r in reqs], dim=0)
             res = [cat.clone() for _ in range(n)]

@@ -97,6 +97,12 @@ _SIGNATURES = {
     "glm_allreduce_oneshot_buffer_elems": (c_size_t, [c_int, c_int64]),
     "glm_allreduce_oneshot": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p,
                                       c_void_p]),
+    "glm_ep_plan": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_void_p, c_void_p, c_void_p]),
+    "glm_grouped_gemm_gateup_silu_cap": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+                                                 c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "glm_grouped_gemm_down_cap": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p,
+                                          c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "glm_gather_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "glm_scatter_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "glm_moe_combine_scaled": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,
@@ -664,6 +670,52 @@ def grouped_gemm_down_fp8w(act, w2_q, w2_s, expert_offsets, sorted_scale, n_scal
     return y
 
 
+def ep_plan(topk_idx: torch.Tensor, topk_w: torch.Tensor, E: int, ep: int, rank: int, cap: int):
+    """Fixed-capacity expert-parallel dispatch plan (glm_ep_plan) from the replicated routing [T, k]: device tensors
+    (send_gather, slot_scale, pair_slot, recv_offs, recv_gidx, overflow); no host synchronisation."""
+    T, k = topk_idx.shape
+    _bf16(topk_w, "topk_w")
+    assert topk_idx.dtype == torch.int64 and topk_idx.is_contiguous() and topk_w.is_contiguous() and E % ep == 0
+    dev = topk_idx.device
+    per = (T + ep - 1) // ep
+    Tl = max(0, min(T, (rank + 1) * per) - min(T, rank * per))
+    send_gather = torch.empty(ep * cap, dtype=torch.int32, device=dev)
+    slot_scale = torch.zeros(ep * cap, dtype=torch.bfloat16, device=dev)
+    pair_slot = torch.empty(max(Tl * k, 1), dtype=torch.int32, device=dev)
+    recv_offs = torch.empty(E // ep + 1, dtype=torch.int32, device=dev)
+    recv_gidx = torch.empty(ep * cap, dtype=torch.int32, device=dev)
+    overflow = torch.empty(1, dtype=torch.int32, device=dev)
+    _check(load_library().glm_ep_plan(_p(topk_idx), _p(topk_w), T, k, E, ep, rank, cap, _p(send_gather), _p(slot_scale),
+                                      _p(pair_slot), _p(recv_offs), _p(recv_gidx), _p(overflow), _stream()), "glm_ep_plan")
+    return send_gather, slot_scale, pair_slot, recv_offs, recv_gidx, overflow
+
+
+def grouped_gemm_gateup_silu_cap(x, w13, expert_offsets, sorted_token, R_cap: int, R_expected: int) -> torch.Tensor:
+    """grouped_gemm_gateup_silu over a capacity-sized row array: expert_offsets say which of the R_cap rows are real."""
+    _bf16(x, "x"); _bf16(w13, "w13")
+    G, I2, H = w13.shape
+    I = I2 // 2
+    assert w13.stride(2) == 1
+    act = torch.empty((R_cap, I), dtype=x.dtype, device=x.device)
+    _check(load_library().glm_grouped_gemm_gateup_silu_cap(_p(x), x.stride(0), _p(w13), w13.stride(0), w13.stride(1),
+                                                           _p(expert_offsets), _p(sorted_token), _p(act), R_cap, R_expected,
+                                                           H, I, G, _stream()), "glm_grouped_gemm_gateup_silu_cap")
+    return act
+
+
+def grouped_gemm_down_cap(act, w2, expert_offsets, R_expected: int) -> torch.Tensor:
+    """Unscaled grouped down projection over a capacity-sized row array (the routing weight is applied at home)."""
+    _bf16(act, "act"); _bf16(w2, "w2")
+    G, H, I = w2.shape
+    R_cap = act.shape[0]
+    assert w2.stride(2) == 1 and act.is_contiguous()
+    y = torch.empty((R_cap, H), dtype=act.dtype, device=act.device)
+    _check(load_library().glm_grouped_gemm_down_cap(_p(act), _p(w2), w2.stride(0), w2.stride(1), _p(expert_offsets), None, 0,
+                                                    _p(y), H, R_cap, R_expected, H, I, G, _stream()),
+           "glm_grouped_gemm_down_cap")
+    return y
+
+
 def moe_combine(y, pair_pos, T: int, k: int, shared_base: int) -> torch.Tensor:
     H = y.shape[1]
     out = torch.empty((T, H), dtype=y.dtype, device=y.device)
@@ -673,7 +725,7 @@ def moe_combine(y, pair_pos, T: int, k: int, shared_base: int) -> torch.Tensor:
 
 
 def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
-    """dst[i] = src[idx[i]] (rows of bf16; idx int32)."""
+    """dst[i] = src[idx[i]] (rows of bf16; idx int32; idx < 0: the row is left uninitialised)."""
     _bf16(src, "src")
     assert src.dim() == 2 and idx.dtype == torch.int32 and idx.is_contiguous()
     dst = torch.empty((idx.numel(), src.shape[1]), dtype=src.dtype, device=src.device)
@@ -682,11 +734,12 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return dst
 
 
-def scatter_rows(src: torch.Tensor, idx: torch.Tensor, n_rows: int | None = None) -> torch.Tensor:
-    """dst[idx[i]] = src[i]; rows of dst no index points at stay zero."""
+def scatter_rows(src: torch.Tensor, idx: torch.Tensor, n_rows: int | None = None, no_init: bool = False) -> torch.Tensor:
+    """dst[idx[i]] = src[i] (idx < 0: skipped); rows of dst no index points at stay zero (no_init: uninitialised)."""
     _bf16(src, "src")
     assert src.dim() == 2 and idx.dtype == torch.int32 and idx.is_contiguous() and idx.numel() == src.shape[0]
-    dst = torch.zeros((n_rows if n_rows is not None else src.shape[0], src.shape[1]), dtype=src.dtype, device=src.device)
+    alloc = torch.empty if no_init else torch.zeros
+    dst = alloc((n_rows if n_rows is not None else src.shape[0], src.shape[1]), dtype=src.dtype, device=src.device)
     _check(load_library().glm_scatter_rows(_p(src), src.stride(0), _p(dst), dst.stride(0), _p(idx), idx.numel(),
                                            src.shape[1], _stream()), "glm_scatter_rows")
     return dst

@@ -143,11 +143,11 @@ class RowParallelLinear(LinearBase):
     @staticmethod
     def _partial_rows(m: int) -> bool:
         import os
-        lo = hip_ops.TINYM_MAX_ROWS if os.environ.get("GLM4MOE_TINYM", "1") != "0" else 0
+        lo = 1 if os.environ.get("GLM4MOE_TINYM", "1") != "0" else 0  # one row: the GEMV body (glm_gemm_bf16 picks it)
         return lo < m <= 32
 
     def forward(self, x: torch.Tensor, defer_reduce: bool = False):
-        # (not at T <= 2: the single-sequence GEMV body streams the whole reduction per row and needs no K split)
+        # (not for a single row: the single-sequence GEMV body streams the whole reduction per row and needs no K split)
         if (defer_reduce and self.tp_size == 1 and self.bias is None and x.dim() == 2 and self._partial_rows(x.shape[0])
                 and x.shape[1] >= self.partial_min_k and x.shape[1] >= 2 * self.weight.shape[0]
                 and x.shape[1] % 8 == 0 and x.stride(1) == 1):

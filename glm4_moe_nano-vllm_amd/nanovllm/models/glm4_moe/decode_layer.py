@@ -68,10 +68,13 @@ class Glm4MoeDecoderLayer(nn.Module):
             # post-attention add-RMSNorm and the router of the same token in one launch
             ln = self.post_attention_layernorm
             # ... and the token -> expert bucketing (moe_align), done by that launch's last workgroup
-            hidden_states, residual, idx, w, aligned = hip_ops.add_rmsnorm_router_topk(
+            # (not under expert parallelism: every rank buckets its own token slice, distributed/expert_parallel.py)
+            want_align = True if getattr(self.mlp, "ep_size", 1) == 1 else None
+            hidden_states, residual, idx, w, *aligned = hip_ops.add_rmsnorm_router_topk(
                 hidden_states, residual, ln.weight.data, ln.eps, gate.weight.data, gate.e_score_correction_bias,
-                gate.top_k, float(gate.routed_scaling_factor), align_with_shared=True)
-            hidden_states = self.mlp(hidden_states, routing=(idx, w), aligned=aligned, defer_combine=defer_combine)
+                gate.top_k, float(gate.routed_scaling_factor), align_with_shared=want_align)
+            hidden_states = self.mlp(hidden_states, routing=(idx, w), aligned=aligned[0] if aligned else None,
+                                     defer_combine=defer_combine)
         else:
             hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
             if gate is not None:

@@ -329,6 +329,30 @@ int glm_moe_combine_scaled(const void* y, int64_t ldy, const int32_t* pair_pos, 
                            const void* shared_rows, int64_t ld_shared, void* out, int64_t T, int k, int H,
                            glm_stream_t stream);
 
+/* N3  expert-parallel dispatch plan with FIXED-capacity slots (graph-capturable; BASELINE config 4): from the replicated
+ *     routing topk_idx / topk_w [T, k] (identical on every rank) compute, on the device, everything rank `rank` of `ep`
+ *     needs for the all-to-all with EQUAL splits — no count exchange, no host read.  Rank r owns experts
+ *     [r E/ep, (r+1) E/ep) and the token slice [r per, (r+1) per), per = ceil(T/ep).  Send buffer = [ep][cap] rows,
+ *     destination d's rows at the head of slot d (expert ascending, then pair index); receive buffer likewise by source.
+ *       send_gather [ep*cap]  row of the full hidden-state matrix for each send row, -1 = unused (glm_gather_rows skips)
+ *       slot_scale  [ep*cap]  bf16 routing weight of the pair in that row       pair_slot [Tl*k]  row of pair (t-lo, j)
+ *       recv_offs   [E/ep+1]  expert_offsets over the received rows             recv_gidx [ep*cap] receive-buffer row of
+ *                             expert-ordered row i, -1 beyond recv_offs[E/ep]
+ *       overflow    [1]       0, or the largest (source, destination) row count above cap (cap = Tl * min(k, E/ep)
+ *                             cannot overflow).  Reference intent: the dead dispatch/combine stubs,
+ *                             distributed/parallel_state_ref.py:792-810.                                             */
+int glm_ep_plan(const int64_t* topk_idx, const void* topk_w, int64_t T, int k, int E, int ep, int rank, int cap,
+                int32_t* send_gather, void* slot_scale, int32_t* pair_slot, int32_t* recv_offs, int32_t* recv_gidx,
+                int32_t* overflow, glm_stream_t stream);
+/*     the grouped expert GEMMs over such capacity-sized row arrays: R_cap sizes the grid (expert_offsets decide which rows
+ *     are real), R_expected picks the kernel configuration the real row count would get                              */
+int glm_grouped_gemm_gateup_silu_cap(const void* x, int64_t ldx, const void* w13, int64_t w13_group_stride,
+                                     int64_t w13_row_stride, const int32_t* expert_offsets, const int32_t* sorted_token,
+                                     void* act, int64_t R_cap, int64_t R_expected, int H, int I, int G, glm_stream_t stream);
+int glm_grouped_gemm_down_cap(const void* act, const void* w2, int64_t w2_group_stride, int64_t w2_row_stride,
+                              const int32_t* expert_offsets, const void* sorted_scale, int n_scaled_groups, void* y,
+                              int64_t ldy, int64_t R_cap, int64_t R_expected, int H, int I, int G, glm_stream_t stream);
+
 /* N3  one-shot all-reduce(sum) of a small bf16 tensor over directly mapped peer buffers (the RowParallel all-reduce,
  *     layers/linear.py:153-154, as ONE hop over all xGMI links instead of a ring), PUSH form.  Every rank owns a receive
  *     buffer of glm_allreduce_oneshot_buffer_elems(world, n_max) = 2 * world * n_max bf16 ([2 slots][sender][n_max]) and

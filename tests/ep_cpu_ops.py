@@ -21,13 +21,58 @@ def moe_align(topk_idx, topk_w, E, with_shared):
 
 
 def gather_rows(src, idx):
-    return src[idx.long()].contiguous()
+    out = torch.full((idx.numel(), src.shape[1]), float("nan"), dtype=src.dtype)  # unused rows: poison, nobody may read them
+    ok = idx >= 0
+    out[ok] = src[idx[ok].long()]
+    return out
 
 
-def scatter_rows(src, idx, n_rows=None):
-    dst = torch.zeros((n_rows if n_rows is not None else src.shape[0], src.shape[1]), dtype=src.dtype)
-    dst[idx.long()] = src
+def scatter_rows(src, idx, n_rows=None, no_init=False):
+    fill = float("nan") if no_init else 0.0
+    dst = torch.full((n_rows if n_rows is not None else src.shape[0], src.shape[1]), fill, dtype=src.dtype)
+    ok = idx >= 0
+    dst[idx[ok].long()] = src[ok]
     return dst
+
+
+def ep_plan(topk_idx, topk_w, E, ep, rank, cap):
+    """Python restatement of glm_ep_plan (csrc/moe_misc.hip): same slot layout, same order inside a slot."""
+    T, k = topk_idx.shape
+    El, per = E // ep, (T + ep - 1) // ep
+    lo, hi = min(T, rank * per), min(T, (rank + 1) * per)
+    Tl = hi - lo
+    cnt = torch.zeros((ep, E), dtype=torch.long)
+    for t in range(T):
+        for j in range(k):
+            cnt[t // per, int(topk_idx[t, j])] += 1
+    send_gather = torch.full((ep * cap,), -1, dtype=torch.int32)
+    slot_scale = torch.zeros(ep * cap, dtype=topk_w.dtype)
+    pair_slot = torch.full((max(Tl * k, 1),), -1, dtype=torch.int32)
+    fill = [0] * ep
+    for e in range(E):                       # expert ascending, then pair index ascending
+        d = e // El
+        for p in range(Tl * k):
+            t, j = lo + p // k, p % k
+            if int(topk_idx[t, j]) != e:
+                continue
+            if fill[d] < cap:
+                slot = d * cap + fill[d]
+                send_gather[slot], slot_scale[slot], pair_slot[p] = t, topk_w[t, j], slot
+            fill[d] += 1
+    recv_offs = torch.zeros(El + 1, dtype=torch.int32)
+    recv_gidx = torch.full((ep * cap,), -1, dtype=torch.int32)
+    row = 0
+    for el in range(El):
+        recv_offs[el] = row
+        for s in range(ep):
+            within = int(cnt[s, rank * El:rank * El + el].sum())
+            n = max(0, min(int(cnt[s, rank * El + el]), cap - within))
+            for i in range(n):
+                recv_gidx[row] = s * cap + within + i
+                row += 1
+    recv_offs[El] = row
+    worst = int(cnt.view(ep, ep, El).sum(-1).max())
+    return send_gather, slot_scale, pair_slot, recv_offs, recv_gidx, torch.tensor([worst if worst > cap else 0], dtype=torch.int32)
 
 
 def grouped_gemm_gateup_silu(x, w13, offs, src_idx, R):
@@ -49,6 +94,14 @@ def grouped_gemm_down(act, w2, offs, scale, n_scaled):
         if hi > lo:
             y[lo:hi] = O.linear(act[lo:hi], w2[g])
     return y
+
+
+def grouped_gemm_gateup_silu_cap(x, w13, offs, src_idx, R_cap, R_expected):
+    return grouped_gemm_gateup_silu(x, w13, offs, src_idx, R_cap)
+
+
+def grouped_gemm_down_cap(act, w2, offs, R_expected):
+    return grouped_gemm_down(act, w2, offs, None, 0)
 
 
 def moe_combine_scaled(y, pair_pos, row_scale, shared_rows, T, k):

@@ -45,7 +45,10 @@ def _worker(rank, world, port, q):
         import ep_cpu_ops
         from oracle import glm4_moe_oracle as O
         from nanovllm.distributed import expert_parallel as EP
-        for T, E, k, H, I, seed in ((9, 4, 2, 64, 48, 0), (1, 8, 2, 32, 16, 1), (16, 8, 8, 64, 32, 2), (5, 2, 1, 32, 16, 3)):
+        cases = ((9, 4, 2, 64, 48, 0), (1, 8, 2, 32, 16, 1), (16, 8, 8, 64, 32, 2), (5, 2, 1, 32, 16, 3))
+        # both dispatch forms: fixed-capacity slots (the default) and variable splits
+        for fixed, (T, E, k, H, I, seed) in [(f, c) for f in ("1", "0") for c in cases]:
+            os.environ["GLM_EP_FIXED"] = fixed
             x, w13, w2, gate_w, bias = _case(T, E, k, H, I, seed)
             idx, w = O.router(x, gate_w, bias, k, 1.0)
             idx = torch.sort(idx, dim=1)[0]  # the product's router returns ascending ids; weights re-gathered to match
@@ -106,11 +109,33 @@ def test_ep_emulated_ranks_match_oracle():
     ep = 4
     El = E // ep
     shared = lambda hh: O.mlp(hh, w13[E], w2[E])
-    gens = [EP.EPExperts(ep_cpu_ops, ep, r, E, k, w13[r * El:(r + 1) * El], w2[r * El:(r + 1) * El], shared).forward(x, idx, w)
-            for r in range(ep)]
-    outs = EP.run_emulated(gens)
     ref = O.moe(x, None, None, k, 1.0, w13[:E], w2[:E], w13[E], w2[E], topk=(idx, w))
-    for o in outs:
-        assert torch.equal(o, outs[0])
-    err = (outs[0].float() - ref.float()).abs().max()
-    assert float(err) <= 2 ** -6 * float(ref.float().abs().max())
+    both = []
+    for form in ("forward_fixed", "forward_varlen"):
+        gens = [getattr(EP.EPExperts(ep_cpu_ops, ep, r, E, k, w13[r * El:(r + 1) * El], w2[r * El:(r + 1) * El], shared), form)(x, idx, w)
+                for r in range(ep)]
+        outs = EP.run_emulated(gens)
+        for o in outs:
+            assert torch.equal(o, outs[0])
+        err = (outs[0].float() - ref.float()).abs().max()
+        assert float(err) <= 2 ** -6 * float(ref.float().abs().max()), form
+        both.append(outs[0])
+    assert torch.equal(both[0], both[1]), "fixed-capacity and variable-split dispatch must give the same rows"
+
+
+def test_ep_plan_capacity_and_overflow():
+    """The stand-in plan (same layout as glm_ep_plan): the worst-case capacity never overflows; a smaller one reports it
+    and drops exactly the rows beyond the slot on both sides."""
+    import ep_cpu_ops
+    g = torch.Generator().manual_seed(5)
+    T, E, k, ep = 12, 8, 4, 4
+    idx = torch.stack([torch.randperm(E, generator=g)[:k].sort()[0] for _ in range(T)])
+    w = torch.rand(T, k, generator=g).to(torch.bfloat16)
+    per, El = 3, 2
+    cap = per * min(k, El)
+    for r in range(ep):
+        sg, sc, ps, ro, rg, ovf = ep_cpu_ops.ep_plan(idx, w, E, ep, r, cap)
+        assert int(ovf) == 0 and int((ps >= 0).sum()) == per * k
+        assert int(ro[-1]) == int((idx // El == r).sum())
+    sg, sc, ps, ro, rg, ovf = ep_cpu_ops.ep_plan(idx, w, E, ep, 0, 1)
+    assert int(ovf) > 1

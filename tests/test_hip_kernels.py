@@ -1011,16 +1011,83 @@ def test_expert_parallel_emulated_equals_single_gpu(ops, ep, T, E, k, H, I):
     def shared(hh):
         a = ops.grouped_gemm_gateup_silu(hh, W13[E:E + 1], None, None, hh.shape[0])
         return ops.grouped_gemm_down(a, W2[E:E + 1], None, None, 0)
-    gens = [EP.EPExperts(ops, ep, r, E, k, W13[r * El:(r + 1) * El], W2[r * El:(r + 1) * El], shared)
-            .forward(xd, dev(idx), dev(w)) for r in range(ep)]
-    outs = EP.run_emulated(gens)
-    for o in outs:
-        assert torch.equal(o, outs[0])
+    both = []
+    for form in ("forward_fixed", "forward_varlen"):  # fixed-capacity slots (graph-capturable, the default) / exact splits
+        gens = [getattr(EP.EPExperts(ops, ep, r, E, k, W13[r * El:(r + 1) * El], W2[r * El:(r + 1) * El], shared), form)
+                (xd, dev(idx), dev(w)) for r in range(ep)]
+        outs = EP.run_emulated(gens)
+        for o in outs:
+            assert torch.equal(o, outs[0])
+        both.append(outs[0])
+    assert torch.equal(both[0], both[1]), "fixed-capacity dispatch differs from the variable-split dispatch"
     if not torch.equal(outs[0], ref_dev):
         # sums of 8 + 1 rows that cancel to ~0 are compared absolutely (one ulp of a 0.5-sized row is 2^-9 .. 2^-8)
         assert_close_bf16(outs[0], ref_dev, 2, 0.05, atol=2 ** -5, what="expert-parallel vs single-GPU kernels")
     ref = O.moe(x, None, None, k, 1.0, w13[:E], w2[:E], w13[E], w2[E], topk=(idx, w))
     assert_mixed(outs[0], ref, 2 ** -6, 2 ** -6 * float(ref.float().abs().max()), "expert-parallel vs oracle")
+
+
+@pytest.mark.parametrize("T,E,k,ep", [(256, 64, 8, 8), (33, 64, 8, 4), (1, 8, 2, 2), (7, 128, 8, 8), (64, 16, 4, 2)])
+def test_ep_plan_kernel_equals_restatement(ops, T, E, k, ep):
+    """glm_ep_plan (one workgroup, device-side plan of the fixed-capacity dispatch) == its Python restatement
+    (tests/ep_cpu_ops.ep_plan), every output array, for every rank; a capacity below the worst case reports overflow."""
+    import ep_cpu_ops
+    g = torch.Generator().manual_seed(T * 131 + E)
+    idx = torch.stack([torch.randperm(E, generator=g)[:k].sort()[0] for _ in range(T)]).to(torch.int64)
+    w = (torch.rand(T, k, generator=g) + 0.1).to(BF)
+    El, per = E // ep, (T + ep - 1) // ep
+    cap = max(1, per * min(k, El))
+    for r in range(ep):
+        got = [t.cpu() for t in ops.ep_plan(dev(idx), dev(w), E, ep, r, cap)]
+        exp = ep_cpu_ops.ep_plan(idx, w, E, ep, r, cap)
+        lo, hi = min(T, r * per), min(T, (r + 1) * per)
+        used = exp[0] >= 0
+        assert torch.equal(got[0], exp[0]), f"rank {r}: send_gather"
+        assert torch.equal(got[1][used], exp[1][used]), f"rank {r}: slot_scale"
+        assert torch.equal(got[2][: (hi - lo) * k], exp[2][: (hi - lo) * k]), f"rank {r}: pair_slot"
+        assert torch.equal(got[3], exp[3]) and torch.equal(got[4], exp[4]), f"rank {r}: receive side"
+        assert int(got[5]) == 0
+    if cap > 1:
+        small = [t.cpu() for t in ops.ep_plan(dev(idx), dev(w), E, ep, 0, cap // 2 if cap // 2 >= 1 else 1)]
+        exp = ep_cpu_ops.ep_plan(idx, w, E, ep, 0, cap // 2 if cap // 2 >= 1 else 1)
+        assert int(small[5]) == int(exp[5]) and torch.equal(small[0], exp[0]) and torch.equal(small[4], exp[4])
+
+
+def test_expert_parallel_fixed_dispatch_captures_in_a_graph(ops):
+    """The fixed-capacity dispatch has no host read: ep = 4 logical ranks on one device, collectives by copies, the whole
+    MoE block of all ranks captured in ONE HIP graph and replayed with new inputs == the eager run, bit for bit."""
+    from nanovllm.distributed import expert_parallel as EP
+    T, E, k, H, I, ep = 64, 32, 4, 512, 256, 4
+    w13, w2 = dev(rnd(E + 1, 2 * I, H, seed=402, scale=H ** -0.5)), dev(rnd(E + 1, H, I, seed=403, scale=I ** -0.5))
+    El = E // ep
+
+    def shared(hh):
+        a = ops.grouped_gemm_gateup_silu(hh, w13[E:E + 1], None, None, hh.shape[0])
+        return ops.grouped_gemm_down(a, w2[E:E + 1], None, None, 0)
+    xs, idxs, ws = dev(rnd(T, H, seed=404)), torch.zeros(T, k, dtype=torch.int64, device="cuda"), torch.zeros(T, k, dtype=BF, device="cuda")
+
+    def block():
+        gens = [EP.EPExperts(ops, ep, r, E, k, w13[r * El:(r + 1) * El], w2[r * El:(r + 1) * El], shared)
+                .forward_fixed(xs, idxs, ws) for r in range(ep)]
+        return EP.run_emulated(gens)[0]
+
+    def new_inputs(seed):
+        g = torch.Generator().manual_seed(seed)
+        xs.copy_(rnd(T, H, seed=seed))
+        idxs.copy_(torch.stack([torch.randperm(E, generator=g)[:k].sort()[0] for _ in range(T)]))
+        ws.copy_((torch.rand(T, k, generator=g) + 0.1).to(BF))
+    new_inputs(1)
+    block()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        out_g = block()
+    for seed in (2, 3, 4):
+        new_inputs(seed)
+        gr.replay()
+        torch.cuda.synchronize()
+        got = out_g.clone()
+        assert torch.equal(got, block()), f"replay with inputs {seed} differs from the eager run"
 
 
 def test_in_launch_handoffs_under_repetition(ops):
