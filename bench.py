@@ -703,7 +703,7 @@ def measure_fp8(model, cfg, ops, step, B, ctx, L, args, dev):
         g.replay()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    ks = measure_kernels(model, cfg, ops, B, ctx, 1, max(6, args.kernel_iters // 2), dev, only_experts=True)
+    ks = measure_kernels(model, cfg, ops, B, ctx, 1, args.kernel_iters, dev, only_experts=True)
     return {"workload": f"same model and decode step (bs={B} ctx={ctx} L={L}), experts as fp8 e4m3 weight-only",
             "tokens_per_s": round(B / dt, 2), "ms_per_step": round(dt * 1e3, 4), "ms_per_layer": round(dt * 1e3 / L, 4),
             "steps": steps, "hip_graph": True,

@@ -63,9 +63,7 @@ extern "C" int glm_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t 
     p.bias = (const bf16_t*)bias;
     p.y = (bf16_t*)y; p.ldy = ldy;
     p.R = M; p.N = N; p.K = K; p.G = 1;
-    // single-sequence decode: the GEMV body.  Two rows keep the small-M MFMA kernels (tools/tinym_probe.py, r03: QKV 26.0
-    // vs 21.8 us, grouped down 41.4 vs 34.7 us at T = 2 — the FMA stream of two rows needs half the bytes in flight per
-    // register); the fused combine + norm + QKV launch below takes T = 2 too, where it still saves a whole launch.
+    // single-sequence decode: the GEMV body (two rows keep the small-M MFMA kernels: gemm_tinym.hip, glm_tinym_max_rows)
     if (M == 1 && tinym_enabled()) {
         const int rc = glm_launch_gemm_tinym(GEMM_PLAIN, p, (int)M, glm_s(stream));
         if (rc != GLM_ERR_UNSUPPORTED) return rc;
@@ -91,6 +89,28 @@ extern "C" int glm_gemm_bf16_combine_norm(const void* y_prev, int64_t ld_yprev, 
     p.R = T; p.N = N; p.K = H; p.G = 1;
     return glm_launch_gemm_tinym_combine_norm(p, y_prev, ld_yprev, pair_pos, k, shared_base, residual_in, norm_weight,
                                               residual_out, x_out, eps, glm_s(stream));
+}
+
+extern "C" int glm_gemm_bf16_router_tail(const void* x, const void* w, int64_t ldw, int K, int H, void* o_row,
+                                         uint32_t* ticket, const void* residual_in, const void* norm_weight, float eps,
+                                         void* y_norm, void* residual_out, const void* gate_w,
+                                         const float* e_score_correction_bias, int E, int k, float routed_scaling_factor,
+                                         int64_t* topk_idx, void* topk_w, int32_t* expert_offsets, int32_t* sorted_token,
+                                         void* sorted_scale, int32_t* pair_pos, int with_shared, glm_stream_t stream) {
+    GLM_CHECK_ARG(x && w && o_row && ticket && residual_in && norm_weight && y_norm && residual_out && gate_w &&
+                      e_score_correction_bias && topk_idx && topk_w && expert_offsets && sorted_token && sorted_scale && pair_pos,
+                  GLM_ERR_INVALID, "glm_gemm_bf16_router_tail: null pointer");
+    GLM_CHECK_ARG(K > 0 && H > 0 && ldw >= K && E > 0 && k > 0 && k <= E, GLM_ERR_INVALID,
+                  "glm_gemm_bf16_router_tail: bad shape K=%d H=%d E=%d k=%d", K, H, E, k);
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)x; p.ldx = K;
+    p.w = (const bf16_t*)w; p.ldw = ldw;
+    p.y = (bf16_t*)o_row; p.ldy = H;
+    p.R = 1; p.N = H; p.K = K; p.G = 1;
+    return glm_launch_gemm_tinym_router_tail(p, ticket, residual_in, norm_weight, eps, y_norm, residual_out, gate_w,
+                                             e_score_correction_bias, E, k, routed_scaling_factor, topk_idx, topk_w,
+                                             expert_offsets, sorted_token, sorted_scale, pair_pos, with_shared, glm_s(stream));
 }
 
 extern "C" int glm_gemm_bf16_partial_slices(int K, int want) { return glm_smallm_partial_slices(K, want); }

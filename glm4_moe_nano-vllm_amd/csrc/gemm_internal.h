@@ -48,6 +48,11 @@ int glm_launch_gemm_tinym(int mode, const GemmParams& p, int n_tokens, hipStream
 int glm_launch_gemm_tinym_combine_norm(const GemmParams& p, const void* y_prev, int64_t ld_yprev, const int32_t* pair_pos,
                                        int k, int64_t shared_base, const void* residual_in, const void* norm_w,
                                        void* residual_out, void* x_out, float eps, hipStream_t st);
+// ... and, for ONE row, continued by the post-attention add-RMSNorm + router + bucketing in the last workgroup to finish
+int glm_launch_gemm_tinym_router_tail(const GemmParams& p, unsigned* ticket, const void* residual_in, const void* norm_w,
+                                      float eps, void* y_norm, void* residual_out, const void* gate_w, const float* bias, int E,
+                                      int k, float rsf, int64_t* topk_idx, void* topk_w, int32_t* offs, int32_t* tok,
+                                      void* scale, int32_t* pos, int with_shared, hipStream_t st);
 // same, weights stored as OCP fp8 e4m3 (1 byte/element, ldw/w_gstride in elements) + per-row scale
 int glm_launch_gemm_smallm_fp8w(int mode, const GemmParams& p, hipStream_t st);
 // LDS-tiled MFMA kernels for many rows per group (prefill); p.wscale != nullptr: per-weight-row fp32 scale applied to

@@ -58,6 +58,23 @@ struct TinyParams {
     bf16_t* pc_res_out;       // [T, H]  (written by workgroup 0)
     bf16_t* pc_x_out;         // [T, H] or nullptr: the normalised rows, for callers that want them (workgroup 0)
     float pc_eps;
+    // TAIL_ROUTER (one token): the projection's output row is the attention's o_proj; the workgroup that finishes LAST
+    // continues with the post-attention add-RMSNorm, the router (R1..R7) and glm_moe_align's structure for that token
+    unsigned* tr_ticket;       // zero before the first launch; the last arriver puts the zero back
+    const bf16_t* tr_res_in;   // [H]
+    const bf16_t* tr_norm_w;   // [H]
+    bf16_t* tr_y;              // [H] normalised hidden state (the experts' input)
+    bf16_t* tr_res_out;        // [H]
+    const bf16_t* tr_gate_w;   // [E, H]
+    const float* tr_bias;      // [E]
+    int64_t* tr_idx;           // [k]
+    bf16_t* tr_w;              // [k]
+    int32_t* tr_offs;          // moe_align outputs
+    int32_t* tr_tok;
+    bf16_t* tr_scale;
+    int32_t* tr_pos;
+    int tr_E, tr_k, tr_shared;
+    float tr_eps, tr_rsf;
 };
 
 template <int M>
@@ -78,8 +95,112 @@ __device__ __forceinline__ void tm_fma8(float (&acc)[M], const u32x4_t w, const 
     }
 }
 
+// Post-attention add-RMSNorm + router + bucketing of ONE token by one 512-thread workgroup: the arithmetic, the rounding
+// points and the summation orders of router_topk_kernel<PRE = 1> (moe_misc.hip) — the squares chain of threads 0..255
+// over vectors j, j + 256, the per-expert FMA chain over a lane's chunks lane, lane + 64, ... ending in wave_sum, and
+// router_select_wave itself — so the results are bit-identical to that launch fed with the projection's bf16 row.
+__device__ __forceinline__ void tinym_router_tail(const TinyParams& tp, char* smem, float* red) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = tp.g.N, E = tp.tr_E, nvec = H >> 3;
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                         // [H] normalised row
+    float* xch = reinterpret_cast<float*>(smem + (size_t)H * 2);           // [(nvec - 256) * 8] hand-over of the squares chain
+    float* lg = xch + (nvec > 256 ? (nvec - 256) * 8 : 0);                 // [E] logits
+    float* bias_l = lg + ROUTER_MAX_E;                                     // [E]
+    unsigned* keys = reinterpret_cast<unsigned*>(bias_l + ROUTER_MAX_E);   // [64]
+    bf16_t* wl = reinterpret_cast<bf16_t*>(keys + 64);                     // [k]
+    const bool act = tid < nvec;
+    float s8[8], nwf[8];
+    float ss = 0.f;
+    if (act) {
+        // the projection's row, stored write-through by the other workgroups and drained before their ticket
+        const unsigned long long a = ld_sc1_u64(tp.g.y + (int64_t)tid * 8), b = ld_sc1_u64(tp.g.y + (int64_t)tid * 8 + 4);
+        const u32x4_t xv = {(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
+        const u32x4_t rv = reinterpret_cast<const u32x4_t*>(tp.tr_res_in)[tid];
+        const u32x4_t wv = reinterpret_cast<const u32x4_t*>(tp.tr_norm_w)[tid];
+        u32x4_t ov;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s8[2 * j] = bflo(xv[j]) + bflo(rv[j]);
+            s8[2 * j + 1] = bfhi(xv[j]) + bfhi(rv[j]);
+            ov[j] = pack2bf(s8[2 * j], s8[2 * j + 1]);
+            nwf[2 * j] = bflo(wv[j]);
+            nwf[2 * j + 1] = bfhi(wv[j]);
+        }
+        reinterpret_cast<u32x4_t*>(tp.tr_res_out)[tid] = ov;
+    }
+    for (int e = tid; e < E; e += TM_NT) bias_l[e] = tp.tr_bias[e];
+    if (act && tid >= 256) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xch[(tid - 256) * 8 + j] = s8[j];
+    }
+    __syncthreads();
+    if (act && tid < 256) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += s8[j] * s8[j];
+        for (int v = tid + 256; v < nvec; v += 256) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = xch[(v - 256) * 8 + j];
+                ss += f * f;
+            }
+        }
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) red[wid] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < TM_NW; ++w) tot += red[w];  // (the 1024-thread kernel adds eight more waves' zeros)
+    const float rstd = 1.0f / sqrtf(tot / (float)H + tp.tr_eps);
+    if (act) {
+        u32x4_t o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a = rbf(s8[2 * i] * rstd) * nwf[2 * i];
+            const float b = rbf(s8[2 * i + 1] * rstd) * nwf[2 * i + 1];
+            o[i] = pack2bf(a, b);
+        }
+        reinterpret_cast<u32x4_t*>(tp.tr_y)[tid] = o;
+        reinterpret_cast<u32x4_t*>(xs)[tid] = o;
+    }
+    __syncthreads();
+    // R1: logits = bf16(fp32 dot), one expert per wave at a time, every K step's gate-row load in flight at once
+    constexpr int STEPS = 8;
+    for (int e = wid; e < E; e += TM_NW) {
+        const u32x4_t* grow = reinterpret_cast<const u32x4_t*>(tp.tr_gate_w + (int64_t)e * H);
+        float acc = 0.f;
+        for (int c0 = 0; c0 < nvec; c0 += 64 * STEPS) {
+            u32x4_t wv[STEPS];
+#pragma unroll
+            for (int u = 0; u < STEPS; ++u) {
+                wv[u] = u32x4_t{0, 0, 0, 0};
+                if (c0 + 64 * u < nvec) wv[u] = grow[c0 + lane + 64 * u < nvec ? c0 + lane + 64 * u : lane];
+            }
+#pragma unroll
+            for (int u = 0; u < STEPS; ++u) {
+                const int c = c0 + lane + 64 * u;
+                if (c < nvec) {
+                    const u32x4_t xv = reinterpret_cast<const u32x4_t*>(xs)[c];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc = fmaf(bflo(xv[q]), bflo(wv[u][q]), acc);
+                        acc = fmaf(bfhi(xv[q]), bfhi(wv[u][q]), acc);
+                    }
+                }
+            }
+        }
+        const float sdot = wave_sum(acc);
+        if (lane == 0) lg[e] = rbf(sdot);
+    }
+    __syncthreads();
+    if (wid == 0)  // R2..R7 + the token's moe_align structure (one token: the selecting wave buckets)
+        router_select_wave<ROUTER_MAX_E / 64>(lg, bias_l, keys, wl, lane, E, tp.tr_k, tp.tr_rsf, 0, tp.tr_idx, tp.tr_w, nullptr,
+                                              false, tp.tr_offs, tp.tr_tok, tp.tr_scale, tp.tr_pos, tp.tr_shared);
+}
+
 // MODE as gemm_smallm; M = token rows per group block (1 or 2); SEGS = 1-KiB segments of a weight row per unit
-template <int MODE, int M, int SEGS, bool PRO>
+template <int MODE, int M, int SEGS, bool PRO, bool TAIL = false>
 __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) {
     const GemmParams& p = tp.g;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -265,7 +386,11 @@ __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) 
                     if (scaled) a = rbf(a) * sc;
                     v[r] = a;
                 }
-                *reinterpret_cast<u32x2_t*>(p.y + row * p.ldy + t.ncol) = u32x2_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                const u32x2_t o2 = u32x2_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                if (TAIL)  // read by another workgroup of this launch: write-through (Guideline 16 R1)
+                    st_sc1_u64(p.y + row * p.ldy + t.ncol, (unsigned long long)o2[0] | ((unsigned long long)o2[1] << 32));
+                else
+                    *reinterpret_cast<u32x2_t*>(p.y + row * p.ldy + t.ncol) = o2;
             }
         }
     };
@@ -309,6 +434,23 @@ __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) 
             }
         }
     }
+    if constexpr (TAIL) {
+        // ---- hand-off (valid-forms table, row 1): every wave drains its write-through stores, the workgroup meets, one
+        // lane adds to the ticket; the workgroup whose add came last loads (sc1) behind its barrier ----
+        static_assert(MODE == GEMM_PLAIN && M == 1, "the router tail continues a one-row dense projection");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __shared__ int tr_last;
+        if (tid == 0) {
+            const unsigned got = __hip_atomic_fetch_add(tp.tr_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = got == gridDim.x - 1u;
+            if (last) __hip_atomic_store(tp.tr_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tr_last = last;
+        }
+        __syncthreads();
+        if (!tr_last) return;
+        tinym_router_tail(tp, smem, sh_red);
+    }
 }
 
 int n_cus() {
@@ -322,7 +464,7 @@ int n_cus() {
     return n;
 }
 
-template <int MODE, int M, int SEGS, bool PRO>
+template <int MODE, int M, int SEGS, bool PRO, bool TAIL = false>
 int launch_tiny(const TinyParams& tp, int xrows, hipStream_t st) {
     const GemmParams& p = tp.g;
     constexpr int KU = SEGS * 512;
@@ -331,11 +473,15 @@ int launch_tiny(const TinyParams& tp, int xrows, hipStream_t st) {
     size_t lds = (size_t)xrows * Kp * 2;
     if (lds < 84 * 1024) lds = 84 * 1024;
     GLM_CHECK_ARG(lds <= 156 * 1024, GLM_ERR_UNSUPPORTED, "gemm_tinym: %d activation rows of %d do not fit the LDS", xrows, Kp);
-    auto kern = gemm_tinym_kernel<MODE, M, SEGS, PRO>;
+    auto kern = gemm_tinym_kernel<MODE, M, SEGS, PRO, TAIL>;
     GLM_SET_MAX_LDS(kern, 156 * 1024, "gemm_tinym");
     const int64_t tiles = (int64_t)(p.offs ? p.G : 1) * (MODE == GEMM_GATEUP ? p.N / 2 : p.N / TM_RPW);
     int nwg = n_cus();
     if (tiles < nwg) nwg = (int)tiles;
+    if (TAIL) {  // the tail's scratch lives in the (dead) activation area
+        const size_t need = (size_t)p.N * 2 + (size_t)(p.N / 8 > 256 ? (p.N / 8 - 256) * 32 : 0) + 2 * ROUTER_MAX_E * 4 + 64 * 4 + 256;
+        if (lds < need) lds = need;
+    }
     if (nwg <= 0) return GLM_OK;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(TM_NT), lds, st, tp);
     GLM_CHECK_LAUNCH("gemm_tinym");
@@ -350,8 +496,9 @@ bool tiny_shape_ok(int mode, const GemmParams& p) {
 
 }  // namespace
 
-// rows the fused combine + norm + projection launch takes (the plain and grouped launches take ONE row: api.hip)
-int glm_tinym_max_rows() { return 2; }
+// token rows this body takes: ONE.  (Two rows were built and measured in r03 — tools/tinym_probe.py: QKV 26.0 vs 21.8 us,
+// grouped down 41.4 vs 34.7 us against the small-M MFMA kernels — and dropped.)
+int glm_tinym_max_rows() { return 1; }
 
 // One token row per weight matrix / per expert group (T = 1).  n_tokens: rows of x (grouped gate|up), must be 1.
 int glm_launch_gemm_tinym(int mode, const GemmParams& p, int n_tokens, hipStream_t st) {
@@ -380,7 +527,7 @@ int glm_launch_gemm_tinym_combine_norm(const GemmParams& p, const void* y_prev, 
     GemmParams q = p;
     q.x = (const bf16_t*)residual_in;  // any aligned pointer: the shape check wants one
     q.ldx = p.K;
-    if (!tiny_shape_ok(GEMM_PLAIN, q) || p.K % 8 != 0 || p.K / 8 > TM_NT || p.R < 1 || p.R > 2 || k > GLM_COMBINE_MAX_K ||
+    if (!tiny_shape_ok(GEMM_PLAIN, q) || p.K % 8 != 0 || p.K / 8 > TM_NT || p.R != 1 || k > GLM_COMBINE_MAX_K ||
         ld_yprev % 8 != 0 || !glm_aligned16(y_prev) || !glm_aligned16(residual_in) || !glm_aligned16(norm_w) ||
         !glm_aligned16(residual_out) || (x_out && !glm_aligned16(x_out))) {
         glm_set_error("gemm_tinym(combine+norm): shape not covered (K=%d N=%d T=%ld k=%d)", p.K, p.N, (long)p.R, k);
@@ -392,6 +539,29 @@ int glm_launch_gemm_tinym_combine_norm(const GemmParams& p, const void* y_prev, 
     tp.pc_y = (const bf16_t*)y_prev; tp.pc_ldy = ld_yprev; tp.pc_pos = pair_pos; tp.pc_k = k; tp.pc_shared_base = shared_base;
     tp.pc_res_in = (const bf16_t*)residual_in; tp.pc_norm_w = (const bf16_t*)norm_w; tp.pc_res_out = (bf16_t*)residual_out;
     tp.pc_x_out = (bf16_t*)x_out; tp.pc_eps = eps;
-    if (p.R == 1) return launch_tiny<GEMM_PLAIN, 1, 4, true>(tp, 1, st);
-    return launch_tiny<GEMM_PLAIN, 2, 2, true>(tp, 2, st);
+    return launch_tiny<GEMM_PLAIN, 1, 4, true>(tp, 1, st);
+}
+
+// o_proj of ONE token row continued, in the last workgroup to finish, by the post-attention add-RMSNorm + router +
+// bucketing (glm_add_rmsnorm_router_topk_align at T = 1).  p: the projection (y = its bf16 output row, written
+// write-through and read back by the tail); ticket: one zeroed uint32 that the launch leaves zero.
+int glm_launch_gemm_tinym_router_tail(const GemmParams& p, unsigned* ticket, const void* residual_in, const void* norm_w,
+                                      float eps, void* y_norm, void* residual_out, const void* gate_w, const float* bias, int E,
+                                      int k, float rsf, int64_t* topk_idx, void* topk_w, int32_t* offs, int32_t* tok,
+                                      void* scale, int32_t* pos, int with_shared, hipStream_t st) {
+    const int H = p.N;
+    if (!tiny_shape_ok(GEMM_PLAIN, p) || p.R != 1 || p.bias != nullptr || H % 8 != 0 || H / 8 > TM_NT || H < 2048 || E > ROUTER_MAX_E ||
+        k > 64 || k > E || !glm_aligned16(residual_in) || !glm_aligned16(norm_w) || !glm_aligned16(y_norm) ||
+        !glm_aligned16(residual_out) || !glm_aligned16(gate_w) || !glm_aligned16(p.y) || p.N / TM_RPW < n_cus() / 4) {
+        glm_set_error("gemm_tinym(router tail): shape not covered (K=%d H=%d E=%d k=%d)", p.K, H, E, k);
+        return GLM_ERR_UNSUPPORTED;
+    }
+    TinyParams tp;
+    memset(&tp, 0, sizeof(tp));
+    tp.g = p;
+    tp.tr_ticket = ticket; tp.tr_res_in = (const bf16_t*)residual_in; tp.tr_norm_w = (const bf16_t*)norm_w; tp.tr_eps = eps;
+    tp.tr_y = (bf16_t*)y_norm; tp.tr_res_out = (bf16_t*)residual_out; tp.tr_gate_w = (const bf16_t*)gate_w; tp.tr_bias = bias;
+    tp.tr_E = E; tp.tr_k = k; tp.tr_rsf = rsf; tp.tr_idx = topk_idx; tp.tr_w = (bf16_t*)topk_w;
+    tp.tr_offs = offs; tp.tr_tok = tok; tp.tr_scale = (bf16_t*)scale; tp.tr_pos = pos; tp.tr_shared = with_shared;
+    return launch_tiny<GEMM_PLAIN, 1, 4, false, true>(tp, 1, st);
 }

@@ -83,6 +83,9 @@ _SIGNATURES = {
     "glm_gemm_bf16_combine_norm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p,
                                            c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                            c_int, c_int, c_void_p]),
+    "glm_gemm_bf16_router_tail": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "glm_gemm_bf16_partial_slices": (c_int, [c_int, c_int]),
     "glm_gemm_bf16_partial": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
                                       c_int, c_void_p]),
@@ -562,7 +565,7 @@ def moe_align(topk_idx: torch.Tensor, topk_w: torch.Tensor, E: int, with_shared:
     return offs, tok, scale, pos
 
 
-TINYM_MAX_ROWS = 2  # token rows the single-sequence GEMV body takes (csrc/gemm_tinym.hip)
+TINYM_MAX_ROWS = 1  # token rows the single-sequence GEMV body takes (csrc/gemm_tinym.hip)
 
 
 def grouped_gemm_gateup_silu(x, w13, expert_offsets, sorted_token, R: int, max_rows_per_group: int | None = None) -> torch.Tensor:
@@ -809,6 +812,39 @@ def combine_add_rmsnorm_gemm(dc: DeferredCombine, residual: torch.Tensor, norm_w
 def can_combine_norm_gemm(dc, H: int) -> bool:
     return (isinstance(dc, DeferredCombine) and dc.T <= TINYM_MAX_ROWS and H % 8 == 0 and H <= 4096
             and os.environ.get("GLM4MOE_TINYM", "1") != "0" and os.environ.get("GLM4MOE_FUSE_COMBINE_QKV", "1") != "0")
+
+
+def can_gemm_router_tail(x: torch.Tensor, H: int, E: int) -> bool:
+    return (x.dim() == 2 and x.shape[0] == 1 and 2048 <= H <= 4096 and H % 8 == 0 and E <= 256 and x.is_contiguous()
+            and os.environ.get("GLM4MOE_TINYM", "1") != "0" and os.environ.get("GLM4MOE_FUSE_OPROJ_ROUTER", "1") != "0")
+
+
+def gemm_add_rmsnorm_router_topk_align(x: torch.Tensor, w: torch.Tensor, residual: torch.Tensor, norm_weight: torch.Tensor,
+                                       eps: float, gate_w: torch.Tensor, bias: torch.Tensor, k: int,
+                                       routed_scaling_factor: float, with_shared: bool):
+    """ONE token: o_proj + post-attention add-RMSNorm + router + bucketing in one launch (glm_gemm_bf16_router_tail).
+    x [1, K], w [H, K].  Returns what add_rmsnorm_router_topk(..., align_with_shared=...) returns."""
+    _bf16(x, "x"); _bf16(w, "w"); _bf16(residual, "residual"); _bf16(norm_weight, "norm_weight"); _bf16(gate_w, "gate_w")
+    assert bias.dtype == torch.float32 and x.shape[0] == 1 and w.stride(1) == 1
+    K, H, E = x.shape[1], w.shape[0], gate_w.shape[0]
+    dev = x.device
+    r2 = residual.reshape(1, H).contiguous()
+    o_row = torch.empty((1, H), dtype=x.dtype, device=dev)
+    y, ro = torch.empty_like(r2), torch.empty_like(r2)
+    idx = torch.empty((1, k), dtype=torch.int64, device=dev)
+    tw = torch.empty((1, k), dtype=torch.bfloat16, device=dev)
+    G, R = E + (1 if with_shared else 0), k + (1 if with_shared else 0)
+    offs = torch.empty(G + 1, dtype=torch.int32, device=dev)
+    tok = torch.empty(R, dtype=torch.int32, device=dev)
+    scale = torch.empty(R, dtype=torch.bfloat16, device=dev)
+    pos = torch.empty(k, dtype=torch.int32, device=dev)
+    rws = _router_workspace(dev, 1, E)
+    ticket = rws.data_ptr() + 16  # word 4 of the router workspace's (zeroed, self-restoring) counter block
+    _check(load_library().glm_gemm_bf16_router_tail(
+        _p(x), _p(w), w.stride(0), K, H, _p(o_row), ticket, _p(r2), _p(norm_weight), eps, _p(y), _p(ro), _p(gate_w),
+        _p(bias), E, k, routed_scaling_factor, _p(idx), _p(tw), _p(offs), _p(tok), _p(scale), _p(pos), 1 if with_shared else 0,
+        _stream()), "glm_gemm_bf16_router_tail")
+    return y.view(residual.shape), ro.view(residual.shape), idx, tw, (offs, tok, scale, pos)
 
 
 class PartialSum:

@@ -69,11 +69,13 @@ class Glm4MoeAttention(nn.Module):
                 and self.rotary_emb.rotary_dim % 16 == 0)
 
     def forward(self, hidden_states: torch.Tensor | None, positions: torch.Tensor, defer_o_reduce: bool = False,
-                qkv: torch.Tensor | None = None):
+                qkv: torch.Tensor | None = None, skip_o_proj: bool = False):
         """defer_o_reduce: the caller feeds the result straight into RMSNorm.forward(x, residual) and accepts a
         hip_ops.PartialSum (K-slice partial sums of o_proj, reduced inside that add-RMSNorm kernel).
         qkv: the QKV projection of this layer's normalised input, already computed by the caller (the T <= 2 launch that
-        fuses combine + input norm + projection); hidden_states is then unused (may be None)."""
+        fuses combine + input norm + projection); hidden_states is then unused (may be None).
+        skip_o_proj: return the attention output [T, nh*hd] itself — the caller runs o_proj fused with what follows it
+        (one token: o_proj + post-attention norm + router in one launch; TP = 1 only)."""
         ctx = get_context()
         attn = self.attn
         has_cache = attn.k_cache.numel() > 0 and attn.v_cache.numel() > 0
@@ -95,6 +97,8 @@ class Glm4MoeAttention(nn.Module):
                 qkv, self.num_heads, self.num_kv_heads, self.head_dim, positions, self.rotary_emb.cos_sin_cache,
                 self.rotary_emb.rotary_dim, ctx.slot_mapping, attn.k_cache, attn.v_cache, ctx.context_lens,
                 ctx.block_tables, attn.scale, qkv_bias=bias)
+            if skip_o_proj:
+                return o.reshape(o.shape[0], -1)
             return self.o_proj(o.reshape(o.shape[0], -1), defer_reduce=defer_o_reduce)
         if qkv is None:
             qkv = self.qkv_proj(hidden_states)
@@ -118,6 +122,8 @@ class Glm4MoeAttention(nn.Module):
                 q, k = self.q_norm(q), self.k_norm(k)
             q, k = self.rotary_emb(positions, q, k)
             o = attn(q, k, v)
+        if skip_o_proj:
+            return o.reshape(o.shape[0], -1)
         return self.o_proj(o.reshape(o.shape[0], -1), defer_reduce=defer_o_reduce)
 
     def load_weights(self, path: str, prefix: str):

@@ -61,9 +61,26 @@ class Glm4MoeDecoderLayer(nn.Module):
             hidden_states, residual = self.input_layernorm(hidden_states), hidden_states
         else:
             hidden_states, residual = self.input_layernorm(hidden_states, residual)
-        # o_proj may hand over K-slice partial sums; the add-RMSNorm right below reduces them (decode batches)
-        hidden_states = self.self_attn(hidden_states, positions, defer_o_reduce=True, qkv=qkv)
         gate = getattr(self.mlp, "gate", None)
+        T1 = residual.reshape(-1, residual.shape[-1])
+        op = self.self_attn.o_proj
+        if (self.fuse_norm_router and gate is not None and T1.shape[0] == 1 and op.tp_size == 1 and op.bias is None
+                and getattr(self.mlp, "ep_size", 1) == 1
+                and hip_ops.can_gemm_router_tail(T1, residual.shape[-1], gate.weight.shape[0])):
+            # ONE token: o_proj, post-attention add-RMSNorm, router and bucketing in one launch — the workgroup of the
+            # o_proj GEMV that finishes last carries on with the token's norm + router (bit-identical to the two launches)
+            o = self.self_attn(hidden_states, positions, qkv=qkv, skip_o_proj=True)
+            ln = self.post_attention_layernorm
+            if o.dim() == 2 and o.shape[0] == 1 and o.is_contiguous():
+                hidden_states, residual, idx, w, aligned = hip_ops.gemm_add_rmsnorm_router_topk_align(
+                    o, op.weight.data, residual, ln.weight.data, ln.eps, gate.weight.data, gate.e_score_correction_bias,
+                    gate.top_k, float(gate.routed_scaling_factor), True)
+                hidden_states = self.mlp(hidden_states, routing=(idx, w), aligned=aligned, defer_combine=defer_combine)
+                return hidden_states, residual
+            hidden_states = op(o, defer_reduce=True)
+        else:
+            # o_proj may hand over K-slice partial sums; the add-RMSNorm right below reduces them (decode batches)
+            hidden_states = self.self_attn(hidden_states, positions, defer_o_reduce=True, qkv=qkv)
         if self.fuse_norm_router and gate is not None and residual.shape[-1] <= 8192:
             # post-attention add-RMSNorm and the router of the same token in one launch
             ln = self.post_attention_layernorm

@@ -184,6 +184,21 @@ int glm_grouped_gemm_down(const void* act, const void* w2,
                           int n_scaled_groups, void* y, int64_t ldy,
                           int64_t R, int H, int I, int G, glm_stream_t stream);
 
+/* a10 + a3 + a11 + bucketing for ONE token (attention_new.py o_proj, decode_layer.py:86-93, moe.py:28-50), r03:
+ *     o = bf16(x·Woᵀ)  (x [1, K], Wo [H, K], no bias);  then, in the workgroup of the GEMV that finishes LAST (its peers'
+ *     rows reach it through write-through stores and a ticket — no second launch):
+ *     s = f32(o) + f32(residual_in); residual_out = bf16(s); y_norm = bf16(bf16(s*rstd)*norm_weight);
+ *     (topk_idx, topk_w) = router R1..R7 on y_norm;  expert_offsets / sorted_token / sorted_scale / pair_pos as
+ *     glm_moe_align(T = 1).  Bit-identical to glm_gemm_bf16 followed by glm_add_rmsnorm_router_topk_align.
+ *     o_row: [H] bf16 scratch (the projection's output row).  ticket: one uint32, ZERO before the first launch, left zero.
+ *     GLM_ERR_UNSUPPORTED: H > 4096, H < 2048, E > 256, unaligned buffers.                                             */
+int glm_gemm_bf16_router_tail(const void* x, const void* w, int64_t ldw, int K, int H, void* o_row, uint32_t* ticket,
+                              const void* residual_in, const void* norm_weight, float eps, void* y_norm,
+                              void* residual_out, const void* gate_w, const float* e_score_correction_bias, int E, int k,
+                              float routed_scaling_factor, int64_t* topk_idx, void* topk_w, int32_t* expert_offsets,
+                              int32_t* sorted_token, void* sorted_scale, int32_t* pair_pos, int with_shared,
+                              glm_stream_t stream);
+
 /* N4 (no reference counterpart; BASELINE config 5): the same two grouped projections with the
  *     expert weights stored as OCP fp8 e4m3 (1 byte/element) plus one fp32 scale per weight row:
  *     W'[n,k] = scale[n] * fp8(Wq[n,k]).  Weight-only quantisation: activations stay bf16, the
@@ -222,10 +237,10 @@ int glm_moe_combine(const void* y, int64_t ldy, const int32_t* pair_pos, void* o
 int glm_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
                   void* y, int64_t ldy, int64_t M, int N, int K, glm_stream_t stream);
 
-/* Single-sequence decode (BASELINE config 2: greedy bs = 1; T <= 2 token rows), r03.
- * a13 at T <= 2: the same operators as glm_grouped_gemm_gateup_silu / glm_grouped_gemm_down (same arguments, same
+/* Single-sequence decode (BASELINE config 2: greedy bs = 1; T = 1 token row), r03.
+ * a13 at T = 1: the same operators as glm_grouped_gemm_gateup_silu / glm_grouped_gemm_down (same arguments, same
  *     rounding points) on the GEMV body — one persistent workgroup per CU, fp32 FMA, weights streamed 16-32 KiB deep per
- *     wave.  T = number of token rows of x; PRECONDITION: no group holds more than T rows (true for a top-k routing: a
+ *     wave.  T = number of token rows of x (the GEMV body takes T = 1, more rows run the entry points above); PRECONDITION: no group holds more than T rows (true for a top-k routing: a
  *     token's experts are distinct, the shared group holds T rows).  Shapes the body does not cover fall through to the
  *     entry points above.                                                                                             */
 int glm_grouped_gemm_gateup_silu_fewtok(const void* x, int64_t ldx, int64_t T, const void* w13,
@@ -236,12 +251,12 @@ int glm_grouped_gemm_down_fewtok(const void* act, int64_t T, const void* w2, int
                                  int64_t w2_row_stride, const int32_t* expert_offsets, const void* sorted_scale,
                                  int n_scaled_groups, void* y, int64_t ldy, int64_t R, int H, int I, int G,
                                  glm_stream_t stream);
-/* a3 + a5 of layer i+1 with a12 of layer i, T <= 2 (decode_layer.py:47-49 + attention_new.py qkv_proj + moe.py:133-171):
+/* a3 + a5 of layer i+1 with a12 of layer i, T = 1 (decode_layer.py:47-49 + attention_new.py qkv_proj + moe.py:133-171):
  *     c = glm_moe_combine(y_prev, pair_pos, shared_base);  s = f32(c) + f32(residual_in);  residual_out = bf16(s);
  *     xn = bf16(bf16(s * rstd(s)) * norm_weight);  y = bf16(xn·Wᵀ + bias)
  *     in ONE launch: every workgroup of the GEMV recomputes the (tiny) combine + norm behind its first weight loads,
  *     workgroup 0 writes residual_out (and x_out = xn when not NULL).  Bit-identical to
- *     glm_moe_combine_add_rmsnorm followed by glm_gemm_bf16.  GLM_ERR_UNSUPPORTED when T > 2 or H > 4096.             */
+ *     glm_moe_combine_add_rmsnorm followed by glm_gemm_bf16.  GLM_ERR_UNSUPPORTED when T > 1 or H > 4096.             */
 int glm_gemm_bf16_combine_norm(const void* y_prev, int64_t ld_yprev, const int32_t* pair_pos, int64_t T, int k,
                                int64_t shared_base, const void* residual_in, const void* norm_weight, float eps,
                                void* residual_out, void* x_out, const void* w, int64_t ldw, const void* bias,

@@ -8,6 +8,7 @@ from nanovllm.models.glm4_moe.model import Glm4MoeForCausalLM
 torch.set_default_dtype(torch.bfloat16)
 L = 6
 cfg = bench.air64e_config(L, 4096)
+cfg.keep_bf16_experts = True  # this tool times the bf16 and the fp8 stacks side by side
 with torch.device("cuda"):
     model = Glm4MoeForCausalLM(cfg)
 bench.init_weights(model, 1)
