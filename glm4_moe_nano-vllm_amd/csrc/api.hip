@@ -108,7 +108,8 @@ extern "C" int glm_gemm_bf16_router_tail(const void* x, const void* w, int64_t l
     p.w = (const bf16_t*)w; p.ldw = ldw;
     p.y = (bf16_t*)o_row; p.ldy = H;
     p.R = 1; p.N = H; p.K = K; p.G = 1;
-    return glm_launch_gemm_tinym_router_tail(p, ticket, residual_in, norm_weight, eps, y_norm, residual_out, gate_w,
+    // ticket words 0/1 = the two counters, words 4.. = E floats of logits scratch (the caller provides 16 + 4 E bytes)
+    return glm_launch_gemm_tinym_router_tail(p, ticket, reinterpret_cast<float*>(ticket + 4), residual_in, norm_weight, eps, y_norm, residual_out, gate_w,
                                              e_score_correction_bias, E, k, routed_scaling_factor, topk_idx, topk_w,
                                              expert_offsets, sorted_token, sorted_scale, pair_pos, with_shared, glm_s(stream));
 }

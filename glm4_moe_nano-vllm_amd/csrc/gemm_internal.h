@@ -49,7 +49,7 @@ int glm_launch_gemm_tinym_combine_norm(const GemmParams& p, const void* y_prev, 
                                        int k, int64_t shared_base, const void* residual_in, const void* norm_w,
                                        void* residual_out, void* x_out, float eps, hipStream_t st);
 // ... and, for ONE row, continued by the post-attention add-RMSNorm + router + bucketing in the last workgroup to finish
-int glm_launch_gemm_tinym_router_tail(const GemmParams& p, unsigned* ticket, const void* residual_in, const void* norm_w,
+int glm_launch_gemm_tinym_router_tail(const GemmParams& p, unsigned* ticket, float* logits_scratch, const void* residual_in, const void* norm_w,
                                       float eps, void* y_norm, void* residual_out, const void* gate_w, const float* bias, int E,
                                       int k, float rsf, int64_t* topk_idx, void* topk_w, int32_t* offs, int32_t* tok,
                                       void* scale, int32_t* pos, int with_shared, hipStream_t st);

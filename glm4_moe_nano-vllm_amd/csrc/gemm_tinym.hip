@@ -60,7 +60,8 @@ struct TinyParams {
     float pc_eps;
     // TAIL_ROUTER (one token): the projection's output row is the attention's o_proj; the workgroup that finishes LAST
     // continues with the post-attention add-RMSNorm, the router (R1..R7) and glm_moe_align's structure for that token
-    unsigned* tr_ticket;       // zero before the first launch; the last arriver puts the zero back
+    unsigned* tr_ticket;       // TWO zeroed uint32 (projection workgroups done, designated workgroups done); left zero
+    float* tr_logits;          // [E] scratch (logits in bf16 precision, handed between the designated workgroups)
     const bf16_t* tr_res_in;   // [H]
     const bf16_t* tr_norm_w;   // [H]
     bf16_t* tr_y;              // [H] normalised hidden state (the experts' input)
@@ -95,17 +96,66 @@ __device__ __forceinline__ void tm_fma8(float (&acc)[M], const u32x4_t w, const 
     }
 }
 
-// Post-attention add-RMSNorm + router + bucketing of ONE token by one 512-thread workgroup: the arithmetic, the rounding
-// points and the summation orders of router_topk_kernel<PRE = 1> (moe_misc.hip) — the squares chain of threads 0..255
-// over vectors j, j + 256, the per-expert FMA chain over a lane's chunks lane, lane + 64, ... ending in wave_sum, and
-// router_select_wave itself — so the results are bit-identical to that launch fed with the projection's bf16 row.
-__device__ __forceinline__ void tinym_router_tail(const TinyParams& tp, char* smem, float* red) {
+// Post-attention add-RMSNorm + router + bucketing of ONE token, continued inside the o_proj GEMV launch by ND DESIGNATED
+// workgroups (blockIdx.x < ND, ND = ceil(E / TR_ROWS)).  A single workgroup cannot do it: the E gate rows are 512 KiB that
+// nobody has touched yet, and one CU takes in 25-50 GB/s (measured r03: the single-workgroup tail cost +13 us per layer).
+//   * at kernel START workgroup d requests ITS gate rows [d TR_ROWS, +TR_ROWS) into LDS by LDS-DMA (no registers held;
+//     the rows do not depend on the activations) and then streams its share of the projection like everybody else;
+//   * every workgroup publishes its output rows write-through, drains them and adds to the ticket; the designated ones
+//     then poll the ticket (one lane, sc1 loads, s_sleep; they wait for workgroups that never wait for anything, so the
+//     wait ends whatever the residency; the spin is bounded all the same);
+//   * each designated workgroup forms the normalised row (all of them, redundantly: 8 KiB), its TR_ROWS logits out of LDS,
+//     stores them write-through and adds to a second counter; the one whose add comes last gathers the E logits, selects
+//     (router_select_wave) and writes glm_moe_align's structure for the token, then puts both counters back to zero.
+// Arithmetic, rounding points and summation orders are router_topk_kernel<PRE = 1>'s (moe_misc.hip): the squares chain
+// of threads 0..255 over vectors j, j + 256, the per-expert FMA chain over a lane's chunks lane, lane + 64, ... ending
+// in wave_sum, router_select_wave itself — bit-identical to that launch fed with the projection's bf16 row.
+constexpr int TR_ROWS = 16;            // gate rows per designated workgroup (16 x 8 KiB = 128 KiB of LDS at H = 4096)
+constexpr unsigned TR_SPIN_LIMIT = 1u << 22;
+
+__device__ __forceinline__ size_t tr_gate_lds_off(int Kp) { return ((size_t)Kp * 2 + 15) & ~(size_t)15; }
+
+__device__ __forceinline__ void tinym_router_prefetch(const TinyParams& tp, char* smem, int Kp) {
+    // rows [d TR_ROWS, +TR_ROWS) of the gate matrix -> LDS behind the activation row; wave w takes rows w, w + 8, ...
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int H = tp.g.N, nvec = H >> 3, e0 = blockIdx.x * TR_ROWS;
+    char* dst = smem + tr_gate_lds_off(Kp);
+    for (int r = wid; r < TR_ROWS && e0 + r < tp.tr_E; r += TM_NW) {
+        const bf16_t* grow = tp.tr_gate_w + (int64_t)(e0 + r) * H;
+        for (int u = 0; 64 * u < nvec; ++u)  // lanes past the row re-read its last chunk into padding nobody reads
+            __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(grow + (int64_t)min(64 * u + lane, nvec - 1) * 8),
+                                             (__attribute__((address_space(3))) void*)(dst + (size_t)r * ((nvec + 63) / 64) * 1024 + u * 1024),
+                                             16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void tinym_router_tail(const TinyParams& tp, char* smem, float* red, int Kp) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = tp.g.N, E = tp.tr_E, nvec = H >> 3;
+    const int d = blockIdx.x, nd = (E + TR_ROWS - 1) / TR_ROWS;
+    unsigned* t_all = tp.tr_ticket;       // workgroups whose projection rows are published
+    unsigned* t_des = tp.tr_ticket + 1;   // designated workgroups whose logits are published
+    __shared__ int tr_ok, tr_last;
+    // ---- wait for the whole projection (one lane polls; everybody else parks at the barrier) ----
+    if (tid == 0) {
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(t_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > TR_SPIN_LIMIT) {
+                ok = 0;
+                break;
+            }
+        }
+        tr_ok = ok;
+    }
+    __syncthreads();
+    if (!tr_ok) return;  // cannot happen while the GPU makes progress; never hang
+    // the x rows are dead (every wave is past its last tile): xs / hand-over area / logits / bias live there
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                         // [H] normalised row
-    float* xch = reinterpret_cast<float*>(smem + (size_t)H * 2);           // [(nvec - 256) * 8] hand-over of the squares chain
-    float* lg = xch + (nvec > 256 ? (nvec - 256) * 8 : 0);                 // [E] logits
+    float* xch = reinterpret_cast<float*>(smem + (size_t)H * 2);           // [(nvec - 256) * 8]
+    float* lg = xch + (nvec > 256 ? (nvec - 256) * 8 : 0);                 // [E]
     float* bias_l = lg + ROUTER_MAX_E;                                     // [E]
     unsigned* keys = reinterpret_cast<unsigned*>(bias_l + ROUTER_MAX_E);   // [64]
     bf16_t* wl = reinterpret_cast<bf16_t*>(keys + 64);                     // [k]
@@ -113,7 +163,6 @@ __device__ __forceinline__ void tinym_router_tail(const TinyParams& tp, char* sm
     float s8[8], nwf[8];
     float ss = 0.f;
     if (act) {
-        // the projection's row, stored write-through by the other workgroups and drained before their ticket
         const unsigned long long a = ld_sc1_u64(tp.g.y + (int64_t)tid * 8), b = ld_sc1_u64(tp.g.y + (int64_t)tid * 8 + 4);
         const u32x4_t xv = {(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
         const u32x4_t rv = reinterpret_cast<const u32x4_t*>(tp.tr_res_in)[tid];
@@ -127,9 +176,8 @@ __device__ __forceinline__ void tinym_router_tail(const TinyParams& tp, char* sm
             nwf[2 * j] = bflo(wv[j]);
             nwf[2 * j + 1] = bfhi(wv[j]);
         }
-        reinterpret_cast<u32x4_t*>(tp.tr_res_out)[tid] = ov;
+        if (d == 0) reinterpret_cast<u32x4_t*>(tp.tr_res_out)[tid] = ov;
     }
-    for (int e = tid; e < E; e += TM_NT) bias_l[e] = tp.tr_bias[e];
     if (act && tid >= 256) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) xch[(tid - 256) * 8 + j] = s8[j];
@@ -161,37 +209,45 @@ __device__ __forceinline__ void tinym_router_tail(const TinyParams& tp, char* sm
             const float b = rbf(s8[2 * i + 1] * rstd) * nwf[2 * i + 1];
             o[i] = pack2bf(a, b);
         }
-        reinterpret_cast<u32x4_t*>(tp.tr_y)[tid] = o;
+        if (d == 0) reinterpret_cast<u32x4_t*>(tp.tr_y)[tid] = o;
         reinterpret_cast<u32x4_t*>(xs)[tid] = o;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's gate rows (requested at kernel start) have landed
     __syncthreads();
-    // R1: logits = bf16(fp32 dot), one expert per wave at a time, every K step's gate-row load in flight at once
-    constexpr int STEPS = 8;
-    for (int e = wid; e < E; e += TM_NW) {
-        const u32x4_t* grow = reinterpret_cast<const u32x4_t*>(tp.tr_gate_w + (int64_t)e * H);
+    // R1 for this workgroup's rows, out of LDS: logits = bf16(fp32 dot), the FMA chain of router_topk_kernel
+    const char* gl = smem + tr_gate_lds_off(Kp);
+    const size_t rowb = (size_t)((nvec + 63) / 64) * 1024;
+    for (int r = wid; r < TR_ROWS && d * TR_ROWS + r < E; r += TM_NW) {
+        const u32x4_t* grow = reinterpret_cast<const u32x4_t*>(gl + (size_t)r * rowb);
         float acc = 0.f;
-        for (int c0 = 0; c0 < nvec; c0 += 64 * STEPS) {
-            u32x4_t wv[STEPS];
+        for (int c = lane; c < nvec; c += 64) {
+            const u32x4_t wv = grow[c];
+            const u32x4_t xv = reinterpret_cast<const u32x4_t*>(xs)[c];
 #pragma unroll
-            for (int u = 0; u < STEPS; ++u) {
-                wv[u] = u32x4_t{0, 0, 0, 0};
-                if (c0 + 64 * u < nvec) wv[u] = grow[c0 + lane + 64 * u < nvec ? c0 + lane + 64 * u : lane];
-            }
-#pragma unroll
-            for (int u = 0; u < STEPS; ++u) {
-                const int c = c0 + lane + 64 * u;
-                if (c < nvec) {
-                    const u32x4_t xv = reinterpret_cast<const u32x4_t*>(xs)[c];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        acc = fmaf(bflo(xv[q]), bflo(wv[u][q]), acc);
-                        acc = fmaf(bfhi(xv[q]), bfhi(wv[u][q]), acc);
-                    }
-                }
+            for (int q = 0; q < 4; ++q) {
+                acc = fmaf(bflo(xv[q]), bflo(wv[q]), acc);
+                acc = fmaf(bfhi(xv[q]), bfhi(wv[q]), acc);
             }
         }
         const float sdot = wave_sum(acc);
-        if (lane == 0) lg[e] = rbf(sdot);
+        if (lane == 0) st_sc1_u32(tp.tr_logits + d * TR_ROWS + r, __float_as_uint(rbf(sdot)));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned got = __hip_atomic_fetch_add(t_des, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tr_last = got == (unsigned)nd - 1u;
+    }
+    __syncthreads();
+    if (!tr_last) return;
+    // ---- the last designated workgroup: every logit was stored write-through and drained before its ticket ----
+    for (int e = tid; e < E; e += TM_NT) {
+        lg[e] = __uint_as_float(ld_sc1_u32(tp.tr_logits + e));
+        bias_l[e] = tp.tr_bias[e];
+    }
+    if (tid == 0) {  // both counters back to zero for the next launch (every designated workgroup is past its polls)
+        __hip_atomic_store(t_all, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(t_des, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (wid == 0)  // R2..R7 + the token's moe_align structure (one token: the selecting wave buckets)
@@ -280,6 +336,9 @@ __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) 
     if (i_live) {
         set_tile(it, i_tile);
         issue(std::integral_constant<int, 0>{}, it, 0);
+    }
+    if constexpr (TAIL) {  // a designated workgroup's gate rows -> LDS, behind its first weight loads
+        if ((int)blockIdx.x < (tp.tr_E + TR_ROWS - 1) / TR_ROWS) tinym_router_prefetch(tp, smem, Kp);
     }
     ct = it;
     int c_tile = i_tile, c_u = 0;
@@ -436,20 +495,13 @@ __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) 
     }
     if constexpr (TAIL) {
         // ---- hand-off (valid-forms table, row 1): every wave drains its write-through stores, the workgroup meets, one
-        // lane adds to the ticket; the workgroup whose add came last loads (sc1) behind its barrier ----
+        // lane adds to the ticket; the designated workgroups poll it (sc1 loads) and load behind their barrier ----
         static_assert(MODE == GEMM_PLAIN && M == 1, "the router tail continues a one-row dense projection");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        __shared__ int tr_last;
-        if (tid == 0) {
-            const unsigned got = __hip_atomic_fetch_add(tp.tr_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = got == gridDim.x - 1u;
-            if (last) __hip_atomic_store(tp.tr_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tr_last = last;
-        }
-        __syncthreads();
-        if (!tr_last) return;
-        tinym_router_tail(tp, smem, sh_red);
+        if (tid == 0) __hip_atomic_fetch_add(tp.tr_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)blockIdx.x >= (tp.tr_E + TR_ROWS - 1) / TR_ROWS) return;
+        tinym_router_tail(tp, smem, sh_red, Kp);
     }
 }
 
@@ -478,9 +530,13 @@ int launch_tiny(const TinyParams& tp, int xrows, hipStream_t st) {
     const int64_t tiles = (int64_t)(p.offs ? p.G : 1) * (MODE == GEMM_GATEUP ? p.N / 2 : p.N / TM_RPW);
     int nwg = n_cus();
     if (tiles < nwg) nwg = (int)tiles;
-    if (TAIL) {  // the tail's scratch lives in the (dead) activation area
-        const size_t need = (size_t)p.N * 2 + (size_t)(p.N / 8 > 256 ? (p.N / 8 - 256) * 32 : 0) + 2 * ROUTER_MAX_E * 4 + 64 * 4 + 256;
-        if (lds < need) lds = need;
+    if (TAIL) {  // the tail's scratch lives in the (dead) activation area; behind it TR_ROWS gate rows
+        const size_t scratch = (size_t)p.N * 2 + (size_t)(p.N / 8 > 256 ? (p.N / 8 - 256) * 32 : 0) + 2 * ROUTER_MAX_E * 4 + 64 * 4 + 256;
+        const size_t x_area = (((size_t)Kp * 2 + 15) & ~(size_t)15);
+        GLM_CHECK_ARG(scratch <= x_area, GLM_ERR_UNSUPPORTED, "gemm_tinym(router tail): K too short for the tail's scratch");
+        lds = x_area + (size_t)TR_ROWS * ((p.N / 8 + 63) / 64) * 1024;
+        GLM_CHECK_ARG(lds <= 156 * 1024, GLM_ERR_UNSUPPORTED, "gemm_tinym(router tail): %zu B of LDS", lds);
+        if (lds < 84 * 1024) lds = 84 * 1024;
     }
     if (nwg <= 0) return GLM_OK;
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(TM_NT), lds, st, tp);
@@ -544,22 +600,23 @@ int glm_launch_gemm_tinym_combine_norm(const GemmParams& p, const void* y_prev, 
 
 // o_proj of ONE token row continued, in the last workgroup to finish, by the post-attention add-RMSNorm + router +
 // bucketing (glm_add_rmsnorm_router_topk_align at T = 1).  p: the projection (y = its bf16 output row, written
-// write-through and read back by the tail); ticket: one zeroed uint32 that the launch leaves zero.
-int glm_launch_gemm_tinym_router_tail(const GemmParams& p, unsigned* ticket, const void* residual_in, const void* norm_w,
+// write-through and read back by the tail); ticket: two zeroed uint32 that the launch leaves zero; logits_scratch: E floats.
+int glm_launch_gemm_tinym_router_tail(const GemmParams& p, unsigned* ticket, float* logits_scratch, const void* residual_in, const void* norm_w,
                                       float eps, void* y_norm, void* residual_out, const void* gate_w, const float* bias, int E,
                                       int k, float rsf, int64_t* topk_idx, void* topk_w, int32_t* offs, int32_t* tok,
                                       void* scale, int32_t* pos, int with_shared, hipStream_t st) {
     const int H = p.N;
     if (!tiny_shape_ok(GEMM_PLAIN, p) || p.R != 1 || p.bias != nullptr || H % 8 != 0 || H / 8 > TM_NT || H < 2048 || E > ROUTER_MAX_E ||
         k > 64 || k > E || !glm_aligned16(residual_in) || !glm_aligned16(norm_w) || !glm_aligned16(y_norm) ||
-        !glm_aligned16(residual_out) || !glm_aligned16(gate_w) || !glm_aligned16(p.y) || p.N / TM_RPW < n_cus() / 4) {
+        !glm_aligned16(residual_out) || !glm_aligned16(gate_w) || !glm_aligned16(p.y) || p.N / TM_RPW < 2 * ((E + TR_ROWS - 1) / TR_ROWS) ||
+        logits_scratch == nullptr) {
         glm_set_error("gemm_tinym(router tail): shape not covered (K=%d H=%d E=%d k=%d)", p.K, H, E, k);
         return GLM_ERR_UNSUPPORTED;
     }
     TinyParams tp;
     memset(&tp, 0, sizeof(tp));
     tp.g = p;
-    tp.tr_ticket = ticket; tp.tr_res_in = (const bf16_t*)residual_in; tp.tr_norm_w = (const bf16_t*)norm_w; tp.tr_eps = eps;
+    tp.tr_ticket = ticket; tp.tr_logits = logits_scratch; tp.tr_res_in = (const bf16_t*)residual_in; tp.tr_norm_w = (const bf16_t*)norm_w; tp.tr_eps = eps;
     tp.tr_y = (bf16_t*)y_norm; tp.tr_res_out = (bf16_t*)residual_out; tp.tr_gate_w = (const bf16_t*)gate_w; tp.tr_bias = bias;
     tp.tr_E = E; tp.tr_k = k; tp.tr_rsf = rsf; tp.tr_idx = topk_idx; tp.tr_w = (bf16_t*)topk_w;
     tp.tr_offs = offs; tp.tr_tok = tok; tp.tr_scale = (bf16_t*)scale; tp.tr_pos = pos; tp.tr_shared = with_shared;

@@ -22,6 +22,7 @@
 // block_tables (prefix-cache hit, attention.py:86-87).
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 // timing-only ablations (results are wrong): 1 no exp, 2 no barrier, 4 no S MFMA, 8 no PV MFMA, 16 no LDS reads,
 // 32 no K/V staging after the first two tiles
@@ -656,6 +657,327 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
     }
 }
 
+
+// ==========================================================================================================================
+// r03: the same kernel on v_mfma_f32_32x32x16_bf16 (prefill_attn32_kernel).  Why: with 16x16x32 MFMAs a (32 keys x 32 query
+// rows) step costs 34 MFMA issues (8 of a SIMD's 16 cycles each) next to ~260 cycles of softmax VALU issue — the SIMD's
+// ONE vector issue port is as busy as its matrix pipe (r02: 36 % of peak).  The 32x32x16 shape does the same FLOPs in half
+// the instructions (8 issue cycles of 32), which leaves the port to the softmax: issue ~410 against 512 pipe cycles per step.
+//   * a wave owns 32 query rows (column n = lane & 31 of every tile), a workgroup 4 x 32 = 128 rows as before;
+//   * S^T = K·Q^T: A = K rows (ds_read_b128, lane (r, h) reads hd [16 ks + 8 h, +8) of key r: the K image and its
+//     swizzle are unchanged), B = Q^T fragments kept in registers; the 32x32 result has a query per lane and 16 of the
+//     slab's 32 keys in its registers (key = (reg & 3) + 8 (reg >> 2) + 4 h), the other 16 in lane ^ 32: the softmax is
+//     lane-local up to ONE lane swap for the exact row maximum (slow path only);
+//   * P^T is the accumulator itself: registers 8 s .. 8 s + 7, rounded to bf16 pairwise, are the B fragment of k-step s
+//     of O^T += V^T·P^T with the k order permuted (element j of half h = key 16 s + 8 (j >> 2) + 4 h + (j & 3)); the V^T
+//     A fragment is fetched in that same order by two ds_read_b64_tr_b16 per (k-step, 32-wide hd block) from a V image
+//     swizzled chunk ^ (((key & 3) << 2) | ((key >> 2) & 3)) (conflict-free for this read: cdna_hip_programming.md T10 (b));
+//   * the denominator is a lane-local fp32 sum of the slab's (unrounded) p, the two halves of a row added once at the
+//     end, instead of an MFMA against a ones fragment.
+// Staging, buffer handling, work order, lazy maximum, masking rules and skip of dead slabs are the r02 kernel's.
+constexpr int FB_BQ = 128;  // query rows per workgroup (4 waves x 32)
+
+template <bool PAGED>
+__global__ __launch_bounds__(256, 2) void prefill_attn32_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
+    const int32_t* __restrict__ block_tables, int64_t bt_stride, bf16_t* __restrict__ out, int nh,
+    int nkv, int block_size, float scale_log2e, int nqblk, int nseq, int xcd_groups) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* bt_lds = reinterpret_cast<int*>(smem + 2 * FA_STAGE);
+    int qblk, head;
+    int64_t b;
+    {
+        const int L = blockIdx.x;
+        const int hpg = nh / nkv;
+        if (xcd_groups > 0) {
+            const int xcd = L & 7, j = L >> 3;
+            const int per_q = xcd_groups * hpg;
+            const int sidx = j / per_q, r = j - sidx * per_q;
+            const int group = (r / hpg) * 8 + xcd;
+            qblk = nqblk - 1 - sidx;
+            b = group / nkv;
+            head = (group % nkv) * hpg + r % hpg;
+        } else {
+            const int per_q = nh * nseq;
+            const int sidx = L / per_q, r = L - sidx * per_q;
+            qblk = nqblk - 1 - sidx;
+            b = r / nh;
+            head = r % nh;
+        }
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n32 = lane & 31, h = lane >> 5;
+    const int q0 = cu_q[b], lq = cu_q[b + 1] - q0;
+    const int k0 = cu_k[b], lk = cu_k[b + 1] - k0;
+    const int qbase = qblk * FB_BQ;
+    if (qbase >= lq) return;  // uniform
+    const int kvh = head / (nh / nkv);
+    const int off = lk - lq;
+    const int kend = min(lk, min(lq, qbase + FB_BQ) + off);
+    const int ntiles = (kend + FA_BK - 1) / FA_BK;
+    if (PAGED) {
+        const int nblk = (kend + block_size - 1) / block_size;
+        for (int i = tid; i < nblk; i += 256) bt_lds[i] = block_tables[b * bt_stride + i];
+    }
+    // Q^T fragments: lane (n32, h), k-step ks -> Q[row][16 ks + 8 h, +8)
+    const int qi = qbase + 32 * wid + n32;
+    const int row_first = qbase + 32 * wid;
+    bf16x8_t qf[8];
+    {
+        const bool ok = qi < lq;
+        const bf16_t* qrow = q + ((int64_t)(q0 + (ok ? qi : 0)) * nh + head) * FA_HD;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            u32x4_t t = {0, 0, 0, 0};
+            if (ok) t = *reinterpret_cast<const u32x4_t*>(qrow + 16 * ks + 8 * h);
+            qf[ks] = __builtin_bit_cast(bf16x8_t, t);
+        }
+    }
+    __syncthreads();
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(qf[4]), "+v"(qf[5]), "+v"(qf[6]), "+v"(qf[7]));
+
+    // ---- staging (as the r02 kernel; only the V swizzle differs) ----
+    constexpr int PPW = 4;  // 1 KiB pieces per wave, for K and for V
+    const int64_t row_bytes = (int64_t)nkv * FA_ROWB;
+    unsigned soff_k[PPW], soff_v[PPW];
+    auto vswz = [](int row) { return ((row & 3) << 2) | ((row >> 2) & 3); };
+    auto stage_offsets = [&](int t) {
+        const int r4 = lane >> 4, pch = lane & 15;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int row = (wid * PPW + i) * 4 + r4;
+            const int rc = min(t * FA_BK + row, lk - 1) - t * FA_BK;
+            soff_k[i] = (unsigned)(rc * (int)row_bytes) + ((pch ^ (row & 15)) << 4);
+            soff_v[i] = (unsigned)(rc * (int)row_bytes) + ((pch ^ vswz(row)) << 4);
+        }
+    };
+    if (!PAGED) stage_offsets(0);
+    auto stage_piece = [&](int buf, int t, int i) {
+        char* kd = smem + buf * FA_STAGE + (wid * PPW + i) * 1024;
+        char* vd = kd + FA_TILE;
+        if (!PAGED) {
+            if (i == 0 && (t + 1) * FA_BK > lk) stage_offsets(t);
+            const int64_t tb = ((int64_t)(k0 + t * FA_BK) * nkv + kvh) * FA_ROWB;
+            glds16(reinterpret_cast<const char*>(k) + tb + soff_k[i], kd);
+            glds16(reinterpret_cast<const char*>(v) + tb + soff_v[i], vd);
+        } else {
+            const int r4 = lane >> 4, pch = lane & 15;
+            const int row = (wid * PPW + i) * 4 + r4;
+            int key = t * FA_BK + row;
+            key = key < lk ? key : lk - 1;
+            const int pb = bt_lds[key / block_size];
+            const int64_t tok = (int64_t)pb * block_size + key % block_size;
+            const int64_t ro = (tok * nkv + kvh) * FA_HD;
+            glds16(k + ro + ((pch ^ (row & 15)) << 3), kd);
+            glds16(v + ro + ((pch ^ vswz(row)) << 3), vd);
+        }
+    };
+    auto stage = [&](int buf, int t) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) stage_piece(buf, t, i);
+    };
+
+    // ---- LDS fragment addresses of the CURRENT buffer ----
+    // K: row n32 (+32 per slab: immediate), chunk (2 ks + h) ^ (row & 15): one register per k-step
+    // V: lane = 16 g16 + 4 qq + pp supplies row r0 + qq, hd columns c0 + 4 pp .. +3 with r0 = 16 s + 8 jh + 4 (g16 >> 1),
+    //    c0 = 32 blk + 16 (g16 & 1): one register per (blk, jh); k-step s (+4096) and slab (+8192) are immediates
+    unsigned k_abs[8], v_abs[4][2];
+    {
+        const unsigned base = lds_addr(smem);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) k_abs[ks] = base + n32 * FA_ROWB + (((2 * ks + h) ^ (n32 & 15)) << 4);
+        const int g16 = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {
+                const int row = 8 * jh + 4 * (g16 >> 1) + qq;
+                const int ch = 4 * blk + 2 * (g16 & 1) + (pp >> 1);
+                v_abs[blk][jh] = base + FA_TILE + row * FA_ROWB + ((ch ^ vswz(row)) << 4) + ((pp & 1) << 3);
+            }
+    }
+
+    f32x16_t acc[4];  // O^T: hd block blk, lane = query column, reg -> hd 32 blk + (reg & 3) + 8 (reg >> 2) + 4 h
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float l_part = 0.f, m_run = -INFINITY, m_thr = -INFINITY;
+    const int jmax = qi + off;
+
+    u32x4_t kf[8];
+    u32x2_t vf[2][4][2];  // [k-step s][hd block][jh]
+#define FB_READ_K(SLAB)                                                                      \
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) lds_read_b128<(SLAB) * 8192>(kf[ks], k_abs[ks]);
+#define FB_READ_V(SLAB)                                                                      \
+    _Pragma("unroll") for (int blk = 0; blk < 4; ++blk) {                                    \
+        lds_read_tr16_b64<(SLAB) * 8192>(vf[0][blk][0], v_abs[blk][0]);                      \
+        lds_read_tr16_b64<(SLAB) * 8192>(vf[0][blk][1], v_abs[blk][1]);                      \
+        lds_read_tr16_b64<(SLAB) * 8192 + 4096>(vf[1][blk][0], v_abs[blk][0]);               \
+        lds_read_tr16_b64<(SLAB) * 8192 + 4096>(vf[1][blk][1], v_abs[blk][1]);               \
+    }
+#define FB_K_REGS "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]), "+v"(kf[5]), "+v"(kf[6]), "+v"(kf[7])
+#define FB_V_REGS                                                                                                  \
+    "+v"(vf[0][0][0]), "+v"(vf[0][0][1]), "+v"(vf[0][1][0]), "+v"(vf[0][1][1]), "+v"(vf[0][2][0]), "+v"(vf[0][2][1]), \
+        "+v"(vf[0][3][0]), "+v"(vf[0][3][1]), "+v"(vf[1][0][0]), "+v"(vf[1][0][1]), "+v"(vf[1][1][0]),               \
+        "+v"(vf[1][1][1]), "+v"(vf[1][2][0]), "+v"(vf[1][2][1]), "+v"(vf[1][3][0]), "+v"(vf[1][3][1])
+
+    auto s_mfma = [&](f32x16_t& s) {
+        const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf[0]), qf[0], zero, 0, 0, 0);  // C = 0 inline
+#pragma unroll
+        for (int ks = 1; ks < 8; ++ks)
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf[ks]), qf[ks], s, 0, 0, 0);
+    };
+    // online softmax of one slab (keys [kbase, kbase + 32) x this wave's 32 query rows): returns the two bf16 P^T fragments
+    // (k-steps 0 and 1) and leaves acc rescaled.  Reference point and lazy maximum exactly as the r02 kernel.
+    auto softmax = [&](f32x16_t& s, int kbase, bf16x8_t (&pf)[2]) {
+        const bool need_mask = kbase + 31 > row_first + off || kbase + 31 >= lk;
+        if (need_mask) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = kbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (j > jmax || j >= lk) s[r] = -INFINITY;
+            }
+        }
+        float mloc = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+        mloc = fmaxf(mloc, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
+        float ms = mloc * scale_log2e;
+        float m_use = m_run;
+        if (need_mask || !__all(ms <= m_thr)) {
+            // exact row maximum: the other 16 keys of the slab live in lane ^ 32
+            const u32x2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ms), __float_as_uint(ms), false, false);
+            ms = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            const float m_new = ms > m_run ? ms : m_run;
+            m_use = m_new;
+            if (need_mask) m_use = m_new == -INFINITY ? 0.f : m_new;
+            if (__any(m_new > m_run)) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+                l_part *= alpha;
+            }
+            m_run = m_new;
+            m_thr = m_new + 8.0f;
+        }
+        float lsum = 0.f;
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            u32x4_t pk;
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(s[8 * sidx + 2 * j2], scale_log2e, -m_use));
+                const float p1 = __builtin_amdgcn_exp2f(fmaf(s[8 * sidx + 2 * j2 + 1], scale_log2e, -m_use));
+                lsum += p0;  // fp32 denominator (flash-attention's convention; the oracle normalises in fp32 too)
+                lsum += p1;
+                unsigned w;
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(p0), "v"(p1));  // one instruction per pair (T12)
+                pk[j2] = w;
+            }
+            pf[sidx] = __builtin_bit_cast(bf16x8_t, pk);
+        }
+        l_part += lsum;
+    };
+    auto pv_mfma = [&](const bf16x8_t (&pf)[2]) {
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) {
+                const u32x4_t vv = {vf[sidx][blk][0][0], vf[sidx][blk][0][1], vf[sidx][blk][1][0], vf[sidx][blk][1][1]};
+                acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pf[sidx], acc[blk], 0, 0, 0);
+            }
+    };
+    asm volatile("" ::"s"(scale_log2e), "s"(lk), "s"(off));
+
+    if (ntiles > 0) {
+        f32x16_t sbuf[2];
+        bf16x8_t pf[2];
+        stage(0, 0);
+        if (ntiles > 1) {
+            stage(1, 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        // a slab whose 32 keys are all past the causal diagonal of this wave's 32 query rows (or past the sequence end)
+        auto live = [&](int kbase) -> bool { return kbase <= row_first + 31 + off && kbase < lk; };
+        FB_READ_K(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : FB_K_REGS : : "memory");
+        s_mfma(sbuf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        FB_READ_K(1);
+        for (int t = 0; t < ntiles; ++t) {
+            const int kb0 = t * FA_BK;
+            const bool more = t + 1 < ntiles;
+            // ---- slab 0: S(slab 1) goes to the matrix pipe first; V of slab 0 arrives while the softmax runs
+            asm volatile("s_waitcnt lgkmcnt(0)" : FB_K_REGS : : "memory");  // K of slab 1 (requested a whole step ago)
+            if (live(kb0 + 32)) s_mfma(sbuf[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            FB_READ_V(0);
+            if (t >= 1 && more) { stage_piece((t + 1) & 1, t + 1, 2); }
+            if (live(kb0)) softmax(sbuf[0], kb0, pf);
+            asm volatile("s_waitcnt lgkmcnt(0)" : FB_V_REGS : : "memory");
+            if (live(kb0)) pv_mfma(pf);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- slab 1: its V is the last LDS read of this buffer
+            FB_READ_V(1);
+            if (t >= 1 && more) { stage_piece((t + 1) & 1, t + 1, 3); }
+            if (more) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : FB_V_REGS : : "memory");
+                // tile t+1 was issued a whole tile ago; after the barrier every wave is done with this buffer, which tile
+                // t+2 may then overwrite
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (t + 2 < ntiles) { stage_piece(t & 1, t + 2, 0); }
+                const int flip = (t & 1) ? -FA_STAGE : FA_STAGE;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) k_abs[ks] += flip;
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) {
+                    v_abs[blk][0] += flip;
+                    v_abs[blk][1] += flip;
+                }
+                FB_READ_K(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" : FB_K_REGS : : "memory");
+                if (live(kb0 + FA_BK)) s_mfma(sbuf[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                FB_READ_K(1);
+                if (t + 2 < ntiles) { stage_piece(t & 1, t + 2, 1); }
+            }
+            if (live(kb0 + 32)) softmax(sbuf[1], kb0 + 32, pf);
+            if (!more) asm volatile("s_waitcnt lgkmcnt(0)" : FB_V_REGS : : "memory");
+            if (live(kb0 + 32)) pv_mfma(pf);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef FB_READ_K
+#undef FB_READ_V
+#undef FB_K_REGS
+#undef FB_V_REGS
+    // the two halves of a query's keys: one lane swap
+    {
+        const u32x2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_part), __float_as_uint(l_part), false, false);
+        const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        if (qi < lq) {
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+            bf16_t* orow = out + ((int64_t)(q0 + qi) * nh + head) * FA_HD;
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const u32x2_t o = {pack2bf(acc[blk][4 * rg] * inv, acc[blk][4 * rg + 1] * inv),
+                                       pack2bf(acc[blk][4 * rg + 2] * inv, acc[blk][4 * rg + 3] * inv)};
+                    *reinterpret_cast<u32x2_t*>(orow + 32 * blk + 8 * rg + 4 * h) = o;
+                }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int glm_varlen_attn_prefill(const void* q, const void* k, const void* v,
@@ -686,6 +1008,23 @@ extern "C" int glm_varlen_attn_prefill(const void* q, const void* k, const void*
     // K/V ring + the block-table slice (paged only): two workgroups per CU need <= 80 KiB each
     const size_t lds = 2 * FA_STAGE + (paged ? (size_t)bt_stride * 4 : 0);
     const float sl2 = scale * 1.4426950408889634f;
+    // r03 default: the 32x32x16 kernel (same grid, same workgroup shape); GLM_FA_MFMA32=0 runs the 16x16x32 kernel (A/B)
+    static const bool use32 = [] { const char* e = getenv("GLM_FA_MFMA32"); return !(e && e[0] == '0'); }();
+    if (use32 && FA_BQ == FB_BQ && FA_NT == 256) {
+        if (paged) {
+            GLM_SET_MAX_LDS(prefill_attn32_kernel<true>, 2 * FA_STAGE + FA_MAX_BT * 4, "glm_varlen_attn_prefill");
+            hipLaunchKernelGGL((prefill_attn32_kernel<true>), grid, dim3(256), lds, glm_s(stream), (const bf16_t*)q,
+                               (const bf16_t*)k, (const bf16_t*)v, cu_seqlens_q, cu_seqlens_k, block_tables, bt_stride,
+                               (bf16_t*)out, nh, nkv, block_size, sl2, nqblk, (int)B, xcd_groups);
+        } else {
+            GLM_SET_MAX_LDS(prefill_attn32_kernel<false>, 2 * FA_STAGE + FA_MAX_BT * 4, "glm_varlen_attn_prefill");
+            hipLaunchKernelGGL((prefill_attn32_kernel<false>), grid, dim3(256), lds, glm_s(stream), (const bf16_t*)q,
+                               (const bf16_t*)k, (const bf16_t*)v, cu_seqlens_q, cu_seqlens_k, block_tables, bt_stride,
+                               (bf16_t*)out, nh, nkv, block_size, sl2, nqblk, (int)B, xcd_groups);
+        }
+        GLM_CHECK_LAUNCH("glm_varlen_attn_prefill");
+        return GLM_OK;
+    }
     if (paged)
         hipLaunchKernelGGL((prefill_attn_kernel<true>), grid, dim3(FA_NT), lds, glm_s(stream), (const bf16_t*)q,
                            (const bf16_t*)k, (const bf16_t*)v, cu_seqlens_q, cu_seqlens_k, block_tables,

@@ -814,6 +814,10 @@ def can_combine_norm_gemm(dc, H: int) -> bool:
             and os.environ.get("GLM4MOE_TINYM", "1") != "0" and os.environ.get("GLM4MOE_FUSE_COMBINE_QKV", "1") != "0")
 
 
+_tail_ws: dict = {}
+_tail_ws_retired: list = []
+
+
 def can_gemm_router_tail(x: torch.Tensor, H: int, E: int) -> bool:
     return (x.dim() == 2 and x.shape[0] == 1 and 2048 <= H <= 4096 and H % 8 == 0 and E <= 256 and x.is_contiguous()
             and os.environ.get("GLM4MOE_TINYM", "1") != "0" and os.environ.get("GLM4MOE_FUSE_OPROJ_ROUTER", "1") != "0")
@@ -838,8 +842,8 @@ def gemm_add_rmsnorm_router_topk_align(x: torch.Tensor, w: torch.Tensor, residua
     tok = torch.empty(R, dtype=torch.int32, device=dev)
     scale = torch.empty(R, dtype=torch.bfloat16, device=dev)
     pos = torch.empty(k, dtype=torch.int32, device=dev)
-    rws = _router_workspace(dev, 1, E)
-    ticket = rws.data_ptr() + 16  # word 4 of the router workspace's (zeroed, self-restoring) counter block
+    # two self-restoring counters + E floats of logits scratch, one grow-only zeroed buffer per device
+    ticket = _grow_only(_tail_ws, _tail_ws_retired, dev, 16 + 4 * 256, "router-tail workspace").data_ptr()
     _check(load_library().glm_gemm_bf16_router_tail(
         _p(x), _p(w), w.stride(0), K, H, _p(o_row), ticket, _p(r2), _p(norm_weight), eps, _p(y), _p(ro), _p(gate_w),
         _p(bias), E, k, routed_scaling_factor, _p(idx), _p(tw), _p(offs), _p(tok), _p(scale), _p(pos), 1 if with_shared else 0,

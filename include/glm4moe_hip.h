@@ -185,12 +185,15 @@ int glm_grouped_gemm_down(const void* act, const void* w2,
                           int64_t R, int H, int I, int G, glm_stream_t stream);
 
 /* a10 + a3 + a11 + bucketing for ONE token (attention_new.py o_proj, decode_layer.py:86-93, moe.py:28-50), r03:
- *     o = bf16(x·Woᵀ)  (x [1, K], Wo [H, K], no bias);  then, in the workgroup of the GEMV that finishes LAST (its peers'
- *     rows reach it through write-through stores and a ticket — no second launch):
+ *     o = bf16(x·Woᵀ)  (x [1, K], Wo [H, K], no bias);  then, inside the same launch (the output row reaches the workgroups
+ *     that continue through write-through stores and a completion counter):
  *     s = f32(o) + f32(residual_in); residual_out = bf16(s); y_norm = bf16(bf16(s*rstd)*norm_weight);
  *     (topk_idx, topk_w) = router R1..R7 on y_norm;  expert_offsets / sorted_token / sorted_scale / pair_pos as
  *     glm_moe_align(T = 1).  Bit-identical to glm_gemm_bf16 followed by glm_add_rmsnorm_router_topk_align.
- *     o_row: [H] bf16 scratch (the projection's output row).  ticket: one uint32, ZERO before the first launch, left zero.
+ *     o_row: [H] bf16 scratch (the projection's output row).  ticket: 16 + 4 E bytes of scratch, 16-byte aligned; its first
+ *     two uint32 are counters that must be ZERO before the first launch (the launch leaves them zero), E floats of logits
+ *     follow at byte 16.  The tail runs in ceil(E / 16) designated workgroups that requested their 16 gate rows into LDS at
+ *     kernel start and wait (bounded) for the projection's completion counter.
  *     GLM_ERR_UNSUPPORTED: H > 4096, H < 2048, E > 256, unaligned buffers.                                             */
 int glm_gemm_bf16_router_tail(const void* x, const void* w, int64_t ldw, int K, int H, void* o_row, uint32_t* ticket,
                               const void* residual_in, const void* norm_weight, float eps, void* y_norm,
