@@ -1099,9 +1099,15 @@ int glm_launch_gemm_smallm_fp8w(int mode, const GemmParams& p, hipStream_t st) {
     // 71.3 with the two-step fp8 -> bf16 conversion; with the packed convert (sm_fp8x8_to_bf16x8) the shared-activation
     // body wins for both (tools/fp8_bench.py, same box: gate|up 122.5 -> 111.5 us, down 67.5 (VGPR body) -> 60.1 us);
     // -DGLM_SM_FP8_NO_SX_DOWN keeps the VGPR body for down; 3 stages at one workgroup per CU measured 165.7 / 91.1
-    if (p.R > 16 && mode == GEMM_GATEUP) return launch_cfg_sx<GEMM_GATEUP, 4, 2, 1, true>(p, st);
+#ifndef GLM_SX_GATEUP_NW
+#define GLM_SX_GATEUP_NW 4
+#endif
+#ifndef GLM_SX_DOWN_NW
+#define GLM_SX_DOWN_NW 4   // waves per workgroup = 32-column slabs that share one activation tile (r03 sweep: tools/sweep_fp8_sx.sh)
+#endif
+    if (p.R > 16 && mode == GEMM_GATEUP) return launch_cfg_sx<GEMM_GATEUP, GLM_SX_GATEUP_NW, 2, 1, true>(p, st);
 #ifndef GLM_SM_FP8_NO_SX_DOWN
-    if (p.R > 16 && mode == GEMM_DOWN) return launch_cfg_sx<GEMM_DOWN, 4, 2, 1, true>(p, st);
+    if (p.R > 16 && mode == GEMM_DOWN) return launch_cfg_sx<GEMM_DOWN, GLM_SX_DOWN_NW, 2, 1, true>(p, st);
 #endif
 #endif
     if (mode == GEMM_GATEUP) return launch_cfg<GEMM_GATEUP, GLM_SM_CFG_GATEUP_W8, true>(p, st);

@@ -49,6 +49,10 @@
 #ifndef GLM_FA_STAMP
 #define GLM_FA_STAMP 0
 #endif
+#ifndef GLM_FA_DEFAULT_MFMA32
+#define GLM_FA_DEFAULT_MFMA32 0  // kernel when GLM_FA_MFMA32 is unset: 0 = 16x16x32 (r02), 1 = 32x32x16
+#endif
+constexpr int FA_DEFAULT_MFMA32 = GLM_FA_DEFAULT_MFMA32;
 #if GLM_FA_STAMP
 __device__ unsigned long long g_fa_stamps[16];
 #define FA_T(i) do { unsigned long long t_ = __builtin_readcyclecounter(); if (i) tacc[(i) - 1] += t_ - tprev; tprev = t_; } while (0)
@@ -659,7 +663,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
 
 
 // ==========================================================================================================================
-// r03: the same kernel on v_mfma_f32_32x32x16_bf16 (prefill_attn32_kernel).  Why: with 16x16x32 MFMAs a (32 keys x 32 query
+// r03 (OPT-IN, GLM_FA_MFMA32=1): the same kernel on v_mfma_f32_32x32x16_bf16 (prefill_attn32_kernel).  Why it was built: with 16x16x32 MFMAs a (32 keys x 32 query
 // rows) step costs 34 MFMA issues (8 of a SIMD's 16 cycles each) next to ~260 cycles of softmax VALU issue — the SIMD's
 // ONE vector issue port is as busy as its matrix pipe (r02: 36 % of peak).  The 32x32x16 shape does the same FLOPs in half
 // the instructions (8 issue cycles of 32), which leaves the port to the softmax: issue ~410 against 512 pipe cycles per step.
@@ -675,14 +679,18 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
 //   * the denominator is a lane-local fp32 sum of the slab's (unrounded) p, the two halves of a row added once at the
 //     end, instead of an MFMA against a ones fragment.
 // Staging, buffer handling, work order, lazy maximum, masking rules and skip of dead slabs are the r02 kernel's.
-constexpr int FB_BQ = 128;  // query rows per workgroup (4 waves x 32)
-
-template <bool PAGED>
-__global__ __launch_bounds__(256, 2) void prefill_attn32_kernel(
+// QB = 32-row query blocks per wave.  Only QB = 1 is built (two waves per SIMD, 128 rows per workgroup).  QB = 2 — 64 rows
+// per wave at ONE wave per SIMD, every K/V fragment read feeding two blocks, with its own schedule (S(0), S(1) | softmax(0)
+// beside S(1) in the pipe | PV(0) | softmax(1) beside PV(0) | PV(1)) — was built and measured in r03: hipcc spreads the 512
+// registers as 256 VGPR + 251 AGPR with ~1400 v_accvgpr copies in the kernel, 526 TFLOP/s and one failing parity case; that
+// structure needs asm-pinned accumulators (cdna_hip_programming.md §5.7) and is not in the tree.
+template <bool PAGED, int QB>
+__global__ __launch_bounds__(256, (QB == 1 ? 2 : 1)) void prefill_attn32_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
     const int32_t* __restrict__ block_tables, int64_t bt_stride, bf16_t* __restrict__ out, int nh,
     int nkv, int block_size, float scale_log2e, int nqblk, int nseq, int xcd_groups) {
+    constexpr int BQ = 128 * QB;  // query rows per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* bt_lds = reinterpret_cast<int*>(smem + 2 * FA_STAGE);
     int qblk, head;
@@ -711,32 +719,38 @@ __global__ __launch_bounds__(256, 2) void prefill_attn32_kernel(
     const int n32 = lane & 31, h = lane >> 5;
     const int q0 = cu_q[b], lq = cu_q[b + 1] - q0;
     const int k0 = cu_k[b], lk = cu_k[b + 1] - k0;
-    const int qbase = qblk * FB_BQ;
+    const int qbase = qblk * BQ;
     if (qbase >= lq) return;  // uniform
     const int kvh = head / (nh / nkv);
     const int off = lk - lq;
-    const int kend = min(lk, min(lq, qbase + FB_BQ) + off);
+    const int kend = min(lk, min(lq, qbase + BQ) + off);
     const int ntiles = (kend + FA_BK - 1) / FA_BK;
     if (PAGED) {
         const int nblk = (kend + block_size - 1) / block_size;
         for (int i = tid; i < nblk; i += 256) bt_lds[i] = block_tables[b * bt_stride + i];
     }
-    // Q^T fragments: lane (n32, h), k-step ks -> Q[row][16 ks + 8 h, +8)
-    const int qi = qbase + 32 * wid + n32;
-    const int row_first = qbase + 32 * wid;
-    bf16x8_t qf[8];
-    {
-        const bool ok = qi < lq;
-        const bf16_t* qrow = q + ((int64_t)(q0 + (ok ? qi : 0)) * nh + head) * FA_HD;
+    // Q^T fragments: lane (n32, h), block qb, k-step ks -> Q[row][16 ks + 8 h, +8)
+    int qi[QB], row_first[QB], jmax[QB];
+    bf16x8_t qf[QB][8];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        row_first[qb] = qbase + 32 * QB * wid + 32 * qb;
+        qi[qb] = row_first[qb] + n32;
+        jmax[qb] = qi[qb] + off;
+        const bool ok = qi[qb] < lq;
+        const bf16_t* qrow = q + ((int64_t)(q0 + (ok ? qi[qb] : 0)) * nh + head) * FA_HD;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             u32x4_t t = {0, 0, 0, 0};
             if (ok) t = *reinterpret_cast<const u32x4_t*>(qrow + 16 * ks + 8 * h);
-            qf[ks] = __builtin_bit_cast(bf16x8_t, t);
+            qf[qb][ks] = __builtin_bit_cast(bf16x8_t, t);
         }
     }
     __syncthreads();
-    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(qf[4]), "+v"(qf[5]), "+v"(qf[6]), "+v"(qf[7]));
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+        asm volatile("" : "+v"(qf[qb][0]), "+v"(qf[qb][1]), "+v"(qf[qb][2]), "+v"(qf[qb][3]), "+v"(qf[qb][4]), "+v"(qf[qb][5]),
+                     "+v"(qf[qb][6]), "+v"(qf[qb][7]));
 
     // ---- staging (as the r02 kernel; only the V swizzle differs) ----
     constexpr int PPW = 4;  // 1 KiB pieces per wave, for K and for V
@@ -799,13 +813,18 @@ __global__ __launch_bounds__(256, 2) void prefill_attn32_kernel(
             }
     }
 
-    f32x16_t acc[4];  // O^T: hd block blk, lane = query column, reg -> hd 32 blk + (reg & 3) + 8 (reg >> 2) + 4 h
+    f32x16_t acc[QB][4];  // O^T: hd block blk, lane = query column, reg -> hd 32 blk + (reg & 3) + 8 (reg >> 2) + 4 h
+    float l_part[QB], m_run[QB], m_thr[QB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    float l_part = 0.f, m_run = -INFINITY, m_thr = -INFINITY;
-    const int jmax = qi + off;
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[qb][i][r] = 0.f;
+        l_part[qb] = 0.f;
+        m_run[qb] = -INFINITY;
+        m_thr[qb] = -INFINITY;
+    }
 
     u32x4_t kf[8];
     u32x2_t vf[2][4][2];  // [k-step s][hd block][jh]
@@ -824,45 +843,45 @@ __global__ __launch_bounds__(256, 2) void prefill_attn32_kernel(
         "+v"(vf[0][3][0]), "+v"(vf[0][3][1]), "+v"(vf[1][0][0]), "+v"(vf[1][0][1]), "+v"(vf[1][1][0]),               \
         "+v"(vf[1][1][1]), "+v"(vf[1][2][0]), "+v"(vf[1][2][1]), "+v"(vf[1][3][0]), "+v"(vf[1][3][1])
 
-    auto s_mfma = [&](f32x16_t& s) {
+    auto s_mfma = [&](f32x16_t& s, int qb) {
         const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf[0]), qf[0], zero, 0, 0, 0);  // C = 0 inline
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf[0]), qf[qb][0], zero, 0, 0, 0);  // C = 0 inline
 #pragma unroll
         for (int ks = 1; ks < 8; ++ks)
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf[ks]), qf[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf[ks]), qf[qb][ks], s, 0, 0, 0);
     };
-    // online softmax of one slab (keys [kbase, kbase + 32) x this wave's 32 query rows): returns the two bf16 P^T fragments
-    // (k-steps 0 and 1) and leaves acc rescaled.  Reference point and lazy maximum exactly as the r02 kernel.
-    auto softmax = [&](f32x16_t& s, int kbase, bf16x8_t (&pf)[2]) {
-        const bool need_mask = kbase + 31 > row_first + off || kbase + 31 >= lk;
+    // online softmax of one slab (keys [kbase, kbase + 32) x query block qb): returns the two bf16 P^T fragments (k-steps 0
+    // and 1) and leaves acc[qb] rescaled.  Reference point and lazy maximum exactly as the r02 kernel.
+    auto softmax = [&](f32x16_t& s, int kbase, int qb, bf16x8_t (&pf)[2]) {
+        const bool need_mask = kbase + 31 > row_first[qb] + off || kbase + 31 >= lk;
         if (need_mask) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = kbase + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (j > jmax || j >= lk) s[r] = -INFINITY;
+                if (j > jmax[qb] || j >= lk) s[r] = -INFINITY;
             }
         }
         float mloc = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
         mloc = fmaxf(mloc, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
         float ms = mloc * scale_log2e;
-        float m_use = m_run;
-        if (need_mask || !__all(ms <= m_thr)) {
+        float m_use = m_run[qb];
+        if (need_mask || !__all(ms <= m_thr[qb])) {
             // exact row maximum: the other 16 keys of the slab live in lane ^ 32
             const u32x2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ms), __float_as_uint(ms), false, false);
             ms = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-            const float m_new = ms > m_run ? ms : m_run;
+            const float m_new = ms > m_run[qb] ? ms : m_run[qb];
             m_use = m_new;
             if (need_mask) m_use = m_new == -INFINITY ? 0.f : m_new;
-            if (__any(m_new > m_run)) {
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+            if (__any(m_new > m_run[qb])) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
-                l_part *= alpha;
+                    for (int r = 0; r < 16; ++r) acc[qb][i][r] *= alpha;
+                l_part[qb] *= alpha;
             }
-            m_run = m_new;
-            m_thr = m_new + 8.0f;
+            m_run[qb] = m_new;
+            m_thr[qb] = m_new + 8.0f;
         }
         float lsum = 0.f;
 #pragma unroll
@@ -880,22 +899,22 @@ __global__ __launch_bounds__(256, 2) void prefill_attn32_kernel(
             }
             pf[sidx] = __builtin_bit_cast(bf16x8_t, pk);
         }
-        l_part += lsum;
+        l_part[qb] += lsum;
     };
-    auto pv_mfma = [&](const bf16x8_t (&pf)[2]) {
+    auto pv_mfma = [&](const bf16x8_t (&pf)[2], int qb) {
 #pragma unroll
         for (int sidx = 0; sidx < 2; ++sidx)
 #pragma unroll
             for (int blk = 0; blk < 4; ++blk) {
                 const u32x4_t vv = {vf[sidx][blk][0][0], vf[sidx][blk][0][1], vf[sidx][blk][1][0], vf[sidx][blk][1][1]};
-                acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pf[sidx], acc[blk], 0, 0, 0);
+                acc[qb][blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pf[sidx], acc[qb][blk], 0, 0, 0);
             }
     };
     asm volatile("" ::"s"(scale_log2e), "s"(lk), "s"(off));
 
     if (ntiles > 0) {
-        f32x16_t sbuf[2];
-        bf16x8_t pf[2];
+        f32x16_t sbuf[2][QB];
+        bf16x8_t pf[QB][2];
         stage(0, 0);
         if (ntiles > 1) {
             stage(1, 1);
@@ -904,11 +923,12 @@ __global__ __launch_bounds__(256, 2) void prefill_attn32_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        // a slab whose 32 keys are all past the causal diagonal of this wave's 32 query rows (or past the sequence end)
-        auto live = [&](int kbase) -> bool { return kbase <= row_first + 31 + off && kbase < lk; };
+        // a slab whose 32 keys are all past the causal diagonal of a 32-row query block (or past the sequence end)
+        auto live = [&](int kbase, int qb) -> bool { return kbase <= row_first[qb] + 31 + off && kbase < lk; };
         FB_READ_K(0);
         asm volatile("s_waitcnt lgkmcnt(0)" : FB_K_REGS : : "memory");
-        s_mfma(sbuf[0]);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) s_mfma(sbuf[0][qb], qb);
         __builtin_amdgcn_sched_barrier(0);
         FB_READ_K(1);
         for (int t = 0; t < ntiles; ++t) {
@@ -916,13 +936,19 @@ __global__ __launch_bounds__(256, 2) void prefill_attn32_kernel(
             const bool more = t + 1 < ntiles;
             // ---- slab 0: S(slab 1) goes to the matrix pipe first; V of slab 0 arrives while the softmax runs
             asm volatile("s_waitcnt lgkmcnt(0)" : FB_K_REGS : : "memory");  // K of slab 1 (requested a whole step ago)
-            if (live(kb0 + 32)) s_mfma(sbuf[1]);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+                if (live(kb0 + 32, qb)) s_mfma(sbuf[1][qb], qb);
             __builtin_amdgcn_sched_barrier(0);
             FB_READ_V(0);
             if (t >= 1 && more) { stage_piece((t + 1) & 1, t + 1, 2); }
-            if (live(kb0)) softmax(sbuf[0], kb0, pf);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+                if (live(kb0, qb)) softmax(sbuf[0][qb], kb0, qb, pf[qb]);
             asm volatile("s_waitcnt lgkmcnt(0)" : FB_V_REGS : : "memory");
-            if (live(kb0)) pv_mfma(pf);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+                if (live(kb0, qb)) pv_mfma(pf[qb], qb);
             __builtin_amdgcn_sched_barrier(0);
             // ---- slab 1: its V is the last LDS read of this buffer
             FB_READ_V(1);
@@ -944,14 +970,20 @@ __global__ __launch_bounds__(256, 2) void prefill_attn32_kernel(
                 }
                 FB_READ_K(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" : FB_K_REGS : : "memory");
-                if (live(kb0 + FA_BK)) s_mfma(sbuf[0]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    if (live(kb0 + FA_BK, qb)) s_mfma(sbuf[0][qb], qb);
                 __builtin_amdgcn_sched_barrier(0);
                 FB_READ_K(1);
                 if (t + 2 < ntiles) { stage_piece(t & 1, t + 2, 1); }
             }
-            if (live(kb0 + 32)) softmax(sbuf[1], kb0 + 32, pf);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+                if (live(kb0 + 32, qb)) softmax(sbuf[1][qb], kb0 + 32, qb, pf[qb]);
             if (!more) asm volatile("s_waitcnt lgkmcnt(0)" : FB_V_REGS : : "memory");
-            if (live(kb0 + 32)) pv_mfma(pf);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+                if (live(kb0 + 32, qb)) pv_mfma(pf[qb], qb);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -960,18 +992,19 @@ __global__ __launch_bounds__(256, 2) void prefill_attn32_kernel(
 #undef FB_K_REGS
 #undef FB_V_REGS
     // the two halves of a query's keys: one lane swap
-    {
-        const u32x2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_part), __float_as_uint(l_part), false, false);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const u32x2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_part[qb]), __float_as_uint(l_part[qb]), false, false);
         const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-        if (qi < lq) {
+        if (qi[qb] < lq) {
             const float inv = l > 0.f ? 1.0f / l : 0.f;
-            bf16_t* orow = out + ((int64_t)(q0 + qi) * nh + head) * FA_HD;
+            bf16_t* orow = out + ((int64_t)(q0 + qi[qb]) * nh + head) * FA_HD;
 #pragma unroll
             for (int blk = 0; blk < 4; ++blk)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-                    const u32x2_t o = {pack2bf(acc[blk][4 * rg] * inv, acc[blk][4 * rg + 1] * inv),
-                                       pack2bf(acc[blk][4 * rg + 2] * inv, acc[blk][4 * rg + 3] * inv)};
+                    const u32x2_t o = {pack2bf(acc[qb][blk][4 * rg] * inv, acc[qb][blk][4 * rg + 1] * inv),
+                                       pack2bf(acc[qb][blk][4 * rg + 2] * inv, acc[qb][blk][4 * rg + 3] * inv)};
                     *reinterpret_cast<u32x2_t*>(orow + 32 * blk + 8 * rg + 4 * h) = o;
                 }
         }
@@ -1008,17 +1041,20 @@ extern "C" int glm_varlen_attn_prefill(const void* q, const void* k, const void*
     // K/V ring + the block-table slice (paged only): two workgroups per CU need <= 80 KiB each
     const size_t lds = 2 * FA_STAGE + (paged ? (size_t)bt_stride * 4 : 0);
     const float sl2 = scale * 1.4426950408889634f;
-    // r03 default: the 32x32x16 kernel (same grid, same workgroup shape); GLM_FA_MFMA32=0 runs the 16x16x32 kernel (A/B)
-    static const bool use32 = [] { const char* e = getenv("GLM_FA_MFMA32"); return !(e && e[0] == '0'); }();
-    if (use32 && FA_BQ == FB_BQ && FA_NT == 256) {
+    // GLM_FA_MFMA32=1 (read at every call): the 32x32x16 kernel (same grid and workgroup shape as the default 16x16x32
+    // kernel).  Parity green (test_varlen_attn_prefill_mfma32); measured r03, one box, interleaved processes: 746-754 against
+    // 789-805 TFLOP/s at 4 x 4096 tokens, so it stays opt-in.
+    const char* e32 = getenv("GLM_FA_MFMA32");
+    const bool use32 = (e32 && e32[0] == '1') || (e32 == nullptr && FA_DEFAULT_MFMA32 == 1);
+    if (use32 && FA_BQ == 128) {
         if (paged) {
-            GLM_SET_MAX_LDS(prefill_attn32_kernel<true>, 2 * FA_STAGE + FA_MAX_BT * 4, "glm_varlen_attn_prefill");
-            hipLaunchKernelGGL((prefill_attn32_kernel<true>), grid, dim3(256), lds, glm_s(stream), (const bf16_t*)q,
+            GLM_SET_MAX_LDS((prefill_attn32_kernel<true, 1>), 2 * FA_STAGE + FA_MAX_BT * 4, "glm_varlen_attn_prefill");
+            hipLaunchKernelGGL((prefill_attn32_kernel<true, 1>), grid, dim3(256), lds, glm_s(stream), (const bf16_t*)q,
                                (const bf16_t*)k, (const bf16_t*)v, cu_seqlens_q, cu_seqlens_k, block_tables, bt_stride,
                                (bf16_t*)out, nh, nkv, block_size, sl2, nqblk, (int)B, xcd_groups);
         } else {
-            GLM_SET_MAX_LDS(prefill_attn32_kernel<false>, 2 * FA_STAGE + FA_MAX_BT * 4, "glm_varlen_attn_prefill");
-            hipLaunchKernelGGL((prefill_attn32_kernel<false>), grid, dim3(256), lds, glm_s(stream), (const bf16_t*)q,
+            GLM_SET_MAX_LDS((prefill_attn32_kernel<false, 1>), 2 * FA_STAGE + FA_MAX_BT * 4, "glm_varlen_attn_prefill");
+            hipLaunchKernelGGL((prefill_attn32_kernel<false, 1>), grid, dim3(256), lds, glm_s(stream), (const bf16_t*)q,
                                (const bf16_t*)k, (const bf16_t*)v, cu_seqlens_q, cu_seqlens_k, block_tables, bt_stride,
                                (bf16_t*)out, nh, nkv, block_size, sl2, nqblk, (int)B, xcd_groups);
         }
