@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/pmc_tr
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_tr/$c -- python3 $R/bench.py --layers 3 --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-c2 --kernel-iters 12 > $R/gpurun_out/pmc_tr/$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_tr/$c -- python3 $R/bench.py --layers 3 --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-c2 --no-extras --kernel-iters 12 > $R/gpurun_out/pmc_tr/$c.log 2>&1
 done
 python3 - <<PY
 import csv, glob, json, statistics, collections, re
@@ -51,7 +51,7 @@ import sys
 sys.path.insert(0, "$R")
 import bench
 out["_meta"] = {"kernel_source_digest": bench._kernel_source_digest(), "git_head": bench._git("rev-parse", "--short", "HEAD"),
-                "command": "bench.py --layers 3 --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-c2 --kernel-iters 12",
+                "command": "bench.py --layers 3 --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-c2 --no-extras --kernel-iters 12",
                 "passes": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace", "rocprofv3 --pmc WRITE_SIZE --kernel-trace"]}
 json.dump(out, open("$R/gpurun_out/pmc_traffic.json", "w"), indent=1)
 for k, v in out.items():
