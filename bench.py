@@ -703,6 +703,9 @@ def measure_fp8(model, cfg, ops, step, B, ctx, L, args, dev):
         g.replay()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    # twice, the second reading reported: right after the CPU-baseline leg the first isolated measurement of this leg read
+    # 117 / 144 / 158 us for the same gate|up launch on three boxes while the captured step around it was stable (r03)
+    measure_kernels(model, cfg, ops, B, ctx, 1, max(4, args.kernel_iters // 4), dev, only_experts=True)
     ks = measure_kernels(model, cfg, ops, B, ctx, 1, args.kernel_iters, dev, only_experts=True)
     return {"workload": f"same model and decode step (bs={B} ctx={ctx} L={L}), experts as fp8 e4m3 weight-only",
             "tokens_per_s": round(B / dt, 2), "ms_per_step": round(dt * 1e3, 4), "ms_per_layer": round(dt * 1e3 / L, 4),
