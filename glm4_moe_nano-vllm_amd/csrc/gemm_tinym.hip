@@ -26,7 +26,7 @@ namespace {
 
 constexpr int TM_NT = 512;
 constexpr int TM_NW = TM_NT / 64;
-constexpr int TM_RPW = 4;      // weight rows per tile
+constexpr int TM_RPW = 4;      // weight rows per tile (dense launches; grouped launches: template parameter RPW)
 constexpr int TM_MAXG = 320;   // groups a grouped launch may have (list of non-empty groups in LDS)
 
 #ifndef GLM_TM_NT_LOADS
@@ -256,8 +256,11 @@ __device__ __forceinline__ void tinym_router_tail(const TinyParams& tp, char* sm
 }
 
 // MODE as gemm_smallm; M = token rows per group block (1 or 2); SEGS = 1-KiB segments of a weight row per unit
-template <int MODE, int M, int SEGS, bool PRO, bool TAIL = false>
+template <int MODE, int M, int SEGS, bool PRO, bool TAIL = false, int RPW = TM_RPW>
 __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) {
+    static_assert(RPW == 2 || RPW == 4, "2 or 4 weight rows per tile");
+    static_assert(!TAIL || RPW == 4, "the router tail hands 8-byte pieces over");
+    constexpr int HALF = RPW / 2;  // gate|up: HALF gate rows + the matching HALF up rows
     const GemmParams& p = tp.g;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int sh_grp[TM_MAXG];   // non-empty groups
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) 
     constexpr int KU = SEGS * 512;                 // k elements per unit
     const int nunits = (K + KU - 1) / KU;
     const int Kp = nunits * KU;                    // padded row length in LDS (pad = zeros)
-    const int tpg = MODE == GEMM_GATEUP ? p.N / 2 : p.N / TM_RPW;  // tiles per group
+    const int tpg = MODE == GEMM_GATEUP ? p.N / HALF : p.N / RPW;  // tiles per group
 
     // ---- non-empty groups (grouped modes) ----
     int nact = 1;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) 
 
     // ---- per-tile set-up ----
     struct Tile {
-        const char* wrow[TM_RPW];
+        const char* wrow[RPW];
         int grp, ncol, m0, mcnt;
     };
     auto set_tile = [&](Tile& t, int tile) {
@@ -306,18 +309,18 @@ __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) 
         t.m0 = p.offs ? p.offs[grp] : 0;
         t.mcnt = p.offs ? min(p.offs[grp + 1] - t.m0, M) : (int)min((int64_t)M, p.R);
         const char* wg = reinterpret_cast<const char*>(p.w + (int64_t)grp * p.w_gstride);
-        if (MODE == GEMM_GATEUP) {  // rows: gate n, gate n+1, up n, up n+1
-            t.ncol = 2 * ti;
+        if (MODE == GEMM_GATEUP) {  // rows: gate n .. n+HALF-1, then up n .. n+HALF-1
+            t.ncol = HALF * ti;
 #pragma unroll
-            for (int r = 0; r < TM_RPW; ++r) t.wrow[r] = wg + ((int64_t)((r >> 1) * p.N + t.ncol + (r & 1)) * p.ldw) * 2;
+            for (int r = 0; r < RPW; ++r) t.wrow[r] = wg + ((int64_t)((r / HALF) * p.N + t.ncol + (r % HALF)) * p.ldw) * 2;
         } else {
-            t.ncol = TM_RPW * ti;
+            t.ncol = RPW * ti;
 #pragma unroll
-            for (int r = 0; r < TM_RPW; ++r) t.wrow[r] = wg + ((int64_t)(t.ncol + r) * p.ldw) * 2;
+            for (int r = 0; r < RPW; ++r) t.wrow[r] = wg + ((int64_t)(t.ncol + r) * p.ldw) * 2;
         }
     };
 
-    u32x4_t wbuf[2][SEGS][TM_RPW];
+    u32x4_t wbuf[2][SEGS][RPW];
     const char* zero = reinterpret_cast<const char*>(g_tm_zero_page);
     auto issue = [&](auto buf_tag, const Tile& t, int u) {
         constexpr int B = decltype(buf_tag)::value;
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) 
         for (int s = 0; s < SEGS; ++s) {
             const int k = u * KU + (s * 64 + lane) * 8;
 #pragma unroll
-            for (int r = 0; r < TM_RPW; ++r) wbuf[B][s][r] = tm_wload(k < K ? t.wrow[r] + (int64_t)k * 2 : zero);
+            for (int r = 0; r < RPW; ++r) wbuf[B][s][r] = tm_wload(k < K ? t.wrow[r] + (int64_t)k * 2 : zero);
         }
     };
 
@@ -387,9 +390,9 @@ __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) 
     }
     __syncthreads();
 
-    float acc[TM_RPW][M];
+    float acc[RPW][M];
 #pragma unroll
-    for (int r = 0; r < TM_RPW; ++r)
+    for (int r = 0; r < RPW; ++r)
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[r][m] = 0.f;
 
@@ -410,15 +413,15 @@ __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) 
 #pragma unroll
             for (int m = 0; m < M; ++m) xv[m] = *reinterpret_cast<const u32x4_t*>(xr[m] + u * KU + (s * 64 + lane) * 8);
 #pragma unroll
-            for (int r = 0; r < TM_RPW; ++r) tm_fma8<M>(acc[r], wbuf[B][s][r], xv);
+            for (int r = 0; r < RPW; ++r) tm_fma8<M>(acc[r], wbuf[B][s][r], xv);
         }
     };
 
     auto finish = [&](const Tile& t) {
         // cross-lane sums (every lane ends with the total), then the mode's epilogue from lane 0
-        float o[TM_RPW][M];
+        float o[RPW][M];
 #pragma unroll
-        for (int r = 0; r < TM_RPW; ++r)
+        for (int r = 0; r < RPW; ++r)
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 o[r][m] = wave_sum(acc[r][m]);
@@ -430,26 +433,32 @@ __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) 
             if (m >= t.mcnt) continue;
             const int64_t row = t.m0 + m;
             if (MODE == GEMM_GATEUP) {
-                const float a0 = rbf(glm_silu(rbf(o[0][m]))) * rbf(o[2][m]);
-                const float a1 = rbf(glm_silu(rbf(o[1][m]))) * rbf(o[3][m]);
-                *reinterpret_cast<unsigned*>(p.y + row * p.ldy + t.ncol) = pack2bf(a0, a1);
+                float a[HALF];
+#pragma unroll
+                for (int j = 0; j < HALF; ++j) a[j] = rbf(glm_silu(rbf(o[j][m]))) * rbf(o[HALF + j][m]);
+                if constexpr (HALF == 2) *reinterpret_cast<unsigned*>(p.y + row * p.ldy + t.ncol) = pack2bf(a[0], a[1]);
+                else p.y[row * p.ldy + t.ncol] = f2bf(a[0]);
             } else {
-                float v[TM_RPW];
+                float v[RPW];
                 float sc = 1.0f;
                 const bool scaled = MODE == GEMM_DOWN && t.grp < p.n_scaled;
                 if (scaled) sc = bf2f(p.scale[row]);
 #pragma unroll
-                for (int r = 0; r < TM_RPW; ++r) {
+                for (int r = 0; r < RPW; ++r) {
                     float a = o[r][m];
                     if (MODE == GEMM_PLAIN && p.bias) a += bf2f(p.bias[t.ncol + r]);
                     if (scaled) a = rbf(a) * sc;
                     v[r] = a;
                 }
-                const u32x2_t o2 = u32x2_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                if (TAIL)  // read by another workgroup of this launch: write-through (Guideline 16 R1)
-                    st_sc1_u64(p.y + row * p.ldy + t.ncol, (unsigned long long)o2[0] | ((unsigned long long)o2[1] << 32));
-                else
-                    *reinterpret_cast<u32x2_t*>(p.y + row * p.ldy + t.ncol) = o2;
+                if constexpr (RPW == 4) {
+                    const u32x2_t o2 = u32x2_t{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                    if (TAIL)  // read by another workgroup of this launch: write-through (Guideline 16 R1)
+                        st_sc1_u64(p.y + row * p.ldy + t.ncol, (unsigned long long)o2[0] | ((unsigned long long)o2[1] << 32));
+                    else
+                        *reinterpret_cast<u32x2_t*>(p.y + row * p.ldy + t.ncol) = o2;
+                } else {
+                    *reinterpret_cast<unsigned*>(p.y + row * p.ldy + t.ncol) = pack2bf(v[0], v[1]);
+                }
             }
         }
     };
@@ -516,7 +525,7 @@ int n_cus() {
     return n;
 }
 
-template <int MODE, int M, int SEGS, bool PRO, bool TAIL = false>
+template <int MODE, int M, int SEGS, bool PRO, bool TAIL = false, int RPW = TM_RPW>
 int launch_tiny(const TinyParams& tp, int xrows, hipStream_t st) {
     const GemmParams& p = tp.g;
     constexpr int KU = SEGS * 512;
@@ -525,9 +534,9 @@ int launch_tiny(const TinyParams& tp, int xrows, hipStream_t st) {
     size_t lds = (size_t)xrows * Kp * 2;
     if (lds < 84 * 1024) lds = 84 * 1024;
     GLM_CHECK_ARG(lds <= 156 * 1024, GLM_ERR_UNSUPPORTED, "gemm_tinym: %d activation rows of %d do not fit the LDS", xrows, Kp);
-    auto kern = gemm_tinym_kernel<MODE, M, SEGS, PRO, TAIL>;
+    auto kern = gemm_tinym_kernel<MODE, M, SEGS, PRO, TAIL, RPW>;
     GLM_SET_MAX_LDS(kern, 156 * 1024, "gemm_tinym");
-    const int64_t tiles = (int64_t)(p.offs ? p.G : 1) * (MODE == GEMM_GATEUP ? p.N / 2 : p.N / TM_RPW);
+    const int64_t tiles = (int64_t)(p.offs ? p.G : 1) * (MODE == GEMM_GATEUP ? p.N / (RPW / 2) : p.N / RPW);
     int nwg = n_cus();
     if (tiles < nwg) nwg = (int)tiles;
     if (TAIL) {  // the tail's scratch lives in the (dead) activation area; behind it TR_ROWS gate rows
@@ -570,9 +579,18 @@ int glm_launch_gemm_tinym(int mode, const GemmParams& p, int n_tokens, hipStream
     GLM_CHECK_ARG(M == 1, GLM_ERR_UNSUPPORTED, "gemm_tinym: %d rows per block", M);
     // units: 4 rows x 4 KiB for long rows; a short K (expert down projection, 1408) as ONE unit of 3-KiB rows
     if (mode == GEMM_PLAIN) return launch_tiny<GEMM_PLAIN, 1, 4, false>(tp, 1, st);
-    if (mode == GEMM_GATEUP) return launch_tiny<GEMM_GATEUP, 1, 4, false>(tp, n_tokens, st);
-    if (p.K <= 1536) return launch_tiny<GEMM_DOWN, 1, 3, false>(tp, (int)p.R, st);
-    return launch_tiny<GEMM_DOWN, 1, 4, false>(tp, (int)p.R, st);
+    // grouped launches: rows per tile chosen for the TAIL of the launch — a workgroup's waves pull tiles from a counter, and
+    // the launch ends when the slowest wave has finished its last tile; at Air dims one token gives 24.75 tiles of 4 rows per
+    // workgroup for gate|up (7 waves take 3, one takes 4: +29 % on the critical wave), 49.5 tiles of 2 rows even that out
+#ifndef GLM_TM_RPW_GATEUP
+#define GLM_TM_RPW_GATEUP 2
+#endif
+#ifndef GLM_TM_RPW_DOWN
+#define GLM_TM_RPW_DOWN 4
+#endif
+    if (mode == GEMM_GATEUP) return launch_tiny<GEMM_GATEUP, 1, (GLM_TM_RPW_GATEUP == 2 ? 8 : 4), false, false, GLM_TM_RPW_GATEUP>(tp, n_tokens, st);
+    if (p.K <= 1536) return launch_tiny<GEMM_DOWN, 1, 3, false, false, GLM_TM_RPW_DOWN>(tp, (int)p.R, st);
+    return launch_tiny<GEMM_DOWN, 1, 4, false, false, GLM_TM_RPW_DOWN>(tp, (int)p.R, st);
 }
 
 // QKV projection (+bias) of T <= 2 rows whose input is computed in the kernel: moe_combine of the previous layer's expert
