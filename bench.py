@@ -142,6 +142,8 @@ def main():
         local_rank = 0
     # N>1 pre-flight, before this process touches its GPU: may the layer stack be captured with its collectives?
     tp_graph_ok, tp_graph_note = True, None
+    if args.expert_parallel:
+        os.environ["GLM_PROBE_EP"] = "1"  # the capture pre-flight then also captures an all-to-all and an all-gather
     if world > 1 and not args.no_graph:
         if backend != "nccl" and os.environ.get("GLM_BENCH_FORCE_PROBE") != "1":
             tp_graph_ok, tp_graph_note = False, f"{backend} collectives cannot be captured"

@@ -60,6 +60,15 @@ __device__ unsigned long long g_fa_stamps[16];
 #define FA_T(i) do {} while (0)
 #endif
 
+#ifndef GLM_FA_NOSCHED
+#define GLM_FA_NOSCHED 0   // 1 (study): drop the scheduling fences of the unit loops and let hipcc interleave MFMA and VALU itself
+#endif
+#if GLM_FA_NOSCHED
+#define FA_SCHED_FENCE() do {} while (0)
+#else
+#define FA_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 namespace {
 
 constexpr int FA_HD = 128, FA_ROWB = 256;
@@ -455,7 +464,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
                 if (lv_prev) pv_mfma(pf_prev, pq);
                 pf_prev = pf;
                 lv_prev = lv;
-                __builtin_amdgcn_sched_barrier(0);
+                FA_SCHED_FENCE();
                 if constexpr (u == 0) { FA_READ_V(0); }       // PV of the previous tile's last unit is issued
                 if constexpr (u == FA_QT) { FA_READ_V(1); }   // PV(slab 0, last query tile) is issued
                 if constexpr (u == NU - 2) {
@@ -492,7 +501,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
                     asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");  // K of the next tile's slab 0
                     if (live(kb0 + FA_BK, 0)) s_mfma(sbuf[0], 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                FA_SCHED_FENCE();
                 // ---- LDS reads, staging, tile switch
                 if constexpr (u == 0) { FA_READ_V(0); }
                 if constexpr (u == FA_QT - 2) { FA_READ_K(1); }
@@ -525,7 +534,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
                 }
                 if constexpr (u == FA_QT && u != NU - 2) asm volatile("s_waitcnt lgkmcnt(0)" : FA_V_REGS : : "memory");
                 if (lv) pv_mfma(pf, qt);
-                __builtin_amdgcn_sched_barrier(0);
+                FA_SCHED_FENCE();
             });
         }
     }
@@ -561,7 +570,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
             // ---- unit (slab 0, q0): S(slab 0, q1) goes to the matrix pipe first, then K of slab 1 and V of
             // slab 0 are fetched while the softmax runs
             if (live(kb0, 1)) s_mfma(sb, 1);
-            __builtin_amdgcn_sched_barrier(0);
+            FA_SCHED_FENCE();
             FA_T(1);  // 0: S issue
             FA_READ_V(0);
             FA_READ_K(1);
@@ -572,24 +581,24 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
             asm volatile("s_waitcnt lgkmcnt(8)" : FA_V_REGS : : "memory");  // V landed, K may be in flight
             FA_T(4);  // 3: V wait
             if (live(kb0, 0)) pv_mfma(pf, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            FA_SCHED_FENCE();
             FA_T(5);  // 4: PV issue
             // ---- unit (slab 0, q1)
             asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
             FA_T(6);  // 5: K wait
             if (live(kb0 + 32, 0)) s_mfma(sa, 0);  // S(slab 1, q0)
-            __builtin_amdgcn_sched_barrier(0);
+            FA_SCHED_FENCE();
             if (t >= 1 && t + 1 < ntiles) stage_slot((t + 1) & 1, t + 1, 3);
             FA_T(7);  // 6: S issue + DMA
             if (live(kb0, 1)) {
                 pf = softmax(sb, kb0, 1);
                 pv_mfma(pf, 1);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            FA_SCHED_FENCE();
             FA_T(8);  // 7: softmax + PV
             // ---- unit (slab 1, q0): V of slab 1 is the last LDS read of this buffer
             if (live(kb0 + 32, 1)) s_mfma(sb, 1);  // S(slab 1, q1)
-            __builtin_amdgcn_sched_barrier(0);
+            FA_SCHED_FENCE();
             FA_READ_V(1);
             FA_T(9);  // 8: S issue + V read issue
             asm volatile("s_waitcnt lgkmcnt(0)" : FA_V_REGS : : "memory");
@@ -615,13 +624,13 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
                 pf = softmax(sa, kb0 + 32, 0);
                 pv_mfma(pf, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            FA_SCHED_FENCE();
             FA_T(14);  // 13: softmax + PV
             // ---- unit (slab 1, q1)
             if (more) {
                 asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
                 if (live(kb0 + FA_BK, 0)) s_mfma(sa, 0);  // S(tile t+1 slab 0, q0)
-                __builtin_amdgcn_sched_barrier(0);
+                FA_SCHED_FENCE();
                 if (t + 2 < ntiles) stage_slot(t & 1, t + 2, 1);
             }
             FA_T(15);  // 14: K wait + S issue + DMA
@@ -629,7 +638,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
                 pf = softmax(sb, kb0 + 32, 1);
                 pv_mfma(pf, 1);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            FA_SCHED_FENCE();
             FA_T(16);  // 15: softmax + PV
         }
 #if GLM_FA_STAMP
@@ -891,7 +900,7 @@ __global__ __launch_bounds__(256, (QB == 1 ? 2 : 1)) void prefill_attn32_kernel(
             for (int j2 = 0; j2 < 4; ++j2) {
                 const float p0 = __builtin_amdgcn_exp2f(fmaf(s[8 * sidx + 2 * j2], scale_log2e, -m_use));
                 const float p1 = __builtin_amdgcn_exp2f(fmaf(s[8 * sidx + 2 * j2 + 1], scale_log2e, -m_use));
-                lsum += p0;  // fp32 denominator (flash-attention's convention; the oracle normalises in fp32 too)
+                lsum += p0;  // fp32 denominator (flash-attention's convention: normalise in fp32, round P for the second product)
                 lsum += p1;
                 unsigned w;
                 asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(p0), "v"(p1));  // one instruction per pair (T12)
@@ -929,7 +938,7 @@ __global__ __launch_bounds__(256, (QB == 1 ? 2 : 1)) void prefill_attn32_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)" : FB_K_REGS : : "memory");
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) s_mfma(sbuf[0][qb], qb);
-        __builtin_amdgcn_sched_barrier(0);
+        FA_SCHED_FENCE();
         FB_READ_K(1);
         for (int t = 0; t < ntiles; ++t) {
             const int kb0 = t * FA_BK;
@@ -939,7 +948,7 @@ __global__ __launch_bounds__(256, (QB == 1 ? 2 : 1)) void prefill_attn32_kernel(
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
                 if (live(kb0 + 32, qb)) s_mfma(sbuf[1][qb], qb);
-            __builtin_amdgcn_sched_barrier(0);
+            FA_SCHED_FENCE();
             FB_READ_V(0);
             if (t >= 1 && more) { stage_piece((t + 1) & 1, t + 1, 2); }
 #pragma unroll
@@ -949,7 +958,7 @@ __global__ __launch_bounds__(256, (QB == 1 ? 2 : 1)) void prefill_attn32_kernel(
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
                 if (live(kb0, qb)) pv_mfma(pf[qb], qb);
-            __builtin_amdgcn_sched_barrier(0);
+            FA_SCHED_FENCE();
             // ---- slab 1: its V is the last LDS read of this buffer
             FB_READ_V(1);
             if (t >= 1 && more) { stage_piece((t + 1) & 1, t + 1, 3); }
@@ -973,7 +982,7 @@ __global__ __launch_bounds__(256, (QB == 1 ? 2 : 1)) void prefill_attn32_kernel(
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb)
                     if (live(kb0 + FA_BK, qb)) s_mfma(sbuf[0][qb], qb);
-                __builtin_amdgcn_sched_barrier(0);
+                FA_SCHED_FENCE();
                 FB_READ_K(1);
                 if (t + 2 < ntiles) { stage_piece(t & 1, t + 2, 1); }
             }
@@ -984,7 +993,7 @@ __global__ __launch_bounds__(256, (QB == 1 ? 2 : 1)) void prefill_attn32_kernel(
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
                 if (live(kb0 + 32, qb)) pv_mfma(pf[qb], qb);
-            __builtin_amdgcn_sched_barrier(0);
+            FA_SCHED_FENCE();
         }
     }
 #undef FB_READ_K
