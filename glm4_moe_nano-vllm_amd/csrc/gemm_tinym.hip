@@ -151,7 +151,11 @@ __device__ __forceinline__ void tinym_router_tail(const TinyParams& tp, char* sm
         tr_ok = ok;
     }
     __syncthreads();
-    if (!tr_ok) return;  // cannot happen while the GPU makes progress; never hang
+    if (!tr_ok) {  // cannot happen while the GPU makes progress; never hang, and never let stale data pass for a result
+        if (d == 0)
+            for (int i = threadIdx.x; i < (H >> 1); i += TM_NT) reinterpret_cast<unsigned*>(tp.tr_y)[i] = 0x7fc07fc0u;  // NaN
+        return;
+    }
     // the x rows are dead (every wave is past its last tile): xs / hand-over area / logits / bias live there
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                         // [H] normalised row
     float* xch = reinterpret_cast<float*>(smem + (size_t)H * 2);           // [(nvec - 256) * 8]
