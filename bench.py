@@ -559,13 +559,12 @@ def measure_kernels(model, cfg, ops, B, ctx, world, iters, dev, only_experts=Fal
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense
 
 
-def measure_prefill_gemm(layer, cfg, ops, world, dev, T=16384, iters=10, warm=5):
+def measure_prefill_gemm(layer, cfg, ops, world, dev, T=16384, iters=10, warm=5, fp8=False):
     import torch
     H, E, k, I = cfg.hidden_size, cfg.n_routed_experts, cfg.num_experts_per_tok, cfg.moe_intermediate_size // world
     x = torch.randn(T, H, device=dev).to(torch.bfloat16)
     idx, w = layer.mlp.gate(x)
     offs, tok, scale, pos = ops.moe_align(idx, w, E, True)
-    w13, w2 = layer.mlp._stacked()
     R = T * k + T
     out = {}
 
@@ -584,10 +583,18 @@ def measure_prefill_gemm(layer, cfg, ops, world, dev, T=16384, iters=10, warm=5)
         torch.cuda.synchronize()
         return a.elapsed_time(b) / iters * 1e3
 
-    act = ops.grouped_gemm_gateup_silu(x, w13, offs, tok, R)
-    for name, fn, flops in (
-            ("grouped_gemm_gateup_silu@prefill16k", lambda: ops.grouped_gemm_gateup_silu(x, w13, offs, tok, R), 2.0 * R * 2 * I * H),
-            ("grouped_gemm_down@prefill16k", lambda: ops.grouped_gemm_down(act, w2, offs, scale, E), 2.0 * R * H * I)):
+    if fp8:  # the fp8 bytes are the tiled kernel's weight operand (no expansion pass)
+        w13_q, w13_s, w2_q, w2_s = layer.mlp._fp8
+        gu = lambda: ops.grouped_gemm_gateup_silu_fp8w(x, w13_q, w13_s, offs, tok, R)
+        act = gu()
+        dn = lambda: ops.grouped_gemm_down_fp8w(act, w2_q, w2_s, offs, scale, E)
+    else:
+        w13, w2 = layer.mlp._stacked()
+        gu = lambda: ops.grouped_gemm_gateup_silu(x, w13, offs, tok, R)
+        act = gu()
+        dn = lambda: ops.grouped_gemm_down(act, w2, offs, scale, E)
+    for name, fn, flops in (("grouped_gemm_gateup_silu@prefill16k", gu, 2.0 * R * 2 * I * H),
+                            ("grouped_gemm_down@prefill16k", dn, 2.0 * R * H * I)):
         us = timed(fn)
         tf = flops / (us * 1e-6) / 1e12
         out[name] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -709,7 +716,15 @@ def measure_fp8(model, cfg, ops, step, B, ctx, L, args, dev):
     # 117 / 144 / 158 us for the same gate|up launch on three boxes while the captured step around it was stable (r03)
     measure_kernels(model, cfg, ops, B, ctx, 1, max(4, args.kernel_iters // 4), dev, only_experts=True)
     ks = measure_kernels(model, cfg, ops, B, ctx, 1, args.kernel_iters, dev, only_experts=True)
+    moe_layer = next(l for l in model.model.layers if hasattr(l.mlp, "gate"))
+    pf = measure_prefill_gemm(moe_layer, cfg, ops, 1, dev, iters=6, warm=3, fp8=True)
     return {"workload": f"same model and decode step (bs={B} ctx={ctx} L={L}), experts as fp8 e4m3 weight-only",
+            "prefill16k_gateup_tflops": pf["grouped_gemm_gateup_silu@prefill16k"]["achieved"],
+            "prefill16k_down_tflops": pf["grouped_gemm_down@prefill16k"]["achieved"],
+            "prefill16k_pair_tflops": pf["grouped_gemm@prefill16k"]["achieved"],
+            "prefill16k_pair_us": pf["grouped_gemm@prefill16k"]["kernel_us_mean"],
+            "prefill16k_model": "grouped gate|up + down at T=16384 with the fp8 bytes as the tiled kernel's weight operand "
+                                "(bf16 MFMA, fp32 accumulate, per-row scale in the epilogue); no expansion pass, no scratch",
             "tokens_per_s": round(B / dt, 2), "ms_per_step": round(dt * 1e3, 4), "ms_per_layer": round(dt * 1e3 / L, 4),
             "steps": steps, "hip_graph": True,
             "gateup_hbm_frac": ks["grouped_gemm_gateup_silu"]["frac"], "gateup_us": ks["grouped_gemm_gateup_silu"]["kernel_us_mean"],

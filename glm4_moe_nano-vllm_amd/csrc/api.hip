@@ -20,10 +20,25 @@ namespace {
 // rows per group above which the MFMA-bound tiled kernel is used instead of weight streaming
 constexpr int64_t LARGEM_MIN_AVG_ROWS = 96;
 
-// Many rows per group with fp8 weights (prefill): the GEMM is MFMA-bound, weight bytes do not matter, so the stack is
-// expanded (exactly) to bf16 in caller-provided scratch by one streaming pass and the tiled bf16 kernel runs on the copy,
-// with the per-row dequantisation scale applied to its fp32 accumulators — the arithmetic of the streaming fp8 kernel.
+// Many rows per group with fp8 weights (prefill): the GEMM is MFMA-bound.  First choice: the tiled kernel takes the fp8
+// bytes as they are (DMA-staged as fp8, converted exactly to bf16 between the fragment read and the MFMA; per-row
+// dequantisation scale on the fp32 accumulators) — no expansion pass, no scratch.  What that kernel does not cover (a K
+// that is not a multiple of 64, offsets past 2^31) takes the r02 path when the caller brought scratch: the stack is
+// expanded (exactly) to bf16 by one streaming pass and the bf16 kernel runs on the copy, same accumulator scaling — the two
+// are bit-identical (test_fp8_weights_native_operand_equals_expansion).  GLM_ERR_UNSUPPORTED: neither applies.
+bool fp8w_native_enabled() {
+    const char* e = getenv("GLM4MOE_FP8W_NATIVE");  // 0: force the expansion path (A/B runs, the bit-identity test)
+    return !(e && e[0] == '0');
+}
+
 int fp8w_large(int mode, GemmParams p, int rows, int cols, void* scratch, size_t scratch_bytes, hipStream_t st) {
+    if (fp8w_native_enabled()) {
+        GemmParams q = p;
+        q.w_fp8 = 1;
+        const int rc = glm_launch_gemm_largem(mode, q, st);
+        if (rc != GLM_ERR_UNSUPPORTED) return rc;
+    }
+    if (scratch == nullptr) return GLM_ERR_UNSUPPORTED;
     const int64_t pitch = glm_expand_pitch(cols);
     const size_t need = (size_t)p.G * rows * pitch * sizeof(bf16_t);
     GLM_CHECK_ARG(scratch_bytes >= need && glm_aligned16(scratch), GLM_ERR_WORKSPACE,
@@ -281,8 +296,10 @@ extern "C" int glm_grouped_gemm_gateup_silu_fp8w(const void* x, int64_t ldx, con
     p.offs = expert_offsets; p.src = sorted_token;
     p.y = (bf16_t*)act; p.ldy = I;
     p.R = R; p.N = I; p.K = H; p.G = G;
-    if (R / G >= LARGEM_MIN_AVG_ROWS && expand_scratch != nullptr)
-        return fp8w_large(GEMM_GATEUP, p, 2 * I, H, expand_scratch, expand_scratch_bytes, glm_s(stream));
+    if (R / G >= LARGEM_MIN_AVG_ROWS) {
+        const int rc = fp8w_large(GEMM_GATEUP, p, 2 * I, H, expand_scratch, expand_scratch_bytes, glm_s(stream));
+        if (rc != GLM_ERR_UNSUPPORTED) return rc;
+    }
     return glm_launch_gemm_smallm_fp8w(GEMM_GATEUP, p, glm_s(stream));
 }
 
@@ -307,11 +324,15 @@ extern "C" int glm_grouped_gemm_down_fp8w(const void* act, const void* w2_q, int
     p.scale = (const bf16_t*)sorted_scale; p.n_scaled = n_scaled_groups;
     p.y = (bf16_t*)y; p.ldy = ldy;
     p.R = R; p.N = H; p.K = I; p.G = G;
-    if (R / G >= LARGEM_MIN_AVG_ROWS && expand_scratch != nullptr)
-        return fp8w_large(GEMM_DOWN, p, H, I, expand_scratch, expand_scratch_bytes, glm_s(stream));
+    if (R / G >= LARGEM_MIN_AVG_ROWS) {
+        const int rc = fp8w_large(GEMM_DOWN, p, H, I, expand_scratch, expand_scratch_bytes, glm_s(stream));
+        if (rc != GLM_ERR_UNSUPPORTED) return rc;
+    }
     return glm_launch_gemm_smallm_fp8w(GEMM_DOWN, p, glm_s(stream));
 }
 
 extern "C" size_t glm_fp8w_expand_scratch_bytes(int G, int rows, int cols) {
+    // 0: the tiled kernel takes this stack's fp8 bytes directly (K a multiple of its 64-wide K tile)
+    if (fp8w_native_enabled() && cols % 64 == 0) return 0;
     return (size_t)G * rows * glm_expand_pitch(cols) * sizeof(bf16_t);
 }

@@ -16,6 +16,7 @@ struct GemmParams {
     int64_t ldw;
     const float* wscale;  // fp8 weights only: per-row dequantisation scale, group g at + g*wscale_gstride
     int64_t wscale_gstride;
+    int w_fp8;            // gemm_largem only: w points at OCP fp8 e4m3 BYTES (strides in bytes), converted on the fragment read
     const int32_t* offs;  // [G+1] row offsets per group, or nullptr (one group of R rows)
     const int32_t* src;   // source row of sorted row r, or nullptr (identity)
     const bf16_t* scale;  // [R] per-row scale (GEMM_DOWN) or nullptr

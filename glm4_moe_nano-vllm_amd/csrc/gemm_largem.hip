@@ -55,19 +55,28 @@ int g_largem_band = GLM_LM_BAND;  // row blocks per L2 supertile band (glm_debug
 // Tile configurations (the kernel is written once over these):
 //   CfgA 256(n) x 128(m) x 64(k), 3-stage ring, wave tile 64x64  (16 LDS reads + 6 DMA per 32 MFMA)
 //   CfgB 256(n) x 256(m) x 32(k), 4-stage ring, wave tile 64x128 (12 LDS reads + 4 DMA per 32 MFMA)
-template <int BM_, int BK_, int NSTAGE_, bool PH8_ = false>
+template <int BM_, int BK_, int NSTAGE_, bool PH8_ = false, bool W8_ = false>
 struct LmCfg {
     static constexpr int BM = BM_, BK = BK_, NSTAGE = NSTAGE_;
     static constexpr bool PH8 = PH8_;              // quadrant-phase main loop (CfgC)
-    static constexpr int RB = BK * 2;              // bytes per tile row
+    // W8: the weight operand is OCP fp8 e4m3 in memory AND in LDS (half the DMA instructions, half the LDS bytes and
+    // fragment-read bytes of the weight tile); a fragment is converted to bf16 (exactly: every e4m3 value is a bf16
+    // value) between its ds_read and the MFMA, and the per-row dequantisation scale multiplies the fp32 accumulator in the
+    // epilogue (WSCALE) — the arithmetic of the expansion pass + bf16 kernel it replaces, bit for bit.
+    static constexpr bool W8 = W8_;
+    static constexpr int RB = BK * 2;              // bytes per ACTIVATION tile row (and per weight tile row unless W8)
     static constexpr int CPR = RB / 16;            // 16-B chunks per row
     static constexpr int RPI = 1024 / RB;          // rows per DMA instruction
-    static constexpr int W_DMA = LM_BN / RPI / 8;  // weight DMA instructions per wave per tile
+    static constexpr int WRB = W8 ? BK : RB;       // bytes per WEIGHT tile row
+    static constexpr int WCPR = WRB / 16;
+    static constexpr int WRPI = 1024 / WRB;
+    static_assert(!W8 || WRB == 64, "fp8 weight tiles: 64-byte rows (BK = 64)");
+    static constexpr int W_DMA = LM_BN / WRPI / 8; // weight DMA instructions per wave per tile
     static constexpr int X_DMA = BM / RPI / 8;     // activation DMA instructions per wave per tile
     static constexpr int DPW = W_DMA + X_DMA;
     static constexpr int KS = BK / 32;             // MFMA k-steps per tile
     static constexpr int MT = BM / 2 / 16;         // 16-token MFMA tiles per wave (2 waves along m)
-    static constexpr int WT = LM_BN * RB;          // weight tile bytes
+    static constexpr int WT = LM_BN * WRB;         // weight tile bytes
     static constexpr int XT = BM * RB;
     static constexpr int STAGE = WT + XT;
     // the 16 bytes of the tile search normally follow the ring; a ring that takes the CU's whole LDS (5 x 32 KiB) lends
@@ -78,6 +87,10 @@ struct LmCfg {
     static constexpr int NF = KS * (4 + MT);       // fragment registers (u32x4) per tile
     // source-chunk permutation that makes the 16-row ds_read_b128 fragment reads conflict free
     __device__ static constexpr int swz(int row) { return RB == 128 ? ((row >> 1) & 7) : ((row >> 1) & 2); }
+    // fp8 weight rows are 64 B and a fragment read is a ds_read_b64 at row*64 + 16*slot + 8*(g4 & 1): the 32 lanes of a
+    // half wave are rows c = 0..15 x two 8-byte halves; rows c, c+4, c+8, c+12 share their banks unless their slots
+    // differ, so slot = chunk ^ ((row >> 2) & 3) — each half wave then covers all 64 banks exactly once
+    __device__ static constexpr int wswz(int row) { return W8 ? ((row >> 2) & 3) : swz(row); }
 };
 using LmCfgA = LmCfg<128, 64, 3>;
 using LmCfgB = LmCfg<256, 32, 4>;
@@ -88,6 +101,8 @@ using LmCfgB5 = LmCfg<256, 32, 5>;  // variant LM_DEEP: prefetch distance 4
 //        when the whole K tile is done: the weight fragments of a K tile are read in phases 0-1, the activation
 //        fragments in phases 0 and 2 (see the main loop).
 using LmCfgC = LmCfg<256, 64, 2, true>;
+using LmCfgC8 = LmCfg<256, 64, 2, true, true>;  // fp8 weight operand (two 48-KiB buffers)
+using LmCfgA8 = LmCfg<128, 64, 3, false, true>;
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
@@ -127,6 +142,20 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 template <int OFF>
 __device__ __forceinline__ void lds_read_b128_o(u32x4_t& dst, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_b64_o(u32x2_t& dst, unsigned addr) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+// 8 fp8 e4m3 (k ascending from byte 0) -> the bf16x8 MFMA fragment, exact
+__device__ __forceinline__ u32x4_t lm_fp8x8_to_bf16x8(const u32x2_t d) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+    const bf2_t a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d[0], 1.0f, false);
+    const bf2_t b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d[0], 1.0f, true);
+    const bf2_t c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d[1], 1.0f, false);
+    const bf2_t e = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(d[1], 1.0f, true);
+    return u32x4_t{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c),
+                   __builtin_bit_cast(unsigned, e)};
 }
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -340,15 +369,17 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         if (LEAN) {
             // descriptor of the group's weights (wave-uniform; grp came through LDS, so make that provable)
             const int64_t goff = (int64_t)__builtin_amdgcn_readfirstlane(grp) * p.w_gstride;
-            wrs = make_rsrc(p.w + goff);
+            if constexpr (C::W8) wrs = make_rsrc(reinterpret_cast<const char*>(p.w) + goff);  // fp8: strides in bytes
+            else wrs = make_rsrc(p.w + goff);
 #pragma unroll
             for (int i = 0; i < C::W_DMA; ++i) {
-                const int row = (wid * C::W_DMA + i) * C::RPI + lane / C::CPR;
-                const int ch = (lane % C::CPR) ^ C::swz(row);
+                const int row = (wid * C::W_DMA + i) * C::WRPI + lane / C::WCPR;
+                const int ch = (lane % C::WCPR) ^ C::wswz(row);
                 int wr;
                 if (MODE == GEMM_GATEUP) wr = (row >> 7) * p.N + min(ntile * 128 + (row & 127), p.N - 1);
                 else wr = min(ntile * LM_BN + row, p.N - 1);
-                wvo[i] = (unsigned)(wr * (int)p.ldw + ch * 8) * 2u;
+                if constexpr (C::W8) wvo[i] = (unsigned)(wr * (int)p.ldw + ch * 16);
+                else wvo[i] = (unsigned)(wr * (int)p.ldw + ch * 8) * 2u;
             }
 #pragma unroll
             for (int i = 0; i < C::X_DMA; ++i) {
@@ -391,7 +422,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         constexpr int j = decltype(jc)::value;
         const int k0 = kt * C::BK;
         if constexpr (j < C::W_DMA)
-            blds16(wrs, smem + slot * C::STAGE + wid * C::W_DMA * 1024 + j * 1024, wvo[j], k0 * 2);
+            blds16(wrs, smem + slot * C::STAGE + wid * C::W_DMA * 1024 + j * 1024, wvo[j], k0 * (C::W8 ? 1 : 2));
         else
             blds16(xrs, smem + slot * C::STAGE + C::WT + wid * C::X_DMA * 1024 + (j - C::W_DMA) * 1024,
                    xvo[j - C::W_DMA], k0 * 2);
@@ -403,7 +434,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         if (LEAN) {
 #pragma unroll
             for (int i = 0; i < C::W_DMA; ++i)
-                blds16(wrs, wdst + i * 1024, wvo[i], k0 * 2);
+                blds16(wrs, wdst + i * 1024, wvo[i], k0 * (C::W8 ? 1 : 2));
 #pragma unroll
             for (int i = 0; i < C::X_DMA; ++i)
                 blds16(xrs, xdst + i * 1024, xvo[i], k0 * 2);
@@ -441,7 +472,10 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             int wrow;
             if (MODE == GEMM_GATEUP) wrow = (t < 2 ? wn * 32 + 16 * t : 128 + wn * 32 + 16 * (t - 2)) + c;
             else wrow = wn * 64 + 16 * t + c;
-            rel[ks * (4 + C::MT) + t] = wrow * C::RB + (((4 * ks + g4) ^ C::swz(wrow)) << 4);
+            if constexpr (C::W8)  // 8 bytes: k = 32 ks + 8 g4 .. +8 = chunk 2 ks + (g4 >> 1), half g4 & 1
+                rel[ks * (4 + C::MT) + t] = wrow * C::WRB + (((2 * ks + (g4 >> 1)) ^ C::wswz(wrow)) << 4) + ((g4 & 1) << 3);
+            else
+                rel[ks * (4 + C::MT) + t] = wrow * C::RB + (((4 * ks + g4) ^ C::swz(wrow)) << 4);
         }
 #pragma unroll
         for (int t = 0; t < C::MT; ++t) {
@@ -459,7 +493,20 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         fbx[ks] = base + rel[ks * (4 + C::MT) + 4];
     }
     // all fragment reads of a K tile (slot byte offset so, wave-uniform)
-    auto read_frags = [&](u32x4_t (&f)[C::NF], unsigned so, auto half_tag) {
+    // W8: behind the read wait, the weight fragments fp8 -> bf16 (the asm reads are invisible to the compiler: nothing may
+    // touch fr[] between a read and the lgkmcnt wait, which is why they have registers of their own)
+    auto frags_cvt = [&](u32x4_t (&f)[C::NF], u32x2_t (&fr)[C::W8 ? C::KS * 4 : 1]) {
+        if constexpr (C::W8) {
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    asm volatile("" : "+v"(fr[ks * 4 + t]));
+                    f[ks * (4 + C::MT) + t] = lm_fp8x8_to_bf16x8(fr[ks * 4 + t]);
+                }
+        }
+    };
+    auto read_frags = [&](u32x4_t (&f)[C::NF], u32x2_t (&fr)[C::W8 ? C::KS * 4 : 1], unsigned so, auto half_tag) {
         constexpr int HALF = decltype(half_tag)::value;  // 0: all, 1: first half, 2: second half (index order as rel[])
         static_for<C::KS>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value;
@@ -467,8 +514,11 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             static_for<4>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 constexpr int idx = ks * (4 + C::MT) + t;
-                constexpr int off = MODE == GEMM_GATEUP ? (t < 2 ? 16 * t : 128 + 16 * (t - 2)) * C::RB : 16 * t * C::RB;
-                if (HALF == 0 || (HALF == 1) == (idx < C::NF / 2)) lds_read_b128_o<off>(f[idx], aw);
+                constexpr int off = MODE == GEMM_GATEUP ? (t < 2 ? 16 * t : 128 + 16 * (t - 2)) * C::WRB : 16 * t * C::WRB;
+                if (HALF == 0 || (HALF == 1) == (idx < C::NF / 2)) {
+                    if constexpr (C::W8) lds_read_b64_o<off>(fr[ks * 4 + t], aw);  // fp8 as read; frags_cvt() fills f[idx]
+                    else lds_read_b128_o<off>(f[idx], aw);
+                }
             });
             static_for<C::MT>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
@@ -567,6 +617,16 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         static_assert(!(P3X && QW), "LM_P3X refills the X slot while LM_QW still reads it");
         if (wid >= 4) __builtin_amdgcn_s_barrier();   // the stagger
         u32x4_t fw[8], fx[8];  // [k-step][W tile 0-3], [k-step][X tile of the current part]
+        u32x2_t fwr[C::W8 ? 8 : 1];  // W8: the fragments as read (fp8), converted into fw behind the read wait
+        auto cvt_w = [&]() {
+            if constexpr (C::W8) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    asm volatile("" : "+v"(fwr[i]));
+                    fw[i] = lm_fp8x8_to_bf16x8(fwr[i]);
+                }
+            }
+        };
         auto pin = [&](u32x4_t& r) { asm volatile("" : "+v"(r)); };
         // W tiles t0 .. t0+NT-1, both k-steps
         auto rd_w = [&](unsigned so, auto t0c, auto ntc) {
@@ -576,8 +636,9 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                 const unsigned aw = fbw[ks] + so;
                 static_for<NT>([&](auto tc) {
                     constexpr int t = t0 + decltype(tc)::value;
-                    constexpr int off = MODE == GEMM_GATEUP ? (t < 2 ? 16 * t : 128 + 16 * (t - 2)) * C::RB : 16 * t * C::RB;
-                    lds_read_b128_o<off>(fw[ks * 4 + t], aw);
+                    constexpr int off = MODE == GEMM_GATEUP ? (t < 2 ? 16 * t : 128 + 16 * (t - 2)) * C::WRB : 16 * t * C::WRB;
+                    if constexpr (C::W8) lds_read_b64_o<off>(fwr[ks * 4 + t], aw);
+                    else lds_read_b128_o<off>(fw[ks * 4 + t], aw);
                 });
             });
         };
@@ -637,6 +698,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         //           (vmcnt leaves the 6 younger pieces X(kt+1) 0-3, W(kt+2) 0,1 in flight), i.e. before barrier 8kt+6
         //           at the latest, and first read in load interval 4kt+3 (epoch >= 8kt+6).
         static_assert(!P3X && !QW, "LM_MIR is its own schedule");
+        static_assert(!C::W8, "fp8 weight operand: product loop only");
         static_assert(!PARK, "LM_PARK is wired into the plain quadrant loop only");
         auto ktile = [&](int kt, auto parc) {
             constexpr int PAR = decltype(parc)::value;
@@ -711,6 +773,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         //           (retired by the lgkmcnt(0) before its closing barrier, epoch <= 8kt+6) and refilled from load
         //           interval 4kt+4 (epoch >= 8kt+8); W(kt) is last read in load interval 4kt as under LM_QW.
         static_assert(QW, "LM_RPRE is a schedule of the LM_QW quadrants");
+        static_assert(!C::W8, "fp8 weight operand: product loop only");
         static_assert(!PARK, "LM_PARK is wired into the plain quadrant loop only");
         auto pre_x = [&](unsigned so, auto m0c, auto xbc) {  // issue the reads, keep the MFMAs behind them
             rd_x(so, m0c, I2{}, xbc);
@@ -769,6 +832,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         //   LM_RFIRST  the fragment reads of a load interval are issued BEFORE its DMA instructions: the ~70-cycle DMA
         //           issues then run under the LDS round trip of the reads instead of in front of it.
         constexpr bool RF = (VAR & LM_RFIRST) != 0;
+        static_assert(!C::W8 || (QW && !P3X && !PARK), "fp8 weight operand: wired into the product quadrant loop");
 #if GLM_LM_STAMP
         unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
 #endif
@@ -793,6 +857,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             reads_done();
             LM_T(2);  // 1: phase 0 LDS wait
             if constexpr (QW) {
+                cvt_w();
 #pragma unroll
                 for (int i = 0; i < 8; ++i) pin(fw[i]);
 #pragma unroll
@@ -842,7 +907,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             // ---- phase 3: the last pieces, then this wave's share of K tile kt+1 must have landed
             auto dma3 = [&]() {
                 if (has2) {
-                    dma2(b, kt + 2, I2{});
+                    if constexpr (C::W_DMA > 2) dma2(b, kt + 2, I2{});  // (an fp8 weight tile is two pieces: both went in phase 2)
                     if constexpr (P3X) dma2(b, kt + 2, XP0{});
                 }
             };
@@ -886,6 +951,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             // ---------------- phase 1 ----------------
             const unsigned sb = base + slot * C::STAGE;
             u32x4_t f[C::NF];
+            u32x2_t fr[C::W8 ? C::KS * 4 : 1];
             const int nslot = slot == 0 ? C::NSTAGE - 1 : slot - 1;  // slot of tile kt-1
             LM_T(0);
             if constexpr ((VAR & LM_LOADPRIO) != 0) __builtin_amdgcn_s_setprio(1);
@@ -897,7 +963,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             }
             LM_T(1);  // 0: DMA issue
             if (LEAN) {
-                read_frags(f, slot * C::STAGE, std::integral_constant<int, 0>{});
+                read_frags(f, fr, slot * C::STAGE, std::integral_constant<int, 0>{});
             } else {
 #pragma unroll
                 for (int i = 0; i < C::NF / 2; ++i) lds_read_b128(f[i], sb + rel[i]);
@@ -921,6 +987,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             }
             LM_T(3);  // 2: counted DMA wait
             lds_wait(f);
+            frags_cvt(f, fr);
             LM_T(4);  // 3: LDS wait
             __builtin_amdgcn_sched_barrier(0);
             if constexpr ((VAR & LM_LOADPRIO) != 0) __builtin_amdgcn_s_setprio(0);
@@ -990,16 +1057,18 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         for (int kt = 0; kt < nk; ++kt) {
             const unsigned sb = base + slot * C::STAGE;
             u32x4_t f[C::NF];
+            u32x2_t fr[C::W8 ? C::KS * 4 : 1];
             const int nslot = slot == 0 ? C::NSTAGE - 1 : slot - 1;  // slot of tile kt-1
             if (kt + C::DIST < nk) stage(nslot, kt + C::DIST);
             if (LEAN) {
-                read_frags(f, slot * C::STAGE, std::integral_constant<int, 0>{});
+                read_frags(f, fr, slot * C::STAGE, std::integral_constant<int, 0>{});
             } else {
 #pragma unroll
                 for (int i = 0; i < C::NF; ++i) lds_read_b128(f[i], sb + rel[i]);
             }
             dma_wait_leave<C::DPW>(min(kt + C::DIST, nk - 1) - (kt + 1));
             lds_wait(f);
+            frags_cvt(f, fr);
             __builtin_amdgcn_sched_barrier(0);
             if (lead) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_setprio(1);
@@ -1188,7 +1257,7 @@ int launch_largem_cfg(const GemmParams& p, hipStream_t st) {
     GLM_CHECK_ARG(total < (1ll << 31), GLM_ERR_UNSUPPORTED, "gemm_largem: grid too large");
     // the per-row scale of fp8-expanded weights is its own instantiation: as a run-time test it sat inside the epilogue's
     // element loop (a branch per accumulator register)
-    auto kern = p.wscale ? gemm_largem_kernel<MODE, C, VAR, true> : gemm_largem_kernel<MODE, C, VAR, false>;
+    auto kern = (C::W8 || p.wscale) ? gemm_largem_kernel<MODE, C, VAR, true> : gemm_largem_kernel<MODE, C, VAR, !C::W8 ? false : true>;
     constexpr int LDS_BYTES = (C::PH8 && (VAR & LM_PARK) != 0) ? 160 * 1024 : C::LDS;
     GLM_SET_MAX_LDS(kern, LDS_BYTES, "gemm_largem");
     // one workgroup per CU (the ring takes most of the LDS), a multiple of 8 so that every XCD gets the same count
@@ -1239,6 +1308,22 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
     const int64_t wrows = MODE == GEMM_GATEUP ? 2 * (int64_t)p.N : (int64_t)p.N;
     const bool lean_ok = p.K % bk == 0 && p.R * p.ldx * 2 < (1ll << 31) && wrows * p.ldw * 2 < (1ll << 31) &&
                          p.N % 8 == 0 && p.ldy % 8 == 0 && glm_aligned16(p.y);
+    if (p.w_fp8) {
+        // fp8 weight operand: the product loops only (quadrant loop on 256-row blocks, its plain form on 128-row blocks);
+        // what they do not cover (a K tail, offsets past 2^31) goes back to the caller, which expands the stack instead
+        constexpr int V8 = LM_LEAN | LM_WIDEST | LM_PH8 | LM_QW | LM_RFIRST | LM_NOPRIO | LM_EPIORD;
+        if (!lean_ok || p.K % 64 != 0 || p.wscale == nullptr || p.ldw % 16 != 0 || p.w_gstride % 16 != 0) {
+            glm_set_error("gemm_largem(fp8 weights): shape not covered (K=%d N=%d ldw=%ld)", p.K, p.N, (long)p.ldw);
+            return GLM_ERR_UNSUPPORTED;
+        }
+        if constexpr (MODE == GEMM_PLAIN) {
+            glm_set_error("gemm_largem(fp8 weights): only the grouped expert projections are quantised");
+            return GLM_ERR_UNSUPPORTED;
+        } else {
+            if (use_b) return launch_largem_cfg<MODE, LmCfgC8, V8>(p, st);
+            return launch_largem_cfg<MODE, LmCfgA8, V8 & ~LM_PH8>(p, st);
+        }
+    }
     if (!lean_ok) var = 0;
 #define GLM_LM_CASE(V)                                                                                         \
     case V:                                                                                                    \

@@ -631,11 +631,14 @@ _fp8_scratch: dict = {}
 
 
 def _fp8_expand_scratch(device, G: int, rows: int, cols: int, R: int):
-    """Scratch for the prefill-regime fp8 expert GEMM (bf16 copy of ONE weight stack, reused by every layer and both
-    projections); None at decode row counts, where the streaming fp8 kernel runs."""
+    """Scratch for the prefill-regime fp8 expert GEMM where the tiled kernel cannot take the fp8 bytes directly (K not a
+    multiple of 64): bf16 copy of ONE weight stack, reused by every layer and both projections.  None at decode row counts
+    (streaming fp8 kernel) and for the shapes the fp8-operand kernel covers."""
     if R // max(G, 1) < _FP8_LARGE_MIN_AVG_ROWS:
         return None, 0
     need = load_library().glm_fp8w_expand_scratch_bytes(G, rows, cols)
+    if need == 0:  # the tiled kernel takes the fp8 bytes themselves
+        return None, 0
     buf = _fp8_scratch.get(device)
     if buf is None or buf.numel() < need:
         buf = torch.empty(need, dtype=torch.uint8, device=device)

@@ -210,9 +210,12 @@ int glm_gemm_bf16_router_tail(const void* x, const void* w, int64_t ldw, int K, 
  *     w13_q: [G, 2I, H] uint8 with element strides (group, row, 1); w13_scale: f32 [G, 2I]
  *     (row stride 1, group stride w13_scale_group_stride); likewise w2_q [G, H, I], w2_scale [G, H].
  *     Few rows per group (decode): the weights are streamed as fp8 (HBM-bound, half the bytes).  Many rows per group
- *     (prefill, MFMA-bound) and expand_scratch != NULL (glm_fp8w_expand_scratch_bytes(G, weight rows, K) bytes,
- *     16-byte aligned, contents scratch): the stack is expanded exactly to bf16 by one streaming pass and the tiled
- *     bf16 MFMA kernel runs on the copy with the same accumulator scaling; with NULL the streaming kernel is used.  */
+ *     (prefill, MFMA-bound): the tiled MFMA kernel stages the fp8 bytes themselves (LDS-DMA, half the weight tile's LDS
+ *     bytes) and converts a fragment to bf16 between its LDS read and the MFMA — no extra pass, no scratch.  Only a K that
+ *     is not a multiple of 64 needs expand_scratch (glm_fp8w_expand_scratch_bytes(G, weight rows, K) bytes — 0 when the
+ *     stack is covered — 16-byte aligned, contents scratch): the stack is then expanded exactly to bf16 by one streaming
+ *     pass and the bf16 kernel runs on the copy; both forms are bit-identical.  With NULL where scratch would be needed the
+ *     streaming kernel is used.                                                                                       */
 size_t glm_fp8w_expand_scratch_bytes(int G, int rows, int cols);
 int glm_grouped_gemm_gateup_silu_fp8w(const void* x, int64_t ldx, const void* w13_q,
                                       int64_t w13_group_stride, int64_t w13_row_stride,

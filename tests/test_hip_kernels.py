@@ -1011,6 +1011,34 @@ def test_moe_block_fp8_weights(ops, T, E, k, H, I):
     assert rel < 0.08, f"fp8 quantisation error {rel:.3f}"
 
 
+@pytest.mark.parametrize("T,E,k,H,I", [(600, 4, 2, 256, 128),     # 256-row blocks: the quadrant loop with the fp8 operand
+                                       (300, 8, 2, 512, 192),     # ~100 rows per group: 128-row blocks, plain loop
+                                       (2100, 6, 3, 1024, 1408),  # Air's I (22 K tiles of the down projection), ragged groups
+                                       (700, 5, 1, 4096, 64)])    # one expert never chosen (an empty group)
+def test_fp8_weights_native_operand_equals_expansion(ops, T, E, k, H, I, monkeypatch):
+    """Many rows per group: the tiled kernel fed with the fp8 bytes (DMA-staged as fp8, converted between the fragment read
+    and the MFMA) == the exact fp8 -> bf16 expansion pass followed by the bf16 kernel, bit for bit, both projections."""
+    x = rnd(T, H, seed=121)
+    w13, w2 = rnd(E + 1, 2 * I, H, seed=122, scale=H ** -0.5), rnd(E + 1, H, I, seed=123, scale=I ** -0.5)
+    g = torch.Generator().manual_seed(124)
+    pool = E - 1 if E == 5 else E
+    idx = torch.stack([torch.randperm(pool, generator=g)[:k].sort()[0] for _ in range(T)]).to(torch.int64)
+    w = (torch.rand(T, k, generator=g) + 0.1).to(BF)
+    q13, s13 = ops.quantize_fp8_rowwise(dev(w13))
+    q2, s2 = ops.quantize_fp8_rowwise(dev(w2))
+    offs, tok, scale, pos = ops.moe_align(dev(idx), dev(w), E, True)
+    R = T * k + T
+    monkeypatch.setenv("GLM4MOE_FP8W_NATIVE", "0")
+    a0 = ops.grouped_gemm_gateup_silu_fp8w(dev(x), q13, s13, offs, tok, R)
+    y0 = ops.grouped_gemm_down_fp8w(a0, q2, s2, offs, scale, E)
+    monkeypatch.setenv("GLM4MOE_FP8W_NATIVE", "1")
+    a1 = ops.grouped_gemm_gateup_silu_fp8w(dev(x), q13, s13, offs, tok, R)
+    y1 = ops.grouped_gemm_down_fp8w(a0, q2, s2, offs, scale, E)
+    assert torch.equal(a0, a1), "gate|up: native fp8 operand differs from the expansion path"
+    assert torch.equal(y0, y1), "down: native fp8 operand differs from the expansion path"
+    assert float(a1.float().abs().max()) > 0
+
+
 # ------------------------------------------------------------------------------------------
 # N3: expert-parallel dispatch / combine pieces
 def test_row_gather_scatter(ops):
