@@ -55,6 +55,19 @@ def test_host_only_entry_points(lib_path):
     assert rc == -1 and b"bad shape" in lib.glm_last_error()
 
 
+def test_fp8_expansion_scratch_only_where_the_tiled_kernel_cannot_take_fp8(lib_path, monkeypatch):
+    """At prefill row counts the tiled kernel takes the fp8 bytes as its weight operand when K is a multiple of its 64-wide K
+    tile: no scratch is asked for (Air dims: K = 4096 and 1408); other K, or GLM4MOE_FP8W_NATIVE=0, still size the bf16 copy."""
+    from nanovllm import hip_ops
+    lib = hip_ops.load_library(lib_path)
+    monkeypatch.delenv("GLM4MOE_FP8W_NATIVE", raising=False)
+    assert lib.glm_fp8w_expand_scratch_bytes(65, 2816, 4096) == 0
+    assert lib.glm_fp8w_expand_scratch_bytes(65, 4096, 1408) == 0
+    assert lib.glm_fp8w_expand_scratch_bytes(3, 512, 352) >= 3 * 512 * 352 * 2
+    monkeypatch.setenv("GLM4MOE_FP8W_NATIVE", "0")
+    assert lib.glm_fp8w_expand_scratch_bytes(65, 2816, 4096) >= 65 * 2816 * 4096 * 2
+
+
 def test_no_cpu_fallback():
     from nanovllm import hip_ops
     x = torch.randn(2, 64).to(torch.bfloat16)
