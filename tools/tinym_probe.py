@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "glm4_moe_nano-vllm_amd"))
 from nanovllm import hip_ops as ops
 ops.load_library()
-H, nh, nkv, hd, E, k, I, L = 4096, 96, 8, 128, 64, 8, 1408, 6
+H, nh, nkv, hd, E, k, I, L = 4096, 96, 8, 128, 64, 8, 1408, int(os.environ.get("PROBE_L", "6"))
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(1)
 mk = lambda *s: ops.padded_weight(s[-2], s[-1], *s[:-2], dtype=torch.bfloat16, device=dev).normal_(0.0, 0.02, generator=g)
