@@ -44,6 +44,23 @@ __device__ __forceinline__ u32x4_t tm_wload(const void* p) {
 
 __device__ const u32x4_t g_tm_zero_page[4] = {};
 
+// GLM_TM_STAMP=1 (timing study only): per workgroup the 100 MHz real-time counter at kernel entry, when its first weight unit has
+// landed (first FMA), and at its end — where do the ~4.5 us of a launch that move no bytes go (dispatch skew, first byte, tail)?
+#ifndef GLM_TM_STAMP
+#define GLM_TM_STAMP 0
+#endif
+#ifndef GLM_TM_RPW_PLAIN
+#define GLM_TM_RPW_PLAIN 2   // weight rows per tile of the dense one-token projections (r03 sweep, QKV / o_proj at Air dims:
+                             // 4 rows x 4 KiB units 23.3 / 20.4 us, 2 x 4 KiB 22.4 / 19.5, 2 x 8 KiB 23.2 / 19.4, 1 x 8 KiB 24.5 / 20.4;
+                             // with 4 rows o_proj is 4 tiles per workgroup, i.e. 4 of its 8 waves stream)
+#endif
+#ifndef GLM_TM_SEGS_PLAIN
+#define GLM_TM_SEGS_PLAIN 4  // KiB of a weight row per unit
+#endif
+#if GLM_TM_STAMP
+__device__ unsigned long long g_tm_stamps[512][3];
+#endif
+
 struct TinyParams {
     GemmParams g;
     int n_tokens;             // grouped gate|up: rows of x (= tokens) kept in LDS
@@ -262,9 +279,9 @@ __device__ __forceinline__ void tinym_router_tail(const TinyParams& tp, char* sm
 // MODE as gemm_smallm; M = token rows per group block (1 or 2); SEGS = 1-KiB segments of a weight row per unit
 template <int MODE, int M, int SEGS, bool PRO, bool TAIL = false, int RPW = TM_RPW>
 __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) {
-    static_assert(RPW == 2 || RPW == 4, "2 or 4 weight rows per tile");
-    static_assert(!TAIL || RPW == 4, "the router tail hands 8-byte pieces over");
-    constexpr int HALF = RPW / 2;  // gate|up: HALF gate rows + the matching HALF up rows
+    static_assert(RPW == 1 || RPW == 2 || RPW == 4, "1, 2 or 4 weight rows per tile");
+    static_assert(MODE != GEMM_GATEUP || RPW >= 2, "gate|up: a tile is gate rows + the matching up rows");
+    constexpr int HALF = RPW >= 2 ? RPW / 2 : 1;  // gate|up: HALF gate rows + the matching HALF up rows
     const GemmParams& p = tp.g;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int sh_grp[TM_MAXG];   // non-empty groups
@@ -298,8 +315,15 @@ __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) 
         nact = sh_nact;
     }
     const int64_t total = (int64_t)nact * tpg;
+    // tiles of this workgroup: a contiguous run, positions q = 0 .. cnt-1 (every gridDim-th tile instead measured the same: r03)
     const int tb = (int)(total * blockIdx.x / gridDim.x), te = (int)(total * (blockIdx.x + 1) / gridDim.x);
-    if (tid == 0) sh_next = tb + TM_NW;  // waves start with tiles tb + wid
+    const int cnt = te - tb;
+    auto tile_of = [&](int q) -> int { return tb + q; };
+    if (tid == 0) sh_next = TM_NW;  // waves start with positions wid
+#if GLM_TM_STAMP
+    if (tid == 0 && blockIdx.x < 512) g_tm_stamps[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+    bool stamped_first = false;
+#endif
 
     // ---- per-tile set-up ----
     struct Tile {
@@ -338,10 +362,10 @@ __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) 
 
     // issue state runs one unit ahead of the compute state
     Tile it, ct;
-    int i_tile = tb + wid, i_u = 0;
-    bool i_live = i_tile < te;
+    int i_tile = wid, i_u = 0;
+    bool i_live = i_tile < cnt;
     if (i_live) {
-        set_tile(it, i_tile);
+        set_tile(it, tile_of(i_tile));
         issue(std::integral_constant<int, 0>{}, it, 0);
     }
     if constexpr (TAIL) {  // a designated workgroup's gate rows -> LDS, behind its first weight loads
@@ -356,8 +380,8 @@ __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) 
             int nt = 0;
             if (lane == 0) nt = __hip_atomic_fetch_add(&sh_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             i_tile = __builtin_amdgcn_readfirstlane(nt);
-            i_live = i_tile < te;
-            if (i_live) set_tile(it, i_tile);
+            i_live = i_tile < cnt;
+            if (i_live) set_tile(it, tile_of(i_tile));
         }
     };
 
@@ -460,8 +484,15 @@ __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) 
                         st_sc1_u64(p.y + row * p.ldy + t.ncol, (unsigned long long)o2[0] | ((unsigned long long)o2[1] << 32));
                     else
                         *reinterpret_cast<u32x2_t*>(p.y + row * p.ldy + t.ncol) = o2;
+                } else if constexpr (RPW == 2) {
+                    if (TAIL) st_sc1_u32(p.y + row * p.ldy + t.ncol, pack2bf(v[0], v[1]));
+                    else *reinterpret_cast<unsigned*>(p.y + row * p.ldy + t.ncol) = pack2bf(v[0], v[1]);
                 } else {
-                    *reinterpret_cast<unsigned*>(p.y + row * p.ldy + t.ncol) = pack2bf(v[0], v[1]);
+                    if (TAIL)
+                        __hip_atomic_store(reinterpret_cast<unsigned short*>(p.y + row * p.ldy + t.ncol), f2bf(v[0]), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        p.y[row * p.ldy + t.ncol] = f2bf(v[0]);
                 }
             }
         }
@@ -478,6 +509,13 @@ __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) 
         advance_issue();
         if (i_live) issue(std::integral_constant<int, 1>{}, it, i_u);
         compute(std::integral_constant<int, 0>{}, ct, c_u, xr);
+#if GLM_TM_STAMP
+        if (!stamped_first) {
+            stamped_first = true;
+            asm volatile("" ::"v"(acc[0][0]));
+            if (tid == 0 && blockIdx.x < 512) g_tm_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
         if (++c_u == nunits) {
             finish(ct);
             c_u = 0;
@@ -506,6 +544,10 @@ __global__ __launch_bounds__(TM_NT) void gemm_tinym_kernel(const TinyParams tp) 
             }
         }
     }
+#if GLM_TM_STAMP
+    __syncthreads();
+    if (tid == 0 && blockIdx.x < 512) g_tm_stamps[blockIdx.x][2] = __builtin_amdgcn_s_memrealtime();
+#endif
     if constexpr (TAIL) {
         // ---- hand-off (valid-forms table, row 1): every wave drains its write-through stores, the workgroup meets, one
         // lane adds to the ticket; the designated workgroups poll it (sc1 loads) and load behind their barrier ----
@@ -582,7 +624,7 @@ int glm_launch_gemm_tinym(int mode, const GemmParams& p, int n_tokens, hipStream
     const int M = mode == GEMM_PLAIN ? (int)p.R : n_tokens;
     GLM_CHECK_ARG(M == 1, GLM_ERR_UNSUPPORTED, "gemm_tinym: %d rows per block", M);
     // units: 4 rows x 4 KiB for long rows; a short K (expert down projection, 1408) as ONE unit of 3-KiB rows
-    if (mode == GEMM_PLAIN) return launch_tiny<GEMM_PLAIN, 1, 4, false>(tp, 1, st);
+    if (mode == GEMM_PLAIN) return launch_tiny<GEMM_PLAIN, 1, GLM_TM_SEGS_PLAIN, false, false, GLM_TM_RPW_PLAIN>(tp, 1, st);
     // grouped launches: rows per tile chosen for the TAIL of the launch — a workgroup's waves pull tiles from a counter, and
     // the launch ends when the slowest wave has finished its last tile; at Air dims one token gives 24.75 tiles of 4 rows per
     // workgroup for gate|up (7 waves take 3, one takes 4: +29 % on the critical wave), 49.5 tiles of 2 rows even that out
@@ -617,7 +659,7 @@ int glm_launch_gemm_tinym_combine_norm(const GemmParams& p, const void* y_prev, 
     tp.pc_y = (const bf16_t*)y_prev; tp.pc_ldy = ld_yprev; tp.pc_pos = pair_pos; tp.pc_k = k; tp.pc_shared_base = shared_base;
     tp.pc_res_in = (const bf16_t*)residual_in; tp.pc_norm_w = (const bf16_t*)norm_w; tp.pc_res_out = (bf16_t*)residual_out;
     tp.pc_x_out = (bf16_t*)x_out; tp.pc_eps = eps;
-    return launch_tiny<GEMM_PLAIN, 1, 4, true>(tp, 1, st);
+    return launch_tiny<GEMM_PLAIN, 1, GLM_TM_SEGS_PLAIN, true, false, GLM_TM_RPW_PLAIN>(tp, 1, st);
 }
 
 // o_proj of ONE token row continued, in the last workgroup to finish, by the post-attention add-RMSNorm + router +
@@ -642,5 +684,11 @@ int glm_launch_gemm_tinym_router_tail(const GemmParams& p, unsigned* ticket, flo
     tp.tr_y = (bf16_t*)y_norm; tp.tr_res_out = (bf16_t*)residual_out; tp.tr_gate_w = (const bf16_t*)gate_w; tp.tr_bias = bias;
     tp.tr_E = E; tp.tr_k = k; tp.tr_rsf = rsf; tp.tr_idx = topk_idx; tp.tr_w = (bf16_t*)topk_w;
     tp.tr_offs = offs; tp.tr_tok = tok; tp.tr_scale = (bf16_t*)scale; tp.tr_pos = pos; tp.tr_shared = with_shared;
-    return launch_tiny<GEMM_PLAIN, 1, 4, false, true>(tp, 1, st);
+    return launch_tiny<GEMM_PLAIN, 1, GLM_TM_SEGS_PLAIN, false, true, GLM_TM_RPW_PLAIN>(tp, 1, st);
 }
+
+#if GLM_TM_STAMP
+extern "C" int glm_debug_tinym_stamps(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tm_stamps), sizeof(unsigned long long) * 3 * (n < 512 ? n : 512)) == hipSuccess ? 0 : -1;
+}
+#endif
