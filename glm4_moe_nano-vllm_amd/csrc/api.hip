@@ -52,7 +52,7 @@ int fp8w_large(int mode, GemmParams p, int rows, int cols, void* scratch, size_t
     return glm_launch_gemm_largem(mode, p, st);  // p.wscale stays set
 }
 
-// GLM4MOE_TINYM=0 keeps the small-M kernels at T <= 2 (A/B runs and the bit-identity tests of the fused launches)
+// GLM4MOE_TINYM=0 keeps the small-M kernels at one token row (A/B runs and the bit-identity tests of the fused launches)
 bool tinym_enabled() {
     const char* e = getenv("GLM4MOE_TINYM");
     return !(e && e[0] == '0');

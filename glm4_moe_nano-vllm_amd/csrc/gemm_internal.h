@@ -39,7 +39,7 @@ int glm_launch_gemm_smallm(int mode, const GemmParams& p, hipStream_t st);
 // K-split partial sums (p.ksplit > 1, p.ypart): one fp32 [R,N] slab per K slice, no bias, no rounding
 int glm_launch_gemm_smallm_partial(const GemmParams& p, hipStream_t st);
 int glm_smallm_partial_slices(int K, int want);  // slices actually used for a requested count (whole 128-wide chunks)
-// single-sequence decode (gemm_tinym.hip): one or two token rows per weight matrix / per expert group, fp32 FMA GEMV with
+// single-sequence decode (gemm_tinym.hip): ONE token row per weight matrix / per expert group, fp32 FMA GEMV with
 // a persistent workgroup per CU.  n_tokens: rows of x (grouped gate|up).  GLM_ERR_UNSUPPORTED = shape not covered (the
 // caller then takes the small-M kernels).
 int glm_tinym_max_rows();

@@ -1,4 +1,4 @@
-// gemm_tinym.hip — weight-streaming GEMV for ONE token row per weight matrix (two in the fused QKV launch): the greedy
+// gemm_tinym.hip — weight-streaming GEMV for ONE token row per weight matrix: the greedy
 // single-sequence decode of BASELINE config 2 (bs = 1).  Same operators as gemm_smallm.hip (a5/a10 dense projections,
 // a12/a13 grouped expert gate|up + SiLU·mul and down), same rounding points, gfx950 only.
 //
@@ -15,7 +15,7 @@
 //   * the token rows live in LDS for the whole kernel (fragment read = one conflict-free ds_read_b128 per segment).
 // Optional prologue (PRO_COMBINE): the activation row is not loaded but COMPUTED by every workgroup — MoE combine of the
 // previous layer + the input add-RMSNorm (decode_layer.py:47-49 of the next layer) — behind the workgroup's first weight
-// loads, which removes the combine + norm launch of a T <= 2 decode layer.  Bit-identical to that launch: same code
+// loads, which removes the combine + norm launch of a one-token decode layer.  Bit-identical to that launch: same code
 // (fused_rows.h), same 512-thread mapping.
 #include "gemm_internal.h"
 #include "fused_rows.h"
@@ -639,7 +639,7 @@ int glm_launch_gemm_tinym(int mode, const GemmParams& p, int n_tokens, hipStream
     return launch_tiny<GEMM_DOWN, 1, 4, false, false, GLM_TM_RPW_DOWN>(tp, (int)p.R, st);
 }
 
-// QKV projection (+bias) of T <= 2 rows whose input is computed in the kernel: moe_combine of the previous layer's expert
+// QKV projection (+bias) of ONE token row whose input is computed in the kernel: moe_combine of the previous layer's expert
 // rows + add-RMSNorm with `residual_in` (see the file header).  p.x is ignored; p.K = H.
 int glm_launch_gemm_tinym_combine_norm(const GemmParams& p, const void* y_prev, int64_t ld_yprev, const int32_t* pair_pos,
                                        int k, int64_t shared_base, const void* residual_in, const void* norm_w,

@@ -734,7 +734,7 @@ __global__ __launch_bounds__(CN_NT) void moe_combine_add_rmsnorm_kernel(
     const bf16_t* __restrict__ y, int64_t ldy, const int32_t* __restrict__ pair_pos, int k, int64_t shared_base,
     const bf16_t* res_in, const bf16_t* __restrict__ w, bf16_t* out, bf16_t* res_out, int H, float eps) {
     __shared__ float red[CN_NT / 64];
-    // the row function is shared with the T <= 2 QKV launch that runs it as its prologue (gemm_tinym.hip)
+    // the row function is shared with the one-token QKV launch that runs it as its prologue (gemm_tinym.hip)
     glm_combine_add_rmsnorm_row<VPT>(y, ldy, pair_pos, k, shared_base, res_in, w, out, res_out, nullptr, H, eps, blockIdx.x, red);
 }
 

@@ -570,7 +570,7 @@ TINYM_MAX_ROWS = 1  # token rows the single-sequence GEMV body takes (csrc/gemm_
 
 def grouped_gemm_gateup_silu(x, w13, expert_offsets, sorted_token, R: int, max_rows_per_group: int | None = None) -> torch.Tensor:
     """x [T,H]; w13 [G, 2I, H] -> act [R, I].  max_rows_per_group: an upper bound the caller knows (T for a top-k routing
-    with the shared group); with T <= 2 it selects the single-sequence GEMV body."""
+    with the shared group); with ONE token row it selects the single-sequence GEMV body."""
     _bf16(x, "x"); _bf16(w13, "w13")
     G, I2, H = w13.shape
     I = I2 // 2
@@ -797,7 +797,7 @@ def moe_combine_add_rmsnorm(dc: DeferredCombine, residual: torch.Tensor, weight:
 
 def combine_add_rmsnorm_gemm(dc: DeferredCombine, residual: torch.Tensor, norm_weight: torch.Tensor, eps: float,
                              w: torch.Tensor, bias: torch.Tensor | None):
-    """T <= 2: moe_combine + add_rmsnorm(combined, residual) + (x @ w.T + bias) in ONE launch (glm_gemm_bf16_combine_norm).
+    """ONE token: moe_combine + add_rmsnorm(combined, residual) + (x @ w.T + bias) in ONE launch (glm_gemm_bf16_combine_norm).
     Returns (y [T, N], residual_out [T, H]); the normalised hidden state itself is never written."""
     _bf16(residual, "residual"); _bf16(norm_weight, "norm_weight"); _bf16(w, "w")
     H = dc.y.shape[1]

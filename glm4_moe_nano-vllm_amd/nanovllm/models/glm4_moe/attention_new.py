@@ -72,7 +72,7 @@ class Glm4MoeAttention(nn.Module):
                 qkv: torch.Tensor | None = None, skip_o_proj: bool = False):
         """defer_o_reduce: the caller feeds the result straight into RMSNorm.forward(x, residual) and accepts a
         hip_ops.PartialSum (K-slice partial sums of o_proj, reduced inside that add-RMSNorm kernel).
-        qkv: the QKV projection of this layer's normalised input, already computed by the caller (the T <= 2 launch that
+        qkv: the QKV projection of this layer's normalised input, already computed by the caller (the one-token launch that
         fuses combine + input norm + projection); hidden_states is then unused (may be None).
         skip_o_proj: return the attention output [T, nh*hd] itself — the caller runs o_proj fused with what follows it
         (one token: o_proj + post-attention norm + router in one launch; TP = 1 only)."""

@@ -50,7 +50,7 @@ class Glm4MoeDecoderLayer(nn.Module):
         RMSNorm.forward(x, residual)) and accepts a hip_ops.DeferredCombine instead of a tensor."""
         qkv = None
         if residual is not None and hip_ops.can_combine_norm_gemm(hidden_states, residual.shape[-1]):
-            # T <= 2 (single-sequence decode): the previous layer's MoE combine, this layer's input add-RMSNorm and the
+            # one token (single-sequence decode): the previous layer's MoE combine, this layer's input add-RMSNorm and the
             # QKV projection in ONE launch — every workgroup of the GEMV recomputes the tiny combine + norm behind its
             # first weight loads; bit-identical to the separate launches
             ln, qp = self.input_layernorm, self.self_attn.qkv_proj

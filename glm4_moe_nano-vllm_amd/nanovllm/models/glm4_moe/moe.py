@@ -171,7 +171,7 @@ class Glm4MoeMoE(nn.Module):
             y = hip_ops.grouped_gemm_down_fp8w(act, w2_q, w2_s, offs, scale, E)
         else:
             w13, w2 = self._stacked()
-            # a token's k experts are distinct and the shared group holds T rows: no group exceeds T rows (T <= 2 selects
+            # a token's k experts are distinct and the shared group holds T rows: no group exceeds T rows (T = 1 selects
             # the single-sequence GEMV body)
             act = hip_ops.grouped_gemm_gateup_silu(h, w13, offs, tok, R, max_rows_per_group=T)
             y = hip_ops.grouped_gemm_down(act, w2, offs, scale, E, max_rows_per_group=T)
