@@ -38,6 +38,7 @@
 // IPC under HIP-graph replay with an odd number of calls per graph (tools/oneshot_allreduce_2proc.py).  It has NOT run
 // across GPUs (one-GPU lease); RCCL stays the default (GLM_ONESHOT_ALLREDUCE=1 opts in).
 #include "common.h"
+#include <string.h>
 
 namespace {
 constexpr int OS_MAX_WORLD = 8;
@@ -125,6 +126,66 @@ __global__ __launch_bounds__(256) void oneshot_allreduce_kernel(const bf16_t* in
     }
 }
 }  // namespace
+
+// ---- communication memory (host-only helpers; r04) ------------------------------------------------------------------
+// The receive buffer and the flag words are written by PEER GPUs over xGMI and polled / read by the owner INSIDE a running
+// kernel.  Ordinary hipMalloc memory is coarse-grained: its lines may sit in the owner's L2 across the whole kernel, and a
+// same-device test (two streams or two processes on one GPU share that L2) can never show a stale line.  So this memory is
+// allocated UNCACHED (hipExtMallocWithFlags(hipDeviceMallocUncached): MTYPE UC, every access goes to memory) or, on
+// request, fine-grained (coherent at system scope).  Which accesses of oneshot_allreduce_kernel rely on it:
+//   * the owner's relaxed system-scope polls of flag[rank][q] (written by rank q's release store over the fabric);
+//   * the owner's loads of rbuf[rank][slot][q] behind the acquire fence (written by rank q's pushes);
+// the peers' stores themselves travel over the fabric either way.  The memory is exported / opened with hipIpc so that it
+// can be mapped by the other ranks' processes exactly like the torch storage it replaces.
+extern "C" int glm_comm_alloc(void** ptr, size_t bytes, int kind) {
+    GLM_CHECK_ARG(ptr && bytes > 0 && (kind == GLM_COMM_UNCACHED || kind == GLM_COMM_FINEGRAINED), GLM_ERR_INVALID,
+                  "glm_comm_alloc: bad arguments");
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, kind == GLM_COMM_UNCACHED ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
+    if (e == hipSuccess) e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        if (p) (void)hipFree(p);
+        (void)hipGetLastError();
+        glm_set_error("glm_comm_alloc(%zu B, kind %d): %s", bytes, kind, hipGetErrorString(e));
+        return GLM_ERR_LAUNCH;
+    }
+    *ptr = p;
+    return GLM_OK;
+}
+
+extern "C" int glm_comm_free(void* ptr) {
+    if (!ptr) return GLM_OK;
+    hipError_t e = hipFree(ptr);
+    GLM_CHECK_ARG(e == hipSuccess, GLM_ERR_LAUNCH, "glm_comm_free: %s", hipGetErrorString(e));
+    return GLM_OK;
+}
+
+extern "C" int glm_comm_ipc_export(const void* ptr, void* handle) {
+    static_assert(sizeof(hipIpcMemHandle_t) == GLM_COMM_IPC_HANDLE_BYTES, "handle size is part of the ABI");
+    GLM_CHECK_ARG(ptr && handle, GLM_ERR_INVALID, "glm_comm_ipc_export: null pointer");
+    hipError_t e = hipIpcGetMemHandle((hipIpcMemHandle_t*)handle, const_cast<void*>(ptr));
+    GLM_CHECK_ARG(e == hipSuccess, GLM_ERR_LAUNCH, "glm_comm_ipc_export: %s", hipGetErrorString(e));
+    return GLM_OK;
+}
+
+extern "C" int glm_comm_ipc_open(const void* handle, void** ptr) {
+    GLM_CHECK_ARG(ptr && handle, GLM_ERR_INVALID, "glm_comm_ipc_open: null pointer");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    void* p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    GLM_CHECK_ARG(e == hipSuccess, GLM_ERR_LAUNCH, "glm_comm_ipc_open: %s", hipGetErrorString(e));
+    *ptr = p;
+    return GLM_OK;
+}
+
+extern "C" int glm_comm_ipc_close(void* ptr) {
+    if (!ptr) return GLM_OK;
+    hipError_t e = hipIpcCloseMemHandle(ptr);
+    GLM_CHECK_ARG(e == hipSuccess, GLM_ERR_LAUNCH, "glm_comm_ipc_close: %s", hipGetErrorString(e));
+    return GLM_OK;
+}
 
 extern "C" size_t glm_allreduce_oneshot_buffer_elems(int world, int64_t n_max) {
     return (size_t)2 * (size_t)(world > 0 ? world : 0) * (size_t)(n_max > 0 ? n_max : 0);

@@ -26,14 +26,17 @@ or gloo in the CPU tests); `run_emulated` drives the generators of several logic
 (the one-GPU rehearsal and the "EP=2 == TP=1" test).
 
 Two dispatch forms, same arithmetic, same results:
-  * FIXED CAPACITY (r03; the default at decode sizes, graph-capturable): the routing is replicated, so every rank can
-    compute the whole exchange plan on the device (glm_ep_plan: send slots, receive-side expert offsets and gather list)
-    — no count all-gather, no host read.  The all-to-all moves equal, capacity-sized slots ([ep][cap] rows, cap = rows
-    per token slice x min(k, experts per rank): the worst case, overflow impossible); the grouped GEMMs run over the
-    capacity-sized receive buffer with expert_offsets saying which rows are real.  Three collectives per MoE block
-    (all-to-all, all-to-all, all-gather), all with static shapes.
-  * VARIABLE SPLITS (`forward_varlen`, prefill-sized steps and GLM_EP_FIXED=0): all-to-all-v with exact row counts; the
-    split sizes are host integers, so this form reads the count matrix once per MoE block and runs eagerly.
+  * FIXED CAPACITY (r03; decode steps of up to FIXED_MAX_TOKENS tokens and every captured step; graph-capturable): the
+    routing is replicated, so every rank can compute the whole exchange plan on the device (glm_ep_plan: send slots,
+    receive-side expert offsets and gather list) — no count all-gather, no host read.  The all-to-all moves equal,
+    capacity-sized slots ([ep][cap] rows); the grouped GEMMs run over the capacity-sized receive buffer with
+    expert_offsets saying which rows are real.  Three collectives per MoE block (all-to-all, all-to-all, all-gather), all
+    with static shapes.  cap = the worst case (rows per token slice x min(k, experts per rank), overflow impossible) or,
+    when the caller opted in with `EPExperts.set_capacity_factor(f)`, f x the mean with the plan's `overflow` word
+    sending an overflowing step to the variable-split form (see the class).
+  * VARIABLE SPLITS (`forward_varlen`: prefill-sized steps, the redo of an overflowed step, GLM_EP_FIXED=0): all-to-all-v
+    with exact row counts; the split sizes are host integers, so this form reads the count matrix once per MoE block and
+    runs eagerly.
 """
 from __future__ import annotations
 
@@ -61,21 +64,88 @@ class EPExperts:
         self.w13, self.w2, self.shared = w13, w2, shared
 
     FIXED_MAX_SLICE_PAIRS = 16384  # glm_ep_plan keeps a token slice's pairs in LDS
+    # The fixed-capacity form exists for DECODE steps (graph buckets): every buffer has ep*cap rows whatever the routing.
+    # A prefill-sized step (T = 16384 at ep = 8: five [131072, 4096] tensors of 1 GiB each at the worst-case capacity)
+    # takes the variable-split form, which moves exactly the real rows; only a step that is being captured in a HIP graph
+    # may not (a host read cannot be captured).
+    FIXED_MAX_TOKENS = 512
+
+    # Tight capacity (r04).  `capacity_factor` f: cap = ceil(f x mean rows per (source, destination) slot) instead of the
+    # worst case (at B = 256, ep = 8, k = 8: 64 rows per slot instead of 256 => 4 MB per direction per rank instead of
+    # 16 MB).  glm_ep_plan reports a slot that does not fit through its `overflow` word (the SAME value on every rank: the
+    # plan is computed from the replicated routing for every (source, destination) pair) and drops the same rows on both
+    # sides, so nothing is out of bounds — but the step's result is then wrong and has to be redone.  The word is kept in
+    # a sticky device flag; the caller that opted in (`ModelRunner.run`, bench.py, the tests) reads it where it
+    # synchronises anyway (`overflowed()`), and re-runs the step with `force_varlen(True)`: a decode step is idempotent
+    # (its K/V rows are rewritten with the same values).  None (the default) = worst-case capacity, overflow impossible.
+    capacity_factor: float | None = None
+    _force_varlen = False
+    _flags: dict = {}  # device -> sticky overflow word (int32[1]); created by the first eager step on that device
+
+    @classmethod
+    def set_capacity_factor(cls, f: float | None) -> None:
+        cls.capacity_factor = None if f is None or f <= 0 else float(f)
+
+    @classmethod
+    def force_varlen(cls, on: bool) -> None:
+        cls._force_varlen = bool(on)
+
+    @classmethod
+    def overflowed(cls, reset: bool = True) -> int:
+        """Largest (source, destination) row count that exceeded its slot since the last call, 0 if none (one host read
+        per flag: call it where the step is synchronised anyway)."""
+        worst = 0
+        for f in cls._flags.values():
+            v = int(f.item())
+            if v:
+                worst = max(worst, v)
+                if reset:
+                    f.zero_()
+        return worst
 
     def capacity(self, T: int) -> int:
-        """Rows per (source, destination) slot that can never overflow: every token of a slice sends at most
-        min(k, experts per rank) rows to one rank."""
+        """Rows per (source, destination) slot.  Worst case: every token of a slice sends at most min(k, experts per
+        rank) rows to one rank — can never overflow.  With a capacity factor: that many times the mean, capped by the
+        worst case."""
         per = (T + self.ep - 1) // self.ep
-        return max(1, per * min(self.k, self.El))
+        worst = max(1, per * min(self.k, self.El))
+        f = type(self).capacity_factor
+        if f is None:
+            return worst
+        mean = per * self.k / self.ep
+        return max(1, min(worst, int(-(-f * mean // 1))))
+
+    def _capturing(self, h) -> bool:
+        return bool(h.is_cuda and torch.cuda.is_current_stream_capturing())
+
+    def takes_fixed(self, T: int, capturing: bool = False) -> bool:
+        """Which dispatch form a step of T tokens takes (pinned by tests/test_ep_gloo_cpu.py)."""
+        per = (T + self.ep - 1) // self.ep
+        fits = (hasattr(self.ops, "ep_plan") and per * self.k <= self.FIXED_MAX_SLICE_PAIRS and self.ep * self.E <= 2048)
+        if capturing:
+            if not fits:
+                raise RuntimeError(f"expert-parallel step of {T} tokens cannot be captured (fixed-capacity plan limits)")
+            return True
+        return (fits and os.environ.get("GLM_EP_FIXED", "1") != "0" and not type(self)._force_varlen
+                and T <= self.FIXED_MAX_TOKENS)
 
     def forward(self, h: torch.Tensor, topk_idx: torch.Tensor, topk_w: torch.Tensor):
         """Generator.  h [T, H] (replicated), routing of ALL T tokens (replicated, identical on every rank).
         Yields (op, payload...) tuples at the collectives, finally returns the full [T, H] output."""
-        T = h.shape[0]
-        per = (T + self.ep - 1) // self.ep
-        fixed = (hasattr(self.ops, "ep_plan") and os.environ.get("GLM_EP_FIXED", "1") != "0"
-                 and per * self.k <= self.FIXED_MAX_SLICE_PAIRS and self.ep * self.E <= 2048)
+        fixed = self.takes_fixed(h.shape[0], self._capturing(h))
         return (yield from (self.forward_fixed if fixed else self.forward_varlen)(h, topk_idx, topk_w))
+
+    def _note_overflow(self, ovf: torch.Tensor) -> None:
+        if type(self).capacity_factor is None:
+            return  # worst-case capacity: the word is always 0
+        flags = type(self)._flags
+        flag = flags.get(ovf.device)
+        if flag is None:
+            if self._capturing(ovf):
+                raise RuntimeError("expert-parallel overflow flag missing while a HIP graph is being captured: run one eager "
+                                   "step with the capacity factor set before capturing")
+            flag = flags[ovf.device] = torch.zeros(1, dtype=torch.int32, device=ovf.device)
+        torch.maximum(flag, ovf.reshape(1).to(torch.int32), out=flag)
 
     def forward_fixed(self, h: torch.Tensor, topk_idx: torch.Tensor, topk_w: torch.Tensor):
         """Fixed-capacity dispatch: no host synchronisation anywhere (HIP-graph capturable with captured collectives)."""
@@ -84,8 +154,9 @@ class EPExperts:
         lo, hi = token_slice(T, ep, self.rank)
         Tl = hi - lo
         cap = self.capacity(T)
-        send_gather, slot_scale, pair_slot, recv_offs, recv_gidx, _overflow = ops.ep_plan(
+        send_gather, slot_scale, pair_slot, recv_offs, recv_gidx, overflow = ops.ep_plan(
             topk_idx.contiguous(), topk_w.contiguous(), E, ep, self.rank, cap)
+        self._note_overflow(overflow)
         # 1. my pairs' rows into their slots (unused slot rows stay uninitialised: nobody reads them)
         send = ops.gather_rows(h, send_gather)                                  # [ep * cap, H]
         recv = yield ("all_to_all_fixed", send, cap)                            # slot s = the rows rank s sent me

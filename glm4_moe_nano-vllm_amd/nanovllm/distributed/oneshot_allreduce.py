@@ -1,7 +1,8 @@
 """One-shot all-reduce over directly mapped peer buffers (csrc/oneshot_allreduce.hip) — OPT-IN (GLM_ONESHOT_ALLREDUCE=1).
 
 RCCL (`dist.all_reduce`) is the default and the only path measured on more than one GPU.  This module maps every rank's
-receive buffer and flag array into every peer (PyTorch's CUDA-IPC storage sharing, dmabuf on this ROCm), after which an
+receive buffer and flag array — UNCACHED device memory from the library's glm_comm_* helpers (r04; r03 used ordinary torch
+tensors, whose lines the owner's L2 may keep across a running kernel) — into every peer over hipIpc, after which an
 all-reduce of a [T, H] bf16 tensor is ONE kernel per rank: push the rows into every peer's receive slot, signal the
 peers, wait for their signals, sum the contributions out of local memory in rank order.  The call counter (epoch) lives
 in DEVICE memory and is advanced by the kernel, so captured calls stay correct under HIP-graph replay.  Anything that
@@ -22,6 +23,60 @@ import torch.distributed as dist
 from nanovllm import hip_ops
 
 N_FLAGS = 8
+COMM_UNCACHED, COMM_FINEGRAINED = 0, 1
+IPC_HANDLE_BYTES = 64
+
+
+class CommBuffer:
+    """Peer-written communication memory (include/glm4moe_hip.h, glm_comm_*): device memory allocated UNCACHED (or
+    fine-grained with GLM_ONESHOT_COMM_KIND=finegrained) instead of as an ordinary, L2-cacheable torch tensor — a peer GPU
+    writes it over xGMI while the owner polls and reads it inside a running kernel.  Zero-filled.  `handle()` is an
+    opaque bytes object another process turns into a mapping of the same memory with `CommBuffer.open()`."""
+
+    def __init__(self, nbytes: int, device, kind: int | None = None, _ptr: int | None = None, _owner: bool = True):
+        self.nbytes, self.device, self._owner = int(nbytes), torch.device(device), _owner
+        self._lib = hip_ops.load_library()
+        if _ptr is not None:
+            self.ptr = _ptr
+            return
+        if kind is None:
+            kind = COMM_FINEGRAINED if os.environ.get("GLM_ONESHOT_COMM_KIND", "uncached") == "finegrained" else COMM_UNCACHED
+        self.kind = kind
+        p = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            hip_ops._check(self._lib.glm_comm_alloc(ctypes.byref(p), self.nbytes, kind), "glm_comm_alloc")
+        self.ptr = p.value
+
+    def data_ptr(self) -> int:
+        return self.ptr
+
+    def handle(self) -> bytes:
+        h = ctypes.create_string_buffer(IPC_HANDLE_BYTES)
+        hip_ops._check(self._lib.glm_comm_ipc_export(ctypes.c_void_p(self.ptr), h), "glm_comm_ipc_export")
+        return h.raw
+
+    @classmethod
+    def open(cls, handle: bytes, nbytes: int, device) -> "CommBuffer":
+        lib = hip_ops.load_library()
+        p = ctypes.c_void_p()
+        with torch.cuda.device(torch.device(device)):
+            hip_ops._check(lib.glm_comm_ipc_open(ctypes.create_string_buffer(handle, IPC_HANDLE_BYTES), ctypes.byref(p)),
+                           "glm_comm_ipc_open")
+        return cls(nbytes, device, _ptr=p.value, _owner=False)
+
+    def close(self) -> None:
+        ptr, self.ptr = getattr(self, "ptr", None), None
+        if not ptr:
+            return
+        try:
+            with torch.cuda.device(self.device):
+                torch.cuda.synchronize()
+                (self._lib.glm_comm_free if self._owner else self._lib.glm_comm_ipc_close)(ctypes.c_void_p(ptr))
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def __del__(self):
+        self.close()
 
 
 class OneShotAllReduce:
@@ -29,24 +84,19 @@ class OneShotAllReduce:
     def __init__(self, n_max: int, device, rank: int, world: int):
         assert n_max % 8 == 0 and 1 <= world <= N_FLAGS
         self.n_max, self.device, self.rank, self.world = n_max, device, rank, world
-        # receive buffer [2 slots][world senders][n_max]; flags[q] = last epoch complete from rank q; state = epoch,
-        # arrive, done, status (all advanced by the kernel)
-        self.buf = torch.zeros(2 * world * n_max, dtype=torch.bfloat16, device=device)
-        self.flags = torch.zeros(N_FLAGS, dtype=torch.int32, device=device)
+        # receive buffer [2 slots][world senders][n_max] bf16 and flags[q] = last epoch complete from rank q: peer-written
+        # => communication memory (uncached), not torch storage.  state = epoch, arrive, done, status: touched by this
+        # rank's own kernel only => an ordinary tensor.
+        self.buf = CommBuffer(2 * world * n_max * 2, device)
+        self.flags = CommBuffer(N_FLAGS * 4, device)
         self.state = torch.zeros(4, dtype=torch.int32, device=device)
         self.peer_bufs = [self.buf] * world      # replaced by connect()
         self.peer_flags = [self.flags] * world
-        self._keep = []
 
     # ---- wiring -------------------------------------------------------------------------------------------------
     def share_handles(self):
         """What a peer needs to map this rank's buffer and flags (picklable)."""
-        return (self.buf.untyped_storage()._share_cuda_(), self.flags.untyped_storage()._share_cuda_())
-
-    @staticmethod
-    def _open(handle, dtype, numel, device):
-        st = torch.UntypedStorage._new_shared_cuda(*handle)
-        return torch.empty(0, dtype=dtype, device=device).set_(st, 0, (numel,))
+        return (self.buf.handle(), self.flags.handle())
 
     def connect(self, handles: list):
         """handles[r] = rank r's share_handles() (own entry ignored)."""
@@ -56,8 +106,8 @@ class OneShotAllReduce:
                 bufs.append(self.buf)
                 flags.append(self.flags)
             else:
-                bufs.append(self._open(h[0], torch.bfloat16, 2 * self.world * self.n_max, self.device))
-                flags.append(self._open(h[1], torch.int32, N_FLAGS, self.device))
+                bufs.append(CommBuffer.open(h[0], self.buf.nbytes, self.device))
+                flags.append(CommBuffer.open(h[1], self.flags.nbytes, self.device))
         self.peer_bufs, self.peer_flags = bufs, flags
 
     @classmethod

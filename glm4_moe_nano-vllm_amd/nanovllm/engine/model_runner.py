@@ -39,6 +39,9 @@ class ModelRunner:
                 # this rank's communicator exists (a failed capture leaves a process unusable and its peers blocked)
                 from nanovllm.distributed import capture_probe
                 env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(self.world_size))
+                if int(getattr(hf, "expert_parallel_size", 1) or 1) > 1:
+                    # the captured step then holds an all-to-all and an all-gather as well: probe those too
+                    env["GLM_PROBE_EP"] = "1"
                 capture_ok, self.graph_note = capture_probe.probe(env)
             torch.cuda.set_device(rank)
             dist.init_process_group("nccl", world_size=self.world_size, rank=rank,
@@ -51,6 +54,12 @@ class ModelRunner:
                     self.graph_note = self.graph_note or "capture probe failed on another rank"
         torch.cuda.set_device(rank)
         self.device = torch.device("cuda", rank)
+        self.ep = int(getattr(hf, "expert_parallel_size", 1) or 1) > 1
+        if self.ep:
+            # tight all-to-all slots (2x the mean rows per slot unless the config says otherwise; 0 = worst case): this
+            # runner is the caller that checks the plan's overflow word after every step and redoes an overflowed one
+            from nanovllm.distributed.expert_parallel import EPExperts
+            EPExperts.set_capacity_factor(getattr(hf, "expert_parallel_capacity_factor", 2.0))
         old_dtype = torch.get_default_dtype()
         torch.set_default_dtype(hf.torch_dtype)
         try:
@@ -178,9 +187,9 @@ class ModelRunner:
 
     # ------------------------------------------------------------------ execution
     @torch.inference_mode()
-    def run_model(self, input_ids, positions, is_prefill):
+    def run_model(self, input_ids, positions, is_prefill, eager: bool = False):
         bs = input_ids.size(0)
-        if is_prefill or self.enforce_eager or bs > self.graph_bs[-1]:
+        if is_prefill or self.enforce_eager or eager or bs > self.graph_bs[-1]:
             return self.model.compute_logits(self.model(input_ids, positions))
         ctx = get_context()
         bucket = next(b for b in self.graph_bs if b >= bs)
@@ -200,6 +209,20 @@ class ModelRunner:
         temps = self._dev([s.temperature for s in seqs], torch.float32) if self.rank == 0 else None
         logits = self.run_model(input_ids, positions, is_prefill)
         tokens = self.sampler(logits, temps).tolist() if self.rank == 0 else None
+        if self.ep:
+            # expert parallelism with tight slots: did a (source, destination) slot overflow in this step?  The word is
+            # computed from the replicated routing, so every rank reads the same value and takes the same branch.  An
+            # overflowed step dropped rows: redo it eagerly with exact (variable) splits — K/V rows are rewritten with
+            # the same values, nothing else was kept from the first attempt.
+            from nanovllm.distributed.expert_parallel import EPExperts
+            if EPExperts.overflowed():
+                EPExperts.force_varlen(True)
+                try:
+                    logits = self.run_model(input_ids, positions, is_prefill, eager=True)
+                    tokens = self.sampler(logits, temps).tolist() if self.rank == 0 else None
+                finally:
+                    EPExperts.force_varlen(False)
+                self.ep_redone_steps = getattr(self, "ep_redone_steps", 0) + 1
         if self.world_size > 1:
             # a one-shot all-reduce that gave up waiting poisoned its output and set a status word: surface it here, where
             # rank 0 has just synchronised on the tokens anyway (no-op on RCCL)

@@ -98,6 +98,11 @@ _SIGNATURES = {
                                                   c_int, c_void_p, c_size_t, c_void_p]),
     "glm_router_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "glm_allreduce_oneshot_buffer_elems": (c_size_t, [c_int, c_int64]),
+    "glm_comm_alloc": (c_int, [c_void_p, c_size_t, c_int]),
+    "glm_comm_free": (c_int, [c_void_p]),
+    "glm_comm_ipc_export": (c_int, [c_void_p, c_void_p]),
+    "glm_comm_ipc_open": (c_int, [c_void_p, c_void_p]),
+    "glm_comm_ipc_close": (c_int, [c_void_p]),
     "glm_allreduce_oneshot": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p,
                                       c_void_p]),
     "glm_ep_plan": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
@@ -137,6 +142,9 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     if path is None:
         _lib = lib
     return lib
+
+
+GLM_ERR_UNSUPPORTED = -2  # include/glm4moe_hip.h
 
 
 def _check(rc: int, name: str) -> None:
@@ -830,7 +838,8 @@ def gemm_add_rmsnorm_router_topk_align(x: torch.Tensor, w: torch.Tensor, residua
                                        eps: float, gate_w: torch.Tensor, bias: torch.Tensor, k: int,
                                        routed_scaling_factor: float, with_shared: bool):
     """ONE token: o_proj + post-attention add-RMSNorm + router + bucketing in one launch (glm_gemm_bf16_router_tail).
-    x [1, K], w [H, K].  Returns what add_rmsnorm_router_topk(..., align_with_shared=...) returns."""
+    x [1, K], w [H, K].  Returns what add_rmsnorm_router_topk(..., align_with_shared=...) returns — or None when the
+    launcher does not cover the shape (nothing was enqueued: take the two-launch path)."""
     _bf16(x, "x"); _bf16(w, "w"); _bf16(residual, "residual"); _bf16(norm_weight, "norm_weight"); _bf16(gate_w, "gate_w")
     assert bias.dtype == torch.float32 and x.shape[0] == 1 and w.stride(1) == 1
     K, H, E = x.shape[1], w.shape[0], gate_w.shape[0]
@@ -847,10 +856,15 @@ def gemm_add_rmsnorm_router_topk_align(x: torch.Tensor, w: torch.Tensor, residua
     pos = torch.empty(k, dtype=torch.int32, device=dev)
     # two self-restoring counters + E floats of logits scratch, one grow-only zeroed buffer per device
     ticket = _grow_only(_tail_ws, _tail_ws_retired, dev, 16 + 4 * 256, "router-tail workspace").data_ptr()
-    _check(load_library().glm_gemm_bf16_router_tail(
+    rc = load_library().glm_gemm_bf16_router_tail(
         _p(x), _p(w), w.stride(0), K, H, _p(o_row), ticket, _p(r2), _p(norm_weight), eps, _p(y), _p(ro), _p(gate_w),
         _p(bias), E, k, routed_scaling_factor, _p(idx), _p(tw), _p(offs), _p(tok), _p(scale), _p(pos), 1 if with_shared else 0,
-        _stream()), "glm_gemm_bf16_router_tail")
+        _stream())
+    if rc == GLM_ERR_UNSUPPORTED:
+        # the launcher's own limits (K window of the tail's LDS scratch, rows per wave vs experts) are checked before anything
+        # is enqueued: nothing ran, the caller falls back to o_proj + add_rmsnorm_router_topk (two launches)
+        return None
+    _check(rc, "glm_gemm_bf16_router_tail")
     return y.view(residual.shape), ro.view(residual.shape), idx, tw, (offs, tok, scale, pos)
 
 

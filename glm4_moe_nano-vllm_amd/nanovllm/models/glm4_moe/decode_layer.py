@@ -71,13 +71,16 @@ class Glm4MoeDecoderLayer(nn.Module):
             # o_proj GEMV that finishes last carries on with the token's norm + router (bit-identical to the two launches)
             o = self.self_attn(hidden_states, positions, qkv=qkv, skip_o_proj=True)
             ln = self.post_attention_layernorm
+            fused = None
             if o.dim() == 2 and o.shape[0] == 1 and o.is_contiguous():
-                hidden_states, residual, idx, w, aligned = hip_ops.gemm_add_rmsnorm_router_topk_align(
+                fused = hip_ops.gemm_add_rmsnorm_router_topk_align(
                     o, op.weight.data, residual, ln.weight.data, ln.eps, gate.weight.data, gate.e_score_correction_bias,
                     gate.top_k, float(gate.routed_scaling_factor), True)
+            if fused is not None:
+                hidden_states, residual, idx, w, aligned = fused
                 hidden_states = self.mlp(hidden_states, routing=(idx, w), aligned=aligned, defer_combine=defer_combine)
                 return hidden_states, residual
-            hidden_states = op(o, defer_reduce=True)
+            hidden_states = op(o, defer_reduce=True)  # shape outside the fused launch's window: two launches
         else:
             # o_proj may hand over K-slice partial sums; the add-RMSNorm right below reduces them (decode batches)
             hidden_states = self.self_attn(hidden_states, positions, defer_o_reduce=True, qkv=qkv)

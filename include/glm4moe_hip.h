@@ -11,7 +11,9 @@
  *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
  *     (PyTorch storage).  The library never allocates, frees, synchronises or reads back:
  *     every call only enqueues kernels on `stream` (a hipStream_t), so a sequence of calls
- *     can be captured in a hipGraph.
+ *     can be captured in a hipGraph.  (One exception, host-only and outside any captured
+ *     sequence: the glm_comm_* helpers that allocate the one-shot all-reduce's peer-written
+ *     communication memory.)
  *   - bf16 tensors are passed as `const void*` / `void*` (2-byte elements, row-major,
  *     innermost stride 1).  "ld*" / "*_stride" arguments are in ELEMENTS.
  *   - return value: GLM_OK (0) or a negative GLM_ERR_* code; glm_last_error() returns a
@@ -386,6 +388,20 @@ int glm_grouped_gemm_down_cap(const void* act, const void* w2, int64_t w2_group_
  *     NOT the default path: RCCL is; this entry has run with world = 1, with two ranks on two streams of one device and
  *     with two processes on one device (eager and under graph replay) only.                                          */
 size_t glm_allreduce_oneshot_buffer_elems(int world, int64_t n_max);
+/*     Communication memory for the receive buffer and the flags (r04) — the ONE exception to "the library never
+ *     allocates": memory that peer GPUs write over xGMI and the owner polls / reads inside a running kernel must not be
+ *     ordinary (coarse-grained, L2-cacheable) hipMalloc storage.  Host-only helpers, they synchronise and are not
+ *     capturable: glm_comm_alloc = hipExtMallocWithFlags(uncached | fine-grained) + zero fill; the export / open pair
+ *     maps it into the peers' processes (hipIpc; handle = GLM_COMM_IPC_HANDLE_BYTES opaque bytes, picklable) the way the
+ *     reference's ranks share their POSIX shm segment (engine/model_runner.py:51-54 — control plane there, data here). */
+#define GLM_COMM_UNCACHED           0
+#define GLM_COMM_FINEGRAINED        1
+#define GLM_COMM_IPC_HANDLE_BYTES  64
+int glm_comm_alloc(void** ptr, size_t bytes, int kind);
+int glm_comm_free(void* ptr);
+int glm_comm_ipc_export(const void* ptr, void* handle);
+int glm_comm_ipc_open(const void* handle, void** ptr);
+int glm_comm_ipc_close(void* ptr);
 int glm_allreduce_oneshot(const void* in, void* out, void* const* peer_bufs, void* const* peer_flags, int rank, int world,
                           int64_t n, int64_t n_max, void* state, glm_stream_t stream);
 

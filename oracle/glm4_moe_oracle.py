@@ -304,19 +304,31 @@ def attention_block(h, positions, lw: LayerWeights, cfg, cos_sin_cache, k_cache,
 
 
 def decoder_layer(positions, h, residual, lw: LayerWeights, cfg, cos_sin_cache, k_cache,
-                  v_cache, meta: AttnMeta, force_idx=None, trace=None):
+                  v_cache, meta: AttnMeta, force_idx=None, trace=None, fp32_inplace_alias: bool = False):
     """decode_layer.py:79-100 — returns (mlp_out, residual); mlp_out is NOT added to the
     residual here (the next layer's add_rms does it).  `trace` (a dict) receives the intermediates the tests
     compare (attention output, router input, routing); `force_idx` is handed to `router`."""
     eps = cfg["rms_norm_eps"]
+    # layernorm.py:21-25,35-39 work IN PLACE on `x.float()`.  In the runner's bf16 regime (model_runner.py:30) that is a
+    # copy; with fp32 tensors it is the caller's tensor itself, so the reference AS EXECUTED in fp32 returns a residual
+    # that aliases the normalised output (`residual = x.to(orig_dtype)` is x, then `x.mul_` scales both).  That is an
+    # artefact of fp32 module dtype, not the algorithm: only `fp32_inplace_alias=True` (the C1 fixture's fp32 leg)
+    # reproduces it; the default stays the dtype-generic evaluation the tests use as exact arithmetic.
+    alias = fp32_inplace_alias and h.dtype == torch.float32
     if residual is None:
         h, residual = rms_forward(h, lw.input_ln, eps), h
+        if alias:
+            residual = h
     else:
         h, residual = add_rms_forward(h, residual, lw.input_ln, eps)
+        if alias:
+            residual = h
     h = attention_block(h, positions, lw, cfg, cos_sin_cache, k_cache, v_cache, meta)
     if trace is not None:
         trace["attn_out"] = h
     h, residual = add_rms_forward(h, residual, lw.post_ln, eps)
+    if alias:
+        residual = h
     if lw.gate_w is not None and getattr(lw, "fp8", None) is not None:
         # N4: same router, experts evaluated on the dequantised fp8 weights (moe_fp8w)
         hh = h.reshape(-1, h.shape[-1])

@@ -283,7 +283,66 @@ def main():
                      f"{tag}.idx": idx, f"{tag}.w": w, f"{tag}.group": group}
             meta[tag] = dict(E=E, k=kk, H=Hh, T=Tt, rsf=rsf)
         _save("router_ties", tens, meta)
+
+        # ---------------- BASELINE config 1 (r04): ONE MoE decoder layer, 2 experts top-1, bs=1 seq=128 ----------------
+        # The reference's own smoke of this path is examples/decode_layer.py:7-55 (first-layer form, residual=None).
+        # Own generator and own file.  Three evaluations by the reference: (i) the 128-token prompt in the runner's
+        # bf16 regime, K/V written to block 1 of a paged cache; (ii) the decode step that follows it (token 129 attends
+        # the 128 cached rows + its own); (iii) the same prompt with the SAME weights in fp32 modules (the "CPU eager"
+        # evaluation BASELINE.json names; SURVEY.md 8c probe (i)).
+        _c1(gen=torch.Generator().manual_seed(1001), Glm4MoeDecoderLayer=Glm4MoeDecoderLayer,
+            set_context=set_context, reset_context=reset_context)
     print("done")
+
+
+def _c1(gen, Glm4MoeDecoderLayer, set_context, reset_context):
+    bf = torch.bfloat16
+    cfg = _cfg(n_routed_experts=2, num_experts_per_tok=1)
+    layer = Glm4MoeDecoderLayer(cfg, prefix="model.layers.1")
+    _init(layer, gen)
+    N = 128
+    h = torch.randn(N, 128, generator=gen).to(bf)
+    positions = torch.arange(N, dtype=torch.int64)
+    cu = torch.tensor([0, N], dtype=torch.int32)
+    kc = torch.zeros(2, 256, 2, 128)
+    vc = torch.zeros(2, 256, 2, 128)
+    slots = (256 * 1 + torch.arange(N)).to(torch.int32)
+    layer.self_attn.attn.k_cache, layer.self_attn.attn.v_cache = kc, vc
+    set_context(True, cu, cu, N, N, slots, None, None)
+    out, res = layer(positions, h.clone(), None)
+    reset_context()
+    k_rows, v_rows = kc.view(-1, 256)[slots.long()].clone(), vc.view(-1, 256)[slots.long()].clone()
+    # (ii) decode step over the cache the prompt has just filled
+    kc_in, vc_in = kc.clone(), vc.clone()
+    h1 = torch.randn(1, 128, generator=gen).to(bf)
+    r1 = torch.randn(1, 128, generator=gen).to(bf)
+    pos1 = torch.tensor([N], dtype=torch.int64)
+    ctx1 = torch.tensor([N + 1], dtype=torch.int32)
+    bt1 = torch.tensor([[1]], dtype=torch.int32)
+    slot1 = torch.tensor([256 + N], dtype=torch.int32)
+    set_context(False, slot_mapping=slot1, context_lens=ctx1, block_tables=bt1)
+    out_d, res_d = layer(pos1, h1.clone(), r1.clone())
+    reset_context()
+    # (iii) fp32 modules, same weight values
+    torch.set_default_dtype(torch.float32)
+    try:
+        layer32 = Glm4MoeDecoderLayer(cfg, prefix="model.layers.1")
+        layer32.load_state_dict(layer.state_dict())
+        layer32.mlp.gate.e_score_correction_bias.copy_(layer.mlp.gate.e_score_correction_bias)
+        assert layer32.self_attn.qkv_proj.weight.dtype == torch.float32
+        cu32 = cu.clone()
+        set_context(True, cu32, cu32, N, N, None, None, None)
+        out32, res32 = layer32(positions, h.float(), None)
+        reset_context()
+    finally:
+        torch.set_default_dtype(bf)
+    _save("layer_c1", _layer_tensors(layer, "layer.") | dict(
+        h=h, positions=positions, cu_seqlens=cu, slot_mapping=slots, out_first=out, res_first=res,
+        k_rows=k_rows, v_rows=v_rows, out_first_f32=out32, res_first_f32=res32,
+        d_h=h1, d_res_in=r1, d_positions=pos1, d_context_lens=ctx1, d_block_tables=bt1, d_slot_mapping=slot1,
+        d_k_cache_in=kc_in, d_v_cache_in=vc_in, d_out=out_d, d_res=res_d,
+        d_k_row=kc.view(-1, 256)[slot1.long()], d_v_row=vc.view(-1, 256)[slot1.long()],
+        cos_sin=layer.self_attn.rotary_emb.cos_sin_cache), vars(cfg) | dict(lens=[N]))
 
 
 if __name__ == "__main__":

@@ -39,7 +39,7 @@ def test_binding_table_matches_header(lib_path):
     from nanovllm import hip_ops
     assert sorted(hip_ops.EXPORTED_SYMBOLS) == declared_symbols()
     lib = hip_ops.load_library(lib_path)
-    assert lib.glm_abi_version() == 8
+    assert lib.glm_abi_version() == 9
 
 
 def test_host_only_entry_points(lib_path):
@@ -84,3 +84,19 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in src.replace("# oracle", ""), f"{f} mentions the oracle"
+
+
+def test_one_token_fusions_refuse_two_rows():
+    """The fused one-token launches (combine + norm + QKV; o_proj + norm + router tail) run the FMA GEMV body, the
+    stand-alone GEMM of two or more rows runs the small-M MFMA body: another fp32 summation order, so the bit-identity
+    tests can only hold where BOTH sides take the same body.  r03 (gpurun_out/r03_c, commit 2982577) had the fused launch
+    take T = 2 while glm_gemm_bf16 took the GEMV body for M == 1 only — `test_combine_norm_qkv_one_launch[2-...]` then
+    compared two different bodies and failed; the fix (a16f249) restricted the fused launch to one row.  Pinned here."""
+    from nanovllm import hip_ops
+    assert hip_ops.TINYM_MAX_ROWS == 1
+    y = torch.zeros(18, 64, dtype=torch.bfloat16)
+    pos = torch.zeros(16, dtype=torch.int32)
+    assert hip_ops.can_combine_norm_gemm(hip_ops.DeferredCombine(y, pos, 1, 8, 8, (1, 64)), 64)
+    assert not hip_ops.can_combine_norm_gemm(hip_ops.DeferredCombine(y, pos, 2, 8, 16, (2, 64)), 64)
+    assert hip_ops.can_gemm_router_tail(torch.zeros(1, 512, dtype=torch.bfloat16), 4096, 64)
+    assert not hip_ops.can_gemm_router_tail(torch.zeros(2, 512, dtype=torch.bfloat16), 4096, 64)

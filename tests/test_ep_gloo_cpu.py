@@ -69,6 +69,46 @@ def _worker(rank, world, port, q):
             gathered = [torch.empty_like(out) for _ in range(world)]
             dist.all_gather(gathered, out)
             assert all(torch.equal(gathered[0], t) for t in gathered)
+        # ---- tight capacity (r04): cap = f x mean rows per slot; a slot that does not fit is reported by the plan's overflow
+        # word (same value on every rank), the step is redone with exact splits — what ModelRunner.run does ----
+        os.environ["GLM_EP_FIXED"] = "1"
+        T, E, k, H, I, seed = 16, 8, 2, 64, 32, 11
+        x, w13, w2, gate_w, bias = _case(T, E, k, H, I, seed)
+        El = E // world
+        shared = lambda hh: O.mlp(hh, w13[E], w2[E])
+        mk = lambda: EP.EPExperts(ep_cpu_ops, world, rank, E, k, w13[rank * El:(rank + 1) * El], w2[rank * El:(rank + 1) * El], shared)
+        w_uni = torch.full((T, k), 0.5, dtype=torch.bfloat16)
+        # (a) balanced routing, factor 2: every token sends one row to each rank => 8 rows per slot, cap 16: no overflow
+        idx_bal = torch.tensor([[t % El, El + (t // 2) % El] for t in range(T)])
+        # (b) skewed routing: every pair goes to rank 0's experts => 16 rows per slot against cap 16 x 0.5 x ... = overflow
+        idx_skew = torch.tensor([[t % 2, 2 + t % 2] for t in range(T)])
+        try:
+            EP.EPExperts.set_capacity_factor(2.0)
+            ex = mk()
+            assert ex.capacity(T) == 16 and ex.capacity(T) < (T // world) * min(k, El) + 1
+            out = EP.run(ex.forward(x, idx_bal, w_uni))
+            assert EP.EPExperts.overflowed() == 0
+            ref = O.moe(x, None, None, k, 1.0, w13[:E], w2[:E], w13[E], w2[E], topk=(idx_bal, w_uni))
+            assert float((out.float() - ref.float()).abs().max()) <= 2 ** -6 * float(ref.float().abs().max())
+            EP.EPExperts.set_capacity_factor(1.0)  # cap 8 rows; the skewed routing puts 16 into the slots towards rank 0
+            ex = mk()
+            assert ex.capacity(T) == 8
+            bad = EP.run(ex.forward(x, idx_skew, w_uni))
+            worst = EP.EPExperts.overflowed()
+            assert worst == 16, worst                        # reported, identically on both ranks (asserted on both)
+            assert EP.EPExperts.overflowed() == 0            # reading it cleared it
+            ref = O.moe(x, None, None, k, 1.0, w13[:E], w2[:E], w13[E], w2[E], topk=(idx_skew, w_uni))
+            assert float((bad.float() - ref.float()).abs().max()) > 2 ** -6 * float(ref.float().abs().max()), \
+                "an overflowed step dropped rows: it cannot equal the oracle"
+            EP.EPExperts.force_varlen(True)                  # the redo
+            try:
+                assert not ex.takes_fixed(T)
+                out = EP.run(ex.forward(x, idx_skew, w_uni))
+            finally:
+                EP.EPExperts.force_varlen(False)
+            assert float((out.float() - ref.float()).abs().max()) <= 2 ** -6 * float(ref.float().abs().max())
+        finally:
+            EP.EPExperts.set_capacity_factor(None)
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))
@@ -139,3 +179,31 @@ def test_ep_plan_capacity_and_overflow():
         assert int(ro[-1]) == int((idx // El == r).sum())
     sg, sc, ps, ro, rg, ovf = ep_cpu_ops.ep_plan(idx, w, E, ep, 0, 1)
     assert int(ovf) > 1
+
+
+def test_ep_dispatch_form_by_step_size():
+    """Which dispatch form a step takes: decode-sized steps the fixed-capacity one, prefill-sized steps the
+    variable splits (at T = 16384, ep = 8 the fixed form would allocate five [131072, H] buffers and ship ep x the real
+    bytes); a step under HIP-graph capture always the fixed one — or an error when the plan cannot hold it."""
+    sys.path.insert(0, os.path.join(ROOT, "glm4_moe_nano-vllm_amd"))
+    import ep_cpu_ops
+    from nanovllm.distributed import expert_parallel as EP
+    ex = EP.EPExperts(ep_cpu_ops, 8, 0, 64, 8, None, None, None)
+    assert ex.takes_fixed(1) and ex.takes_fixed(256) and ex.takes_fixed(512)
+    assert not ex.takes_fixed(513) and not ex.takes_fixed(8192) and not ex.takes_fixed(16384)
+    assert ex.takes_fixed(16384, capturing=True)            # 2048 tokens per slice x 8 = 16384 pairs: the plan's limit
+    with pytest.raises(RuntimeError, match="cannot be captured"):
+        ex.takes_fixed(32768, capturing=True)
+    calls = []
+    ex.forward_fixed = lambda *a: calls.append("fixed") or (yield from ())
+    ex.forward_varlen = lambda *a: calls.append("varlen") or (yield from ())
+    for T in (32, 16384):
+        list(ex.forward(torch.zeros(T, 8), None, None))
+    assert calls == ["fixed", "varlen"]
+    # capacity: worst case by default, f x mean on request (B = 256, ep = 8, k = 8: 64 rows per slot instead of 256)
+    assert ex.capacity(256) == 256
+    EP.EPExperts.set_capacity_factor(2.0)
+    try:
+        assert ex.capacity(256) == 64 and ex.capacity(8) == 2 and ex.capacity(1) == 2 and ex.capacity(2048) == 512
+    finally:
+        EP.EPExperts.set_capacity_factor(None)

@@ -223,3 +223,71 @@ def test_model_final_norm_variants(tmp_path, without_residual):
     rows = torch.tensor([r for r in range(N) if set(got_idx[r].tolist()) == set(traces[1]["idx"][r].tolist())])
     assert N - len(rows) <= max(1, -(-5 * N // 100)), f"too many routing differences: {N - len(rows)}/{N}"
     _mixed(h, ref, f"final hidden (without_residual={without_residual})", rows)
+
+
+def test_decoder_layer_c1():
+    """BASELINE configs[0]: ONE MoE decoder layer, 2 experts top-1, bs=1 seq=128 (reference path
+    models/glm4_moe/decode_layer.py:79-100, smoke examples/decode_layer.py:7-55) through the product layer on the HIP
+    path: the 128-token prompt in the first-layer form (residual None, K/V written to the paged cache), then the decode
+    step of token 129 over the cache THIS run filled — both against the vectors minted from the reference, and the
+    three-distance report against the alias-free fp32 evaluation."""
+    from nanovllm.utils.context import reset_context, set_context
+    t, cfg = load_golden("layer_c1")
+    layer = build_product_layer(t, cfg, "model.layers.1")
+    captured = {}
+    _hook_router(layer, captured)
+    kc = torch.zeros(2, 256, 2, 128, dtype=torch.bfloat16, device="cuda")
+    vc = torch.zeros_like(kc)
+    layer.self_attn.attn.k_cache, layer.self_attn.attn.v_cache = kc, vc
+    cu = t["cu_seqlens"].cuda()
+    N = t["h"].shape[0]
+    set_context(True, cu, cu, N, N, t["slot_mapping"].cuda(), None, None)
+    with torch.inference_mode():
+        out, res = layer(t["positions"].cuda(), t["h"].cuda(), None)
+    reset_context()
+    torch.cuda.synchronize()
+    _mixed(res, t["res_first"], "c1 residual (input + attention output)")
+    meta = O.AttnMeta(True, slot_mapping=t["slot_mapping"], cu_seqlens_q=t["cu_seqlens"], cu_seqlens_k=t["cu_seqlens"])
+    kz = torch.zeros(2, 256, 2, 128, dtype=torch.bfloat16)
+    hr = _oracle_router_input(t, cfg, meta, kz, kz.clone(), None)
+    rows = _routing_rows(layer, t, cfg, captured, hr)
+    assert set(captured["idx"].flatten().tolist()) == {0, 1}
+    _mixed(out, t["out_first"], "c1 out", rows)
+    s = t["slot_mapping"].long()
+    _mixed(kc.cpu().view(-1, 256)[s], t["k_rows"], "c1 k cache rows")
+    assert_close_bf16(vc.cpu().view(-1, 256)[s], t["v_rows"], 1, 0.05, atol=2 ** -9, what="c1 v cache rows")
+    untouched = torch.ones(512, dtype=torch.bool)
+    untouched[s] = False
+    assert not bool(kc.cpu().view(-1, 256)[untouched].any()) and not bool(vc.cpu().view(-1, 256)[untouched].any())
+    # three distances on the rows routed like the reference (fp32 = the oracle's alias-free evaluation, same routing)
+    lw = layer_weights_from_golden(t, cfg)
+    m32 = O.AttnMeta(True, cu_seqlens_q=t["cu_seqlens"], cu_seqlens_k=t["cu_seqlens"])
+    tr = {}
+    O.decoder_layer(t["positions"], t["h"], None, lw, cfg, t["cos_sin"], None, None, m32, trace=tr)
+    x32, _ = O.decoder_layer(t["positions"], t["h"].float(), None, lw.to(torch.float32), cfg, t["cos_sin"], None, None,
+                             m32, force_idx=tr["idx"])
+    rms = lambda a, b: float((a.float()[rows] - b.float()[rows]).pow(2).mean().sqrt() / b.float()[rows].pow(2).mean().sqrt())
+    d_hip, d_ref = rms(out.cpu(), x32), rms(t["out_first"], x32)
+    assert d_hip <= 1.25 * d_ref + 1e-4, (d_hip, d_ref)
+    # decode step of token 129 over the cache this run has just filled
+    captured.clear()
+    set_context(False, slot_mapping=t["d_slot_mapping"].cuda(), context_lens=t["d_context_lens"].cuda(),
+                block_tables=t["d_block_tables"].cuda())
+    with torch.inference_mode():
+        out_d, res_d = layer(t["d_positions"].cuda(), t["d_h"].cuda(), t["d_res_in"].cuda())
+    reset_context()
+    torch.cuda.synchronize()
+    sd = t["d_slot_mapping"].long()
+    _mixed(kc.cpu().view(-1, 256)[sd], t["d_k_row"], "c1 decode k row")
+    assert_close_bf16(vc.cpu().view(-1, 256)[sd], t["d_v_row"], 1, 0.05, atol=2 ** -9, what="c1 decode v row")
+    _mixed(res_d, t["d_res"], "c1 decode residual")
+    trd = {}
+    O.decoder_layer(t["d_positions"], t["d_h"], t["d_res_in"], lw, cfg, t["cos_sin"], t["d_k_cache_in"].clone(),
+                    t["d_v_cache_in"].clone(), O.AttnMeta(False, slot_mapping=t["d_slot_mapping"],
+                                                          context_lens=t["d_context_lens"],
+                                                          block_tables=t["d_block_tables"]), trace=trd)
+    if set(captured["idx"].cpu()[0].tolist()) == set(trd["idx"][0].tolist()):
+        _mixed(out_d, t["d_out"], "c1 decode out")
+    else:  # a single row: it may only move when the reference's own top-1 margin is a near-tie
+        _, _, choice = O.router_scores(trd["h_router"], lw.gate_w, lw.gate_bias)
+        assert float(router_margin(choice, 1)[0]) <= 0.016

@@ -114,3 +114,45 @@ def test_layer_decode_moe():
 
 def test_layer_decode_qknorm():
     _decode("layer_moe_decode_qknorm")
+
+
+def test_layer_c1():
+    """BASELINE config 1: one MoE decoder layer, 2 experts top-1, bs=1 seq=128 (reference path
+    models/glm4_moe/decode_layer.py:79-100, its own smoke examples/decode_layer.py:7-55).  The oracle must equal the
+    reference bit for bit on the 128-token prompt (bf16 regime AND fp32 modules) and on the decode step behind it."""
+    t, cfg = load_golden("layer_c1")
+    assert cfg["n_routed_experts"] == 2 and cfg["num_experts_per_tok"] == 1 and t["h"].shape[0] == 128
+    lw = layer_weights_from_golden(t, cfg)
+    kc = torch.zeros(2, 256, 2, 128, dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    meta = O.AttnMeta(True, slot_mapping=t["slot_mapping"], cu_seqlens_q=t["cu_seqlens"], cu_seqlens_k=t["cu_seqlens"])
+    tr = {}
+    out, res = O.decoder_layer(t["positions"], t["h"], None, lw, cfg, t["cos_sin"], kc, vc, meta, trace=tr)
+    eq(out, t["out_first"], "c1 out")
+    eq(res, t["res_first"], "c1 residual")
+    s = t["slot_mapping"].long()
+    eq(kc.view(-1, 256)[s], t["k_rows"], "c1 k cache rows")
+    eq(vc.view(-1, 256)[s], t["v_rows"], "c1 v cache rows")
+    assert set(tr["idx"].flatten().tolist()) == {0, 1}, "the fixture must exercise both experts"
+    # decode step over the cache the prompt filled
+    eq(kc, t["d_k_cache_in"], "c1 cache after the prompt")
+    meta = O.AttnMeta(False, slot_mapping=t["d_slot_mapping"], context_lens=t["d_context_lens"],
+                      block_tables=t["d_block_tables"])
+    out, res = O.decoder_layer(t["d_positions"], t["d_h"], t["d_res_in"], lw, cfg, t["cos_sin"], kc, vc, meta)
+    eq(out, t["d_out"], "c1 decode out")
+    eq(res, t["d_res"], "c1 decode residual")
+    eq(kc.view(-1, 256)[t["d_slot_mapping"].long()], t["d_k_row"], "c1 decode k row")
+    eq(vc.view(-1, 256)[t["d_slot_mapping"].long()], t["d_v_row"], "c1 decode v row")
+    # fp32 modules on the same weight values (the "CPU eager" dtype of BASELINE configs[0]): every rounding point of the
+    # bf16 regime vanishes — and the reference's in-place norms alias the residual with the normalised row
+    # (layernorm.py:21-25,35-39; an artefact the oracle reproduces only on request, see decoder_layer)
+    meta = O.AttnMeta(True, cu_seqlens_q=t["cu_seqlens"], cu_seqlens_k=t["cu_seqlens"])
+    lw32 = lw.to(torch.float32)
+    out, res = O.decoder_layer(t["positions"], t["h"].float(), None, lw32, cfg, t["cos_sin"], None, None, meta,
+                               fp32_inplace_alias=True)
+    eq(out, t["out_first_f32"], "c1 out (fp32 modules, as executed)")
+    eq(res, t["res_first_f32"], "c1 residual (fp32 modules, as executed)")
+    # the alias-free fp32 evaluation is the one the bf16 result approximates; the aliased one is not
+    out_x, _ = O.decoder_layer(t["positions"], t["h"].float(), None, lw32, cfg, t["cos_sin"], None, None, meta)
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+    assert rel(t["out_first"], out_x) < 2e-2 and rel(t["out_first"], t["out_first_f32"]) > 0.1

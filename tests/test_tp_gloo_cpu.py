@@ -1,4 +1,4 @@
-"""Tensor-parallel sharding of the product's layers, world_size 2 over gloo on CPU.
+"""Tensor-parallel sharding of the product's layers, world_size 2 and 4 over gloo on CPU.
 
 The HIP kernels cannot run here, so each rank evaluates its shard with the ORACLE's linear/MLP
 math on the weights the product's weight_loader selected, and reduces through the product's TP
@@ -56,10 +56,17 @@ def _worker(rank, world, port, q):
         qkv = QKVParallelLinear(H, hd, nh, nkv, bias=False)
         for w, sid in ((wq, "q"), (wk, "k"), (wv, "v")):
             qkv.weight_loader(qkv.weight, w, sid)
-        assert qkv.weight.shape == ((nh + 2 * nkv) * hd // world, H)
-        nq, nk = nh // world, nkv // world
+        nq, nk = nh // world, max(1, nkv // world)
+        rep = max(1, world // nkv)            # ranks that share (replicate) one kv head when nkv < world
+        kv0 = (rank // rep) * nk              # first kv head this rank holds
+        assert qkv.weight.shape == ((nq + 2 * nk) * hd, H) and qkv.kv_replicas == rep
         assert torch.equal(qkv.weight[: nq * hd], wq[rank * nq * hd:(rank + 1) * nq * hd])
-        assert torch.equal(qkv.weight[nq * hd:(nq + nk) * hd], wk[rank * nk * hd:(rank + 1) * nk * hd])
+        assert torch.equal(qkv.weight[nq * hd:(nq + nk) * hd], wk[kv0 * hd:(kv0 + nk) * hd])
+        assert torch.equal(qkv.weight[(nq + nk) * hd:], wv[kv0 * hd:(kv0 + nk) * hd])
+        # GQA consistency under replication: the q heads of this rank belong to the kv head it holds
+        # (q head h uses kv head h // (nh // nkv); attention_new.py:21-34)
+        for h in range(rank * nq, (rank + 1) * nq):
+            assert kv0 <= h // (nh // nkv) < kv0 + nk, (h, kv0)
         o = RowParallelLinear(nh * hd, H, bias=False)
         o.weight_loader(o.weight, wo)
         assert torch.equal(o.weight, wo[:, rank * nq * hd:(rank + 1) * nq * hd])
@@ -95,11 +102,11 @@ def _worker(rank, world, port, q):
         assert torch.allclose(full.float(), ref.float(), rtol=3e-2, atol=3e-2 * float(ref.float().abs().max()))
 
         # --- vocab-parallel embedding (pure torch in the product: runs on CPU as is) ---
-        V = 50
+        V = 52
         emb_w = torch.randn(V, H, generator=g).to(torch.bfloat16)
         emb = VocabParallelEmbedding(V, H)
         emb.weight_loader(emb.weight, emb_w)
-        ids = torch.tensor([0, 24, 25, 49, 7])
+        ids = torch.tensor([0, 12, 13, 25, 26, 38, 39, 51, 7])
         assert torch.equal(emb(ids), emb_w[ids])
         # --- ParallelLMHead: vocab shard per rank, dist.gather to rank 0 (embed_head.py:64-67).  The projection itself
         # is a HIP kernel; the TEST stands the oracle's linear in for it so that the gather logic runs on CPU ---
@@ -161,9 +168,10 @@ def _worker(rank, world, port, q):
         q.put((rank, "FAIL: " + traceback.format_exc()))
 
 
-@pytest.mark.timeout(180)
-def test_tp2_sharding_over_gloo():
-    world = 2
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("world", [2, 4])
+def test_tp_sharding_over_gloo(world):
+    """world 4 with nkv = 2: every kv head is replicated on two consecutive ranks (r04)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
