@@ -16,6 +16,64 @@ void glm_set_error(const char* fmt, ...) {
 extern "C" int glm_abi_version(void) { return 9; }
 extern "C" const char* glm_last_error(void) { return g_err; }
 
+// ---- launch-path options: name, environment variable read once, default ------------------------------------------------
+namespace {
+struct OptDesc {
+    const char* name;
+    const char* env;
+    int dflt;
+};
+const OptDesc k_opts[GLM_OPT_COUNT] = {
+    {"tinym", "GLM4MOE_TINYM", 1},                 // 0: one token row keeps the small-M MFMA kernels (A/B, bit-identity tests)
+    {"fp8w_native", "GLM4MOE_FP8W_NATIVE", 1},     // 0: fp8 experts at prefill row counts take the expansion path
+    {"largem_variant", "GLM_LARGEM_VARIANT", -1},  // >= 0: loop variant bits of the tiled GEMM (0 = the plain loop)
+    {"largem_cfg", "GLM_LARGEM_CFG", 0},           // 0 = by shape, 1 = 128-row blocks (A), 2 = 256-row blocks (B)
+    {"fa_mfma32", "GLM_FA_MFMA32", -1},            // -1 = the build's default, 0 = 16x16x32 kernel, 1 = 32x32x16 kernel
+};
+int g_opt[GLM_OPT_COUNT];
+bool g_opt_init = false;
+void opts_init() {
+    if (g_opt_init) return;
+    for (int i = 0; i < GLM_OPT_COUNT; ++i) {
+        const char* e = getenv(k_opts[i].env);
+        int v = k_opts[i].dflt;
+        if (e && *e) {
+            if (i == GLM_OPT_LARGEM_CFG) v = (e[0] == 'A' || e[0] == 'a') ? 1 : (e[0] == 'B' || e[0] == 'b') ? 2 : atoi(e);
+            else v = atoi(e);
+        }
+        g_opt[i] = v;
+    }
+    g_opt_init = true;
+}
+int opt_index(const char* name) {
+    for (int i = 0; name && i < GLM_OPT_COUNT; ++i)
+        if (strcmp(name, k_opts[i].name) == 0) return i;
+    return -1;
+}
+}  // namespace
+
+int glm_option(int id) {
+    opts_init();
+    return g_opt[id];
+}
+
+extern "C" int glm_get_option(const char* name, int* value) {
+    const int i = opt_index(name);
+    GLM_CHECK_ARG(i >= 0 && value, GLM_ERR_INVALID, "glm_get_option: unknown option '%s'", name ? name : "(null)");
+    *value = glm_option(i);
+    return GLM_OK;
+}
+
+extern "C" int glm_set_option(const char* name, int value) {
+    const int i = opt_index(name);
+    GLM_CHECK_ARG(i >= 0, GLM_ERR_INVALID, "glm_set_option: unknown option '%s'", name ? name : "(null)");
+    opts_init();
+    g_opt[i] = value;
+    return GLM_OK;
+}
+
+extern "C" const char* glm_option_name(int index) { return index >= 0 && index < GLM_OPT_COUNT ? k_opts[index].name : nullptr; }
+
 namespace {
 // rows per group above which the MFMA-bound tiled kernel is used instead of weight streaming
 constexpr int64_t LARGEM_MIN_AVG_ROWS = 96;
@@ -26,10 +84,7 @@ constexpr int64_t LARGEM_MIN_AVG_ROWS = 96;
 // that is not a multiple of 64, offsets past 2^31) takes the r02 path when the caller brought scratch: the stack is
 // expanded (exactly) to bf16 by one streaming pass and the bf16 kernel runs on the copy, same accumulator scaling — the two
 // are bit-identical (test_fp8_weights_native_operand_equals_expansion).  GLM_ERR_UNSUPPORTED: neither applies.
-bool fp8w_native_enabled() {
-    const char* e = getenv("GLM4MOE_FP8W_NATIVE");  // 0: force the expansion path (A/B runs, the bit-identity test)
-    return !(e && e[0] == '0');
-}
+bool fp8w_native_enabled() { return glm_option(GLM_OPT_FP8W_NATIVE) != 0; }  // 0: force the expansion path
 
 int fp8w_large(int mode, GemmParams p, int rows, int cols, void* scratch, size_t scratch_bytes, hipStream_t st) {
     if (fp8w_native_enabled()) {
@@ -52,11 +107,8 @@ int fp8w_large(int mode, GemmParams p, int rows, int cols, void* scratch, size_t
     return glm_launch_gemm_largem(mode, p, st);  // p.wscale stays set
 }
 
-// GLM4MOE_TINYM=0 keeps the small-M kernels at one token row (A/B runs and the bit-identity tests of the fused launches)
-bool tinym_enabled() {
-    const char* e = getenv("GLM4MOE_TINYM");
-    return !(e && e[0] == '0');
-}
+// option tinym = 0 keeps the small-M kernels at one token row (A/B runs and the bit-identity tests of the fused launches)
+bool tinym_enabled() { return glm_option(GLM_OPT_TINYM) != 0; }
 
 int dispatch(int mode, const GemmParams& p, hipStream_t st) {
     if (p.R <= 0) return GLM_OK;

@@ -120,3 +120,11 @@ __device__ __forceinline__ void glm_locate_block(const int32_t* __restrict__ off
         if (base > target) break;  // uniform
     }
 }
+
+// ---- launch-path options (api.hip) -------------------------------------------------------------------------------------
+// Every switch a launch path consults lives in ONE table, filled from the environment ONCE (first use) and changed only
+// through glm_set_option: a launch never reads the environment, so a HIP graph and the eager launches around it cannot see
+// two different settings, and the effective set can be printed (bench.py puts it into its line's `config.options`).
+enum GlmOption { GLM_OPT_TINYM = 0, GLM_OPT_FP8W_NATIVE, GLM_OPT_LARGEM_VARIANT, GLM_OPT_LARGEM_CFG, GLM_OPT_FA_MFMA32, GLM_OPT_COUNT };
+int glm_option(int id);
+

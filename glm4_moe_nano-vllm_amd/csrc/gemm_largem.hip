@@ -1239,12 +1239,9 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
 
 int g_largem_variant = -1;  // < 0: the default for the shape
 
-// GLM_LARGEM_VARIANT=<bits> makes a variant the process default (A/B runs of whole test suites)
-// (read at every launch, so a test can switch between variant 0 and the product loop inside one process)
-int env_variant() {
-    const char* e = getenv("GLM_LARGEM_VARIANT");
-    return e && *e ? atoi(e) : -1;
-}
+// option largem_variant (environment GLM_LARGEM_VARIANT at start-up, glm_set_option afterwards) makes a variant the
+// process default; consulted at every launch, so a test can switch between variant 0 and the product loop inside one process
+int env_variant() { return glm_option(GLM_OPT_LARGEM_VARIANT); }
 
 template <int MODE, class C, int VAR>
 int launch_largem_cfg(const GemmParams& p, hipStream_t st) {
@@ -1280,15 +1277,8 @@ int launch_largem_cfg(const GemmParams& p, hipStream_t st) {
     return GLM_OK;
 }
 
-// GLM_LARGEM_CFG=A|B overrides the tile configuration (A/B measurements)
-int cfg_choice() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("GLM_LARGEM_CFG");
-        v = (e && (e[0] == 'A' || e[0] == 'a')) ? 1 : (e && (e[0] == 'B' || e[0] == 'b')) ? 2 : 0;
-    }
-    return v;
-}
+// option largem_cfg (GLM_LARGEM_CFG=A|B at start-up) overrides the tile configuration (A/B measurements)
+int cfg_choice() { return glm_option(GLM_OPT_LARGEM_CFG); }
 
 template <int MODE>
 int launch_largem(const GemmParams& p, hipStream_t st) {

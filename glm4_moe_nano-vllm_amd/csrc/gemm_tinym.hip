@@ -168,9 +168,23 @@ __device__ __forceinline__ void tinym_router_tail(const TinyParams& tp, char* sm
         tr_ok = ok;
     }
     __syncthreads();
-    if (!tr_ok) {  // cannot happen while the GPU makes progress; never hang, and never let stale data pass for a result
-        if (d == 0)
-            for (int i = threadIdx.x; i < (H >> 1); i += TM_NT) reinterpret_cast<unsigned*>(tp.tr_y)[i] = 0x7fc07fc0u;  // NaN
+    if (!tr_ok) {
+        // Cannot happen while the GPU makes progress.  Never hang, never let stale data pass for a result, and say so:
+        // the status word (ticket[2], sticky) is read by the host where it synchronises anyway (hip_ops.check_router_tail
+        // raises and re-zeroes the workspace: the two counters are left non-zero here, and workgroups that were late may
+        // still add to them — only the host, after a device synchronisation, can put them back).  Every output of the
+        // launch is poisoned: the normalised row and the routing weights with NaNs, the bucketing with "no rows".
+        if (tid == 0) __hip_atomic_store(tp.tr_ticket + 2, 1u + (unsigned)d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d == 0) {
+            for (int i = tid; i < (H >> 1); i += TM_NT) reinterpret_cast<unsigned*>(tp.tr_y)[i] = 0x7fc07fc0u;  // NaN
+            const int G = E + (tp.tr_shared ? 1 : 0);
+            for (int i = tid; i <= G; i += TM_NT) tp.tr_offs[i] = 0;
+            for (int i = tid; i < tp.tr_k; i += TM_NT) {
+                tp.tr_idx[i] = 0;
+                tp.tr_w[i] = (bf16_t)0x7fc0;
+                tp.tr_pos[i] = -1;
+            }
+        }
         return;
     }
     // the x rows are dead (every wave is past its last tile): xs / hand-over area / logits / bias live there
@@ -664,7 +678,8 @@ int glm_launch_gemm_tinym_combine_norm(const GemmParams& p, const void* y_prev, 
 
 // o_proj of ONE token row continued, in the last workgroup to finish, by the post-attention add-RMSNorm + router +
 // bucketing (glm_add_rmsnorm_router_topk_align at T = 1).  p: the projection (y = its bf16 output row, written
-// write-through and read back by the tail); ticket: two zeroed uint32 that the launch leaves zero; logits_scratch: E floats.
+// write-through and read back by the tail); ticket: two zeroed uint32 that the launch leaves zero + a third, sticky status
+// word (0, or 1 + the designated workgroup whose bounded wait expired); logits_scratch: E floats.
 int glm_launch_gemm_tinym_router_tail(const GemmParams& p, unsigned* ticket, float* logits_scratch, const void* residual_in, const void* norm_w,
                                       float eps, void* y_norm, void* residual_out, const void* gate_w, const float* bias, int E,
                                       int k, float rsf, int64_t* topk_idx, void* topk_w, int32_t* offs, int32_t* tok,

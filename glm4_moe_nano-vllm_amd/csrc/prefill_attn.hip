@@ -21,6 +21,7 @@
 // K/V come either from contiguous [Tk, nkv, hd] tensors or from the paged cache through
 // block_tables (prefix-cache hit, attention.py:86-87).
 #include "common.h"
+#include "gemm_internal.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -1050,11 +1051,11 @@ extern "C" int glm_varlen_attn_prefill(const void* q, const void* k, const void*
     // K/V ring + the block-table slice (paged only): two workgroups per CU need <= 80 KiB each
     const size_t lds = 2 * FA_STAGE + (paged ? (size_t)bt_stride * 4 : 0);
     const float sl2 = scale * 1.4426950408889634f;
-    // GLM_FA_MFMA32=1 (read at every call): the 32x32x16 kernel (same grid and workgroup shape as the default 16x16x32
+    // option fa_mfma32 = 1 (GLM_FA_MFMA32 at start-up, glm_set_option afterwards): the 32x32x16 kernel (same grid and workgroup shape as the default 16x16x32
     // kernel).  Parity green (test_varlen_attn_prefill_mfma32); measured r03, one box, interleaved processes: 746-754 against
     // 789-805 TFLOP/s at 4 x 4096 tokens, so it stays opt-in.
-    const char* e32 = getenv("GLM_FA_MFMA32");
-    const bool use32 = (e32 && e32[0] == '1') || (e32 == nullptr && FA_DEFAULT_MFMA32 == 1);
+    const int o32 = glm_option(GLM_OPT_FA_MFMA32);
+    const bool use32 = o32 == 1 || (o32 < 0 && FA_DEFAULT_MFMA32 == 1);
     if (use32 && FA_BQ == 128) {
         if (paged) {
             GLM_SET_MAX_LDS((prefill_attn32_kernel<true, 1>), 2 * FA_STAGE + FA_MAX_BT * 4, "glm_varlen_attn_prefill");

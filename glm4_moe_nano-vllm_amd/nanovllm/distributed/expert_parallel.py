@@ -34,7 +34,7 @@ Two dispatch forms, same arithmetic, same results:
     with static shapes.  cap = the worst case (rows per token slice x min(k, experts per rank), overflow impossible) or,
     when the caller opted in with `EPExperts.set_capacity_factor(f)`, f x the mean with the plan's `overflow` word
     sending an overflowing step to the variable-split form (see the class).
-  * VARIABLE SPLITS (`forward_varlen`: prefill-sized steps, the redo of an overflowed step, GLM_EP_FIXED=0): all-to-all-v
+  * VARIABLE SPLITS (`forward_varlen`: prefill-sized steps, the redo of an overflowed step, option ep_fixed = 0): all-to-all-v
     with exact row counts; the split sizes are host integers, so this form reads the count matrix once per MoE block and
     runs eagerly.
 """
@@ -115,6 +115,13 @@ class EPExperts:
         mean = per * self.k / self.ep
         return max(1, min(worst, int(-(-f * mean // 1))))
 
+    def _opt_ep_fixed(self) -> bool:
+        """Option "ep_fixed" of the real ops module (nanovllm.hip_ops, read once from GLM_EP_FIXED when the library is
+        loaded); the CPU tests' stand-in ops module carries its own `ep_fixed` attribute."""
+        if hasattr(self.ops, "opt"):
+            return self.ops.opt("ep_fixed") != 0
+        return bool(getattr(self.ops, "ep_fixed", True))
+
     def _capturing(self, h) -> bool:
         return bool(h.is_cuda and torch.cuda.is_current_stream_capturing())
 
@@ -126,7 +133,7 @@ class EPExperts:
             if not fits:
                 raise RuntimeError(f"expert-parallel step of {T} tokens cannot be captured (fixed-capacity plan limits)")
             return True
-        return (fits and os.environ.get("GLM_EP_FIXED", "1") != "0" and not type(self)._force_varlen
+        return (fits and self._opt_ep_fixed() and not type(self)._force_varlen
                 and T <= self.FIXED_MAX_TOKENS)
 
     def forward(self, h: torch.Tensor, topk_idx: torch.Tensor, topk_w: torch.Tensor):

@@ -169,4 +169,4 @@ class OneShotAllReduce:
 
 
 def enabled() -> bool:
-    return os.environ.get("GLM_ONESHOT_ALLREDUCE", "0") == "1"
+    return hip_ops.opt("oneshot_allreduce") == 1

@@ -22,6 +22,9 @@ _lib = None
 _SIGNATURES = {
     "glm_abi_version": (c_int, []),
     "glm_last_error": (c_char_p, []),
+    "glm_get_option": (c_int, [c_char_p, c_void_p]),
+    "glm_set_option": (c_int, [c_char_p, c_int]),
+    "glm_option_name": (c_char_p, [c_int]),
     "glm_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "glm_add_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                 c_float, c_void_p]),
@@ -141,7 +144,77 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
         fn.argtypes = args
     if path is None:
         _lib = lib
+        _read_host_options()
     return lib
+
+
+# ---- options -----------------------------------------------------------------------------------------------------------
+# Host-side switches of the launch paths (which fused launch a layer takes, which collective form): read from the
+# environment ONCE, when the library is loaded, like the library's own table (glm_get_option / glm_set_option).  A path never
+# consults os.environ afterwards; tests and A/B tools call set_option().  options() is the effective set of both sides
+# (bench.py prints it in its line's config).
+_HOST_OPTION_ENV = {  # name -> (environment variable, default)
+    "fuse_combine_qkv": ("GLM4MOE_FUSE_COMBINE_QKV", 1),    # one token: combine + input norm + QKV in one launch
+    "fuse_oproj_router": ("GLM4MOE_FUSE_OPROJ_ROUTER", 1),  # one token: o_proj + norm + router + bucketing in one launch
+    "defer_qkv_reduce": ("GLM4MOE_DEFER_QKV_REDUCE", 1),    # QKV as K-slice partial sums reduced by the attention's loads
+    "ep_fixed": ("GLM_EP_FIXED", 1),                        # expert parallelism: fixed-capacity dispatch at decode sizes
+    "oneshot_allreduce": ("GLM_ONESHOT_ALLREDUCE", 0),      # opt-in one-hop all-reduce over mapped peer buffers
+}
+_host_opts: dict = {}
+
+
+def _read_host_options() -> None:
+    for name, (env, dflt) in _HOST_OPTION_ENV.items():
+        v = os.environ.get(env)
+        _host_opts[name] = int(v) if v not in (None, "") else dflt
+
+
+def opt(name: str) -> int:
+    """Effective value of a launch-path option (host-side table or the library's)."""
+    if not _host_opts:
+        load_library()
+    if name in _host_opts:
+        return _host_opts[name]
+    v = c_int(0)
+    _check(load_library().glm_get_option(name.encode(), ctypes.byref(v)), "glm_get_option")
+    return v.value
+
+
+def set_option(name: str, value: int) -> int:
+    """Change an option for the launches that follow (NOT for HIP graphs captured earlier); returns the old value."""
+    old = opt(name)
+    if name in _host_opts:
+        _host_opts[name] = int(value)
+    else:
+        _check(load_library().glm_set_option(name.encode(), int(value)), "glm_set_option")
+    return old
+
+
+class option:
+    """`with hip_ops.option("tinym", 0): ...`"""
+
+    def __init__(self, name: str, value: int):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = set_option(self.name, self.value)
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
+
+
+def options() -> dict:
+    lib = load_library()
+    out, i = {}, 0
+    while True:
+        n = lib.glm_option_name(i)
+        if not n:
+            break
+        out[n.decode()] = opt(n.decode())
+        i += 1
+    out.update(_host_opts)
+    return out
 
 
 GLM_ERR_UNSUPPORTED = -2  # include/glm4moe_hip.h
@@ -585,7 +658,10 @@ def grouped_gemm_gateup_silu(x, w13, expert_offsets, sorted_token, R: int, max_r
     assert w13.stride(2) == 1  # rows may be padded (stride(1) >= H), groups strided
     act = torch.empty((R, I), dtype=x.dtype, device=x.device)
     if x.shape[0] <= TINYM_MAX_ROWS and max_rows_per_group is not None and max_rows_per_group <= x.shape[0]:
-        # single-sequence decode: the GEMV body (the caller vouches that no group holds more rows than there are tokens)
+        # single-sequence decode: the GEMV body (the caller vouches that no group holds more rows than there are tokens;
+        # the body computes ONE row per group and would silently drop further ones — at least the row count must allow it)
+        if R > G:
+            raise ValueError(f"grouped_gemm_gateup_silu: {R} rows over {G} groups cannot be one row per group")
         _check(load_library().glm_grouped_gemm_gateup_silu_fewtok(
             _p(x), x.stride(0), x.shape[0], _p(w13), w13.stride(0), w13.stride(1), _p(expert_offsets), _p(sorted_token),
             _p(act), R, H, I, G, _stream()), "glm_grouped_gemm_gateup_silu_fewtok")
@@ -607,6 +683,8 @@ def grouped_gemm_down(act, w2, expert_offsets, sorted_scale, n_scaled_groups: in
     assert w2.stride(2) == 1 and act.is_contiguous()
     y = torch.empty((R, H), dtype=act.dtype, device=act.device)
     if max_rows_per_group is not None and max_rows_per_group <= TINYM_MAX_ROWS:
+        if act.shape[0] > w2.shape[0] * max(1, max_rows_per_group):
+            raise ValueError(f"grouped_gemm_down: {act.shape[0]} rows over {w2.shape[0]} groups exceed {max_rows_per_group} per group")
         _check(load_library().glm_grouped_gemm_down_fewtok(_p(act), max_rows_per_group, _p(w2), w2.stride(0), w2.stride(1),
                                                            _p(expert_offsets), _p(sorted_scale), n_scaled_groups, _p(y), H,
                                                            R, H, I, G, _stream()), "glm_grouped_gemm_down_fewtok")
@@ -822,16 +900,31 @@ def combine_add_rmsnorm_gemm(dc: DeferredCombine, residual: torch.Tensor, norm_w
 
 def can_combine_norm_gemm(dc, H: int) -> bool:
     return (isinstance(dc, DeferredCombine) and dc.T <= TINYM_MAX_ROWS and H % 8 == 0 and H <= 4096
-            and os.environ.get("GLM4MOE_TINYM", "1") != "0" and os.environ.get("GLM4MOE_FUSE_COMBINE_QKV", "1") != "0")
+            and opt("tinym") != 0 and opt("fuse_combine_qkv") != 0)
 
 
 _tail_ws: dict = {}
 _tail_ws_retired: list = []
 
 
+def check_router_tail(device=None) -> None:
+    """Raise if a one-token o_proj + router-tail launch gave up its bounded wait since the last call (its outputs were
+    poisoned; word 2 of the tail workspace is the sticky status).  One 4-byte read: call it where the step is synchronised
+    anyway (ModelRunner.run).  The workspace is re-zeroed so that the next launch starts from clean counters."""
+    for key, ws in list(_tail_ws.items()):
+        if device is not None and torch.device(device).index not in (None, key[1]):
+            continue
+        st = int(ws[8:12].view(torch.int32).item())
+        if st:
+            torch.cuda.synchronize(torch.device(key[0], key[1]))
+            ws.zero_()
+            raise RuntimeError(f"one-token router tail: designated workgroup {st - 1} gave up waiting for the projection; "
+                               "the outputs of that step are NaN")
+
+
 def can_gemm_router_tail(x: torch.Tensor, H: int, E: int) -> bool:
     return (x.dim() == 2 and x.shape[0] == 1 and 2048 <= H <= 4096 and H % 8 == 0 and E <= 256 and x.is_contiguous()
-            and os.environ.get("GLM4MOE_TINYM", "1") != "0" and os.environ.get("GLM4MOE_FUSE_OPROJ_ROUTER", "1") != "0")
+            and opt("tinym") != 0 and opt("fuse_oproj_router") != 0)
 
 
 def gemm_add_rmsnorm_router_topk_align(x: torch.Tensor, w: torch.Tensor, residual: torch.Tensor, norm_weight: torch.Tensor,

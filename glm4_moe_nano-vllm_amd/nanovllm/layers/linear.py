@@ -142,8 +142,7 @@ class RowParallelLinear(LinearBase):
 
     @staticmethod
     def _partial_rows(m: int) -> bool:
-        import os
-        lo = 1 if os.environ.get("GLM4MOE_TINYM", "1") != "0" else 0  # one row: the GEMV body (glm_gemm_bf16 picks it)
+        lo = 1 if hip_ops.opt("tinym") != 0 else 0  # one row: the GEMV body (glm_gemm_bf16 picks it)
         return lo < m <= 32
 
     def forward(self, x: torch.Tensor, defer_reduce: bool = False):

@@ -6,8 +6,6 @@ paged decode / varlen prefill attention → o GEMM (+ RCCL all-reduce when tp > 
 reference's per-call debug file read (attention_new.py:288-292) is not reproduced."""
 from __future__ import annotations
 
-import os
-
 import torch
 import torch.nn as nn
 
@@ -61,7 +59,10 @@ class Glm4MoeAttention(nn.Module):
                               cache_config=None, quant_config=quant_config, prefix=f"{prefix}.attn")
 
     fuse_decode_attention = True
-    defer_qkv_reduce = os.environ.get("GLM4MOE_DEFER_QKV_REDUCE", "1") != "0"  # A/B switch
+
+    @property
+    def defer_qkv_reduce(self) -> bool:  # A/B switch (hip_ops option "defer_qkv_reduce")
+        return hip_ops.opt("defer_qkv_reduce") != 0
 
     def _fusable(self) -> bool:
         lph = self.head_dim // 8

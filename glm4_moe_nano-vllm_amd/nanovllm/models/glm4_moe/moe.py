@@ -88,8 +88,11 @@ class Glm4MoeMoE(nn.Module):
     def _stack(self, copy: bool) -> None:
         mlps = self._mlps()
         w13_0, w2_0 = mlps[0].gate_up_proj.weight, mlps[0].down_proj.weight
-        w13 = hip_ops.padded_weight(*w13_0.shape, len(mlps), dtype=w13_0.dtype, device=w13_0.device)
-        w2 = hip_ops.padded_weight(*w2_0.shape, len(mlps), dtype=w2_0.dtype, device=w2_0.device)
+        if w13_0.numel():  # (empty after the fp8 release: the shapes of the first stacking are kept for a reload)
+            self._shapes = (tuple(w13_0.shape), tuple(w2_0.shape))
+        s13, s2 = self._shapes
+        w13 = hip_ops.padded_weight(*s13, len(mlps), dtype=w13_0.dtype, device=w13_0.device)
+        w2 = hip_ops.padded_weight(*s2, len(mlps), dtype=w2_0.dtype, device=w2_0.device)
         for i, m in enumerate(mlps):
             if copy:
                 w13[i].copy_(m.gate_up_proj.weight.data)
@@ -108,9 +111,13 @@ class Glm4MoeMoE(nn.Module):
         return self._w13, self._w2
 
     def quantize_experts_fp8(self, free_bf16: bool | None = None) -> None:
-        """(Re)build the fp8 copies of the stacked expert weights from the current bf16 values.  Unless
+        """Build the fp8 copies of the stacked expert weights from the current bf16 values.  Unless
         `config.keep_bf16_experts` is set, the bf16 stacks are then RELEASED (the per-expert parameters become empty
-        tensors): fp8 experts are there to halve the expert memory, not to add 50 % to it."""
+        tensors): fp8 experts are there to halve the expert memory, not to add 50 % to it.  After the release a second
+        call has nothing to quantise from and is a no-op (the fp8 copies stay); `load_weights` re-allocates the stacks,
+        loads and quantises again."""
+        if self._bf16_freed and self._fp8 is not None:
+            return
         w13, w2 = self._stacked()
         w13_q, w13_s = hip_ops.quantize_fp8_rowwise(w13)
         w2_q, w2_s = hip_ops.quantize_fp8_rowwise(w2)
@@ -133,6 +140,9 @@ class Glm4MoeMoE(nn.Module):
         gb = load_one(path, f"{prefix}.gate.e_score_correction_bias")
         if gb is not None:
             self.gate.e_score_correction_bias.copy_(gb)
+        if self._bf16_freed:  # a reload after the fp8 release: fresh bf16 stacks, re-tied to the per-expert parameters
+            self._bf16_freed, self._fp8 = False, None
+            self._stack(copy=False)
         self._stacked()
         for expert, gid in zip(self.experts, self.expert_ids):
             expert.load_weights(path, f"{prefix}.experts.{gid}")

@@ -43,6 +43,17 @@ typedef void* glm_stream_t; /* hipStream_t */
 int         glm_abi_version(void);
 const char* glm_last_error(void);
 
+/* Launch-path options (host-only; r04).  Every switch a launch consults — which body a one-row GEMM takes, the loop
+ * variant of the tiled GEMM, the prefill-attention kernel ... — lives in one table that is filled from the environment
+ * ONCE (at the first use) and changed only through glm_set_option: a launch never reads the environment, so a HIP graph and
+ * the eager launches around it see one setting.  Names: "tinym" (GLM4MOE_TINYM), "fp8w_native" (GLM4MOE_FP8W_NATIVE),
+ * "largem_variant" (GLM_LARGEM_VARIANT), "largem_cfg" (GLM_LARGEM_CFG: 0 by shape, 1 = A, 2 = B), "fa_mfma32"
+ * (GLM_FA_MFMA32).  glm_option_name(i) enumerates them (NULL past the end).  The reference has no switches of its own on
+ * this path (its Config dataclass, config.py:6-26, holds engine sizes only).                                          */
+int         glm_get_option(const char* name, int* value);
+int         glm_set_option(const char* name, int value);
+const char* glm_option_name(int index);
+
 /* ---------------------------------------------------------------------------------------
  * a2  layers/layernorm.py:17-26  RMSNorm.rms_forward
  *     y = bf16( bf16(x32 * rsqrt(mean(x32^2) + eps)) * w )         x,y: [T,H] bf16, w: [H] bf16
@@ -195,8 +206,11 @@ int glm_grouped_gemm_down(const void* act, const void* w2,
  *     o_row: [H] bf16 scratch (the projection's output row).  ticket: 16 + 4 E bytes of scratch, 16-byte aligned; its first
  *     two uint32 are counters that must be ZERO before the first launch (the launch leaves them zero), E floats of logits
  *     follow at byte 16.  The tail runs in ceil(E / 16) designated workgroups that requested their 16 gate rows into LDS at
- *     kernel start and wait (bounded) for the projection's completion counter.
- *     GLM_ERR_UNSUPPORTED: H > 4096, H < 2048, E > 256, unaligned buffers.                                             */
+ *     kernel start and wait (bounded) for the projection's completion counter.  A wait that expires (it cannot while the
+ *     GPU makes progress) poisons every output (y_norm, topk_w: NaN; expert_offsets: no rows; pair_pos: -1) and stores
+ *     1 + the workgroup's number into the THIRD uint32 of `ticket` (sticky status; the host must then re-zero the scratch).
+ *     GLM_ERR_UNSUPPORTED (nothing enqueued): H > 4096, H < 2048, E > 256, K outside the window the tail's LDS scratch
+ *     fits (at H = 4096: 9472 <= K <= 14336), fewer than 2 ceil(E/16) row tiles, unaligned buffers.                  */
 int glm_gemm_bf16_router_tail(const void* x, const void* w, int64_t ldw, int K, int H, void* o_row, uint32_t* ticket,
                               const void* residual_in, const void* norm_weight, float eps, void* y_norm,
                               void* residual_out, const void* gate_w, const float* e_score_correction_bias, int E, int k,

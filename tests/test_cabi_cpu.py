@@ -55,17 +55,40 @@ def test_host_only_entry_points(lib_path):
     assert rc == -1 and b"bad shape" in lib.glm_last_error()
 
 
-def test_fp8_expansion_scratch_only_where_the_tiled_kernel_cannot_take_fp8(lib_path, monkeypatch):
+def test_fp8_expansion_scratch_only_where_the_tiled_kernel_cannot_take_fp8(lib_path):
     """At prefill row counts the tiled kernel takes the fp8 bytes as its weight operand when K is a multiple of its 64-wide K
-    tile: no scratch is asked for (Air dims: K = 4096 and 1408); other K, or GLM4MOE_FP8W_NATIVE=0, still size the bf16 copy."""
+    tile: no scratch is asked for (Air dims: K = 4096 and 1408); other K, or option fp8w_native = 0, still size the bf16 copy."""
     from nanovllm import hip_ops
-    lib = hip_ops.load_library(lib_path)
-    monkeypatch.delenv("GLM4MOE_FP8W_NATIVE", raising=False)
+    lib = hip_ops.load_library()
+    assert hip_ops.opt("fp8w_native") == 1
     assert lib.glm_fp8w_expand_scratch_bytes(65, 2816, 4096) == 0
     assert lib.glm_fp8w_expand_scratch_bytes(65, 4096, 1408) == 0
     assert lib.glm_fp8w_expand_scratch_bytes(3, 512, 352) >= 3 * 512 * 352 * 2
-    monkeypatch.setenv("GLM4MOE_FP8W_NATIVE", "0")
-    assert lib.glm_fp8w_expand_scratch_bytes(65, 2816, 4096) >= 65 * 2816 * 4096 * 2
+    with hip_ops.option("fp8w_native", 0):
+        assert lib.glm_fp8w_expand_scratch_bytes(65, 2816, 4096) >= 65 * 2816 * 4096 * 2
+    assert lib.glm_fp8w_expand_scratch_bytes(65, 2816, 4096) == 0
+
+
+def test_options_are_read_once_and_listed(lib_path):
+    """Launch-path switches: one table per side, filled from the environment once, changed only through set_option; a
+    later change of the environment is NOT seen (a HIP graph and the eager launches around it cannot disagree)."""
+    import os
+    from nanovllm import hip_ops
+    o = hip_ops.options()
+    assert set(o) == {"tinym", "fp8w_native", "largem_variant", "largem_cfg", "fa_mfma32", "fuse_combine_qkv",
+                      "fuse_oproj_router", "defer_qkv_reduce", "ep_fixed", "oneshot_allreduce"}
+    assert o["tinym"] == 1 and o["largem_variant"] == -1 and o["oneshot_allreduce"] == 0
+    os.environ["GLM4MOE_TINYM"] = "0"
+    os.environ["GLM4MOE_FUSE_COMBINE_QKV"] = "0"
+    try:
+        assert hip_ops.opt("tinym") == 1 and hip_ops.opt("fuse_combine_qkv") == 1
+    finally:
+        del os.environ["GLM4MOE_TINYM"], os.environ["GLM4MOE_FUSE_COMBINE_QKV"]
+    with hip_ops.option("tinym", 0):
+        assert hip_ops.options()["tinym"] == 0
+    assert hip_ops.opt("tinym") == 1
+    with pytest.raises(RuntimeError, match="unknown option"):
+        hip_ops.opt("no_such_option")
 
 
 def test_no_cpu_fallback():

@@ -12,8 +12,9 @@ noise" of it.  Two tests:
     oracle's (that layer must then be a near-tie of the oracle's routing).
   * test_air_dims_generate_greedy_8_steps — `nanovllm.LLM.generate()` (llm_engine.py:59-93) on an Air-dims checkpoint
     (L=3), prefill + 8 greedy decode steps in HIP-graph mode, against the oracle teacher-forced with the product's own
-    tokens over a CPU paged KV cache: every generated token must be the oracle's arg-max, or lie within bf16 logit noise
-    of it."""
+    tokens over a CPU paged KV cache: every generated token must be the oracle's arg-max, or lie within the measured
+    bf16 logit noise of it (6 sigma, sigma = rms distance of the oracle's bf16 logits from the fp32 evaluation of the same
+    step), and at most 2 of the 16 may differ at all."""
 import os
 
 import pytest
@@ -192,32 +193,45 @@ def test_air_dims_generate_greedy_8_steps(tmp_path):
     nkv, hd = cfg["num_key_value_heads"], cfg["head_dim"]
     embed, normw, headw = t["model.embed_tokens.weight"], t["model.norm.weight"], t["lm_head.weight"]
     agree = total = 0
-    worst = 0.0
+    worst, worst_sigma = 0.0, 0.0
+    layers32 = [l.to(torch.float32) for l in layers]
+    e32, n32, h32w = embed.float(), normw.float(), headw.float()
+
+    def both(ids, pos, kvs, kvs32, meta, last):
+        """The oracle's bf16 logits and the rounding-free fp32 logits of the same step (own fp32 K/V cache)."""
+        h = O.model_forward(ids, pos, embed, layers, normw, cfg, cs, kvs, meta)
+        hf = O.model_forward(ids, pos, e32, layers32, n32, cfg, cs, kvs32, meta)
+        return O.linear(h[last:], headw)[0].float(), O.linear(hf[last:], h32w)[0]
+
     for prompt, toks in zip(prompts, got):
         assert len(toks) == steps
         kvs = [(torch.zeros(1, 256, nkv, hd, dtype=BF), torch.zeros(1, 256, nkv, hd, dtype=BF)) for _ in range(L)]
+        kvs32 = [(torch.zeros(1, 256, nkv, hd), torch.zeros(1, 256, nkv, hd)) for _ in range(L)]
         n = len(prompt)
         cu = torch.tensor([0, n], dtype=torch.int32)
         meta = O.AttnMeta(True, slot_mapping=torch.arange(n, dtype=torch.int32), cu_seqlens_q=cu, cu_seqlens_k=cu)
-        h = O.model_forward(torch.tensor(prompt), torch.arange(n), embed, layers, normw, cfg, cs, kvs, meta)
-        logits = O.linear(h[-1:], headw)[0].float()
+        logits, l32 = both(torch.tensor(prompt), torch.arange(n), kvs, kvs32, meta, -1)
         for s, tok in enumerate(toks):
             top = int(logits.argmax())
             total += 1
             if top == tok:
                 agree += 1
             else:
+                # The product picked `tok`, the oracle `top`.  Each side's logits are the exact ones plus that side's bf16
+                # noise; sigma = rms(oracle bf16 - fp32 logits) of THIS step measures it (the HIP path's equals the
+                # oracle's: test_c3_model_logits_L8).  The oracle's gap between the two tokens is then the difference of
+                # four such errors (std 2 sigma) at most: 6 sigma is three standard deviations of it.
                 gap = float(logits[top] - logits[tok])
-                worst = max(worst, gap)
-                assert gap < 0.06, f"step {s}: token {tok} vs oracle {top}, oracle logit gap {gap:.3f}"
+                sigma = float((logits - l32).pow(2).mean().sqrt())
+                worst, worst_sigma = max(worst, gap), max(worst_sigma, gap / sigma)
+                assert gap <= 6 * sigma, f"step {s}: token {tok} vs oracle {top}, oracle logit gap {gap:.3f} = {gap / sigma:.1f} sigma"
             if s + 1 == len(toks):
                 break
             p = n + s  # position of the token just generated
             meta = O.AttnMeta(False, slot_mapping=torch.tensor([p], dtype=torch.int32),
                               context_lens=torch.tensor([p + 1], dtype=torch.int32),
                               block_tables=torch.tensor([[0]], dtype=torch.int32))
-            h = O.model_forward(torch.tensor([tok]), torch.tensor([p]), embed, layers, normw, cfg, cs, kvs, meta)
-            logits = O.linear(h, headw)[0].float()
+            logits, l32 = both(torch.tensor([tok]), torch.tensor([p]), kvs, kvs32, meta, 0)
     F.report("C3dims.generate_greedy_L3", prompts=[len(p) for p in prompts], steps=steps, tokens_compared=total,
-             tokens_equal_to_oracle_argmax=agree, worst_gap_where_different=worst)
+             tokens_equal_to_oracle_argmax=agree, worst_gap_where_different=worst, worst_gap_in_sigma=worst_sigma)
     assert agree >= total - 2, f"{agree}/{total} greedy tokens equal the oracle's"

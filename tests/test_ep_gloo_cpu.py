@@ -48,7 +48,7 @@ def _worker(rank, world, port, q):
         cases = ((9, 4, 2, 64, 48, 0), (1, 8, 2, 32, 16, 1), (16, 8, 8, 64, 32, 2), (5, 2, 1, 32, 16, 3))
         # both dispatch forms: fixed-capacity slots (the default) and variable splits
         for fixed, (T, E, k, H, I, seed) in [(f, c) for f in ("1", "0") for c in cases]:
-            os.environ["GLM_EP_FIXED"] = fixed
+            ep_cpu_ops.ep_fixed = fixed == "1"
             x, w13, w2, gate_w, bias = _case(T, E, k, H, I, seed)
             idx, w = O.router(x, gate_w, bias, k, 1.0)
             idx = torch.sort(idx, dim=1)[0]  # the product's router returns ascending ids; weights re-gathered to match
@@ -71,7 +71,7 @@ def _worker(rank, world, port, q):
             assert all(torch.equal(gathered[0], t) for t in gathered)
         # ---- tight capacity (r04): cap = f x mean rows per slot; a slot that does not fit is reported by the plan's overflow
         # word (same value on every rank), the step is redone with exact splits — what ModelRunner.run does ----
-        os.environ["GLM_EP_FIXED"] = "1"
+        ep_cpu_ops.ep_fixed = True
         T, E, k, H, I, seed = 16, 8, 2, 64, 32, 11
         x, w13, w2, gate_w, bias = _case(T, E, k, H, I, seed)
         El = E // world

@@ -35,17 +35,24 @@ import os
 
 @contextlib.contextmanager
 def largem_variant(v: int):
-    """Loop variant of the large-M GEMM for the launches inside the block (GLM_LARGEM_VARIANT is read at every launch;
-    0 = the plain loop every other variant must equal bit for bit)."""
-    old = os.environ.get("GLM_LARGEM_VARIANT")
-    os.environ["GLM_LARGEM_VARIANT"] = str(v)
-    try:
+    """Loop variant of the large-M GEMM for the launches inside the block (library option "largem_variant", consulted at
+    every launch; 0 = the plain loop every other variant must equal bit for bit)."""
+    from nanovllm import hip_ops
+    with hip_ops.option("largem_variant", v):
         yield
-    finally:
-        if old is None:
-            del os.environ["GLM_LARGEM_VARIANT"]
-        else:
-            os.environ["GLM_LARGEM_VARIANT"] = old
+
+
+@pytest.fixture
+def opt_guard():
+    """set_option for the rest of a test, restored afterwards: `opt_guard("tinym", 0)`."""
+    from nanovllm import hip_ops
+    saved = []
+
+    def set_(name, value):
+        saved.append((name, hip_ops.set_option(name, value)))
+    yield set_
+    for name, old in reversed(saved):
+        hip_ops.set_option(name, old)
 
 
 def rnd(*shape, seed=0, scale=1.0, dtype=BF):
@@ -583,7 +590,7 @@ def test_gemm_bf16_small_m(ops, M, N, K, bias):
 @pytest.mark.parametrize("M,N,K,bias", [
     (1, 14336, 4096, True), (2, 14336, 4096, True), (1, 4096, 12288, False), (2, 4096, 12288, False),
     (1, 4096, 1408, False), (2, 64, 136, True), (1, 151552 // 4, 4096, False), (2, 2052, 2056, True), (1, 8, 8, False)])
-def test_gemm_tinym_dense(ops, monkeypatch, M, N, K, bias):
+def test_gemm_tinym_dense(ops, opt_guard, M, N, K, bias):
     """glm_gemm_bf16 at M <= 2 runs the GEMV body: vs the oracle (<= 1 bf16 ulp: fp32 summation order) and vs the small-M
     MFMA kernel the same call takes with GLM4MOE_TINYM=0 (two fp32 evaluations of the same sum: <= 1 ulp apart)."""
     x = rnd(M, K, seed=271)
@@ -592,13 +599,13 @@ def test_gemm_tinym_dense(ops, monkeypatch, M, N, K, bias):
     ref = O.linear(x, w, b)
     out = ops.gemm_bf16(dev(x), dev(w), dev(b))
     assert_close_bf16(out, ref, 1, 0.05, atol=2 ** -9, what=f"tinym gemm {M}x{N}x{K}")
-    monkeypatch.setenv("GLM4MOE_TINYM", "0")
+    opt_guard("tinym", 0)
     old = ops.gemm_bf16(dev(x), dev(w), dev(b))
     assert_close_bf16(out, old, 1, 0.05, atol=2 ** -9, what=f"tinym vs small-M {M}x{N}x{K}")
 
 
 @pytest.mark.parametrize("T,E,k,H,I", [(1, 64, 8, 4096, 1408), (2, 64, 8, 4096, 1408), (2, 8, 2, 256, 96), (1, 128, 8, 512, 176)])
-def test_grouped_gemms_tinym(ops, monkeypatch, T, E, k, H, I):
+def test_grouped_gemms_tinym(ops, opt_guard, T, E, k, H, I):
     """Grouped gate|up + SiLU.mul and down at T <= 2 (the few-token entry points): every row against the oracle's expert
     arithmetic, and against the small-M kernels of the same call with GLM4MOE_TINYM=0."""
     x = rnd(T, H, seed=281)
@@ -612,7 +619,7 @@ def test_grouped_gemms_tinym(ops, monkeypatch, T, E, k, H, I):
     w13d, w2d = dev(w13), dev(w2)
     act = ops.grouped_gemm_gateup_silu(dev(x), w13d, offs, tok, R, max_rows_per_group=T)
     y = ops.grouped_gemm_down(act, w2d, offs, scale, E, max_rows_per_group=T)
-    monkeypatch.setenv("GLM4MOE_TINYM", "0")
+    opt_guard("tinym", 0)
     act0 = ops.grouped_gemm_gateup_silu(dev(x), w13d, offs, tok, R, max_rows_per_group=T)
     y0 = ops.grouped_gemm_down(act, w2d, offs, scale, E, max_rows_per_group=T)   # same input rows as the GEMV body's
     torch.cuda.synchronize()
@@ -911,7 +918,7 @@ def test_varlen_attn_prefill(ops, lens_q, lens_k, nh, nkv, paged):
 @pytest.mark.parametrize("lens_q,lens_k,nh,nkv,paged", [
     ([300, 17, 513, 64], [300, 17, 513, 64], 16, 4, False), ([100, 50], [612, 306], 16, 4, True),
     ([1025], [1025], 12, 1, False), ([5, 40], [300, 296], 4, 2, True), ([33], [33], 8, 2, False)])
-def test_varlen_attn_prefill_mfma32(ops, monkeypatch, lens_q, lens_k, nh, nkv, paged):
+def test_varlen_attn_prefill_mfma32(ops, opt_guard, lens_q, lens_k, nh, nkv, paged):
     """The opt-in 32x32x16 kernel (GLM_FA_MFMA32=1, read at every call) against the oracle on the varlen cases, and against
     the default kernel's output (two bf16 evaluations of the same attention: same tolerance)."""
     g = torch.Generator().manual_seed(sum(lens_k) + nh)
@@ -930,7 +937,7 @@ def test_varlen_attn_prefill_mfma32(ops, monkeypatch, lens_q, lens_k, nh, nkv, p
         ref = O.attn_prefill_varlen(q, k, v, cu_q, cu_k, scale)
         run = lambda: ops.varlen_attn_prefill(dev(q), dev(k), dev(v), dev(cu_q), dev(cu_k), max(lens_q), scale)
     base = run()
-    monkeypatch.setenv("GLM_FA_MFMA32", "1")
+    opt_guard("fa_mfma32", 1)
     out = run()
     assert torch.isfinite(out.float()).all()
     assert_mixed(out, ref, 1.6e-2, 4e-3, f"prefill attn (32x32x16) q={lens_q} k={lens_k}")
@@ -1015,7 +1022,7 @@ def test_moe_block_fp8_weights(ops, T, E, k, H, I):
                                        (300, 8, 2, 512, 192),     # ~100 rows per group: 128-row blocks, plain loop
                                        (2100, 6, 3, 1024, 1408),  # Air's I (22 K tiles of the down projection), ragged groups
                                        (700, 5, 1, 4096, 64)])    # one expert never chosen (an empty group)
-def test_fp8_weights_native_operand_equals_expansion(ops, T, E, k, H, I, monkeypatch):
+def test_fp8_weights_native_operand_equals_expansion(ops, T, E, k, H, I, opt_guard):
     """Many rows per group: the tiled kernel fed with the fp8 bytes (DMA-staged as fp8, converted between the fragment read
     and the MFMA) == the exact fp8 -> bf16 expansion pass followed by the bf16 kernel, bit for bit, both projections."""
     x = rnd(T, H, seed=121)
@@ -1028,10 +1035,10 @@ def test_fp8_weights_native_operand_equals_expansion(ops, T, E, k, H, I, monkeyp
     q2, s2 = ops.quantize_fp8_rowwise(dev(w2))
     offs, tok, scale, pos = ops.moe_align(dev(idx), dev(w), E, True)
     R = T * k + T
-    monkeypatch.setenv("GLM4MOE_FP8W_NATIVE", "0")
+    opt_guard("fp8w_native", 0)
     a0 = ops.grouped_gemm_gateup_silu_fp8w(dev(x), q13, s13, offs, tok, R)
     y0 = ops.grouped_gemm_down_fp8w(a0, q2, s2, offs, scale, E)
-    monkeypatch.setenv("GLM4MOE_FP8W_NATIVE", "1")
+    opt_guard("fp8w_native", 1)
     a1 = ops.grouped_gemm_gateup_silu_fp8w(dev(x), q13, s13, offs, tok, R)
     y1 = ops.grouped_gemm_down_fp8w(a0, q2, s2, offs, scale, E)
     assert torch.equal(a0, a1), "gate|up: native fp8 operand differs from the expansion path"
