@@ -26,7 +26,7 @@
 #include <stdlib.h>
 
 // timing-only ablations (results are wrong): 1 no exp, 2 no barrier, 4 no S MFMA, 8 no PV MFMA, 16 no LDS reads,
-// 32 no K/V staging after the first two tiles
+// 32 no K/V staging after the first two tiles, 64 every unit live and unmasked (no liveness / mask predicates)
 #ifndef GLM_FA_ABLATE
 #define GLM_FA_ABLATE 0
 #endif
@@ -49,6 +49,27 @@
 #endif
 #ifndef GLM_FA_STAMP
 #define GLM_FA_STAMP 0
+#endif
+// r04: 1 = a separate loop for the INTERIOR tiles of a wave — tiles every one of its rows sees in full — that carries no
+// liveness or mask predicate, followed by the general loop for the diagonal / last tiles; the staging sources advance as
+// running pointers.  (A form unrolled over the two LDS buffers as well, buffer select as an immediate of every LDS access,
+// made hipcc spill 520 registers.)  The r02 loop evaluated ~10 scalar predicates per
+// tile and rebuilt the 64-bit source address per staging slot: ~290 scalar instructions per tile and wave next to 68 MFMAs,
+// and a wave issues one instruction per ~4 cycles whatever its kind.  0 = the r02 loop (kept for A/B).
+#ifndef GLM_FA_LOOP
+#define GLM_FA_LOOP 1
+#endif
+// r04: 1 = Q pre-scaled by scale*log2(e) and the S accumulators INITIALISED with minus the softmax reference point, so
+// that the MFMA chain delivers S' = c*s - m and the fast path is p = exp2(S') with no per-element FMA (8 of a unit's ~30
+// vector instructions) and a constant threshold; 0 = the r02/r03 arithmetic (fp32 scale after the dot product)
+#ifndef GLM_FA_CINIT
+#define GLM_FA_CINIT 0   // measured r04 (profiles/r04/prefill_attn_ab.txt): 913-918 vs 905-908 TFLOP/s (+0.7 %), and one element
+                         // in 10^4-10^6 leaves the parity tolerance (the second rounding of q) => off
+#endif
+// TIMING STUDY ONLY (results unchecked against overflow): with GLM_FA_CINIT, skip the lazy-maximum test once a query tile
+// has a reference point — what an optimistic loop with an overflow check at the end of the workgroup would execute
+#ifndef GLM_FA_NOCHECK
+#define GLM_FA_NOCHECK 0
 #endif
 #ifndef GLM_FA_DEFAULT_MFMA32
 #define GLM_FA_DEFAULT_MFMA32 0  // kernel when GLM_FA_MFMA32 is unset: 0 = 16x16x32 (r02), 1 = 32x32x16
@@ -173,6 +194,12 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
         for (int ks = 0; ks < 4; ++ks) {
             u32x4_t t = {0, 0, 0, 0};
             if (ok) t = *reinterpret_cast<const u32x4_t*>(qrow + 32 * ks + 8 * g);
+#if GLM_FA_CINIT
+            // q' = bf16(q * scale * log2 e): one more bf16 rounding of the query (relative 2^-9 per element, ~1e-3 of a
+            // score's own standard deviation after the 128-term dot product), once per workgroup
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = pack2bf(bflo(t[i]) * scale_log2e, bfhi(t[i]) * scale_log2e);
+#endif
             qf[qt][ks] = __builtin_bit_cast(bf16x8_t, t);
         }
     }
@@ -252,6 +279,11 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
 
     f32x4_t acc[FA_QT][8], acc_l[FA_QT];
     float m_run[FA_QT], m_thr[FA_QT];  // softmax reference point (log2 domain) and m_run + 8
+#if GLM_FA_CINIT
+    // minus the reference point the S accumulators of tile qt start from (0 while the row has seen nothing); m_thr is then
+    // the threshold on S' itself: 8 once a reference point exists, -inf before (the first unit takes the exact path)
+    f32x4_t cinit[FA_QT];
+#endif
     int jmax[FA_QT];  // last visible key of this lane's query row, per tile
 #pragma unroll
     for (int qt = 0; qt < FA_QT; ++qt) {
@@ -260,6 +292,9 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
         acc_l[qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         m_run[qt] = -INFINITY;
         m_thr[qt] = -INFINITY;
+#if GLM_FA_CINIT
+        cinit[qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#endif
         jmax[qt] = qi[qt] + off;
     }
 
@@ -298,7 +333,11 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
 #endif
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
+#if GLM_FA_CINIT
+            s[tt] = cinit[qt];
+#else
             s[tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#endif
             if (GLM_FA_ABLATE & 4) {
                 s[tt] = __builtin_bit_cast(f32x4_t, kf[tt][0]) + __builtin_bit_cast(f32x4_t, kf[tt][1]) +
                         __builtin_bit_cast(f32x4_t, kf[tt][2]) + __builtin_bit_cast(f32x4_t, kf[tt][3]);
@@ -315,11 +354,12 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
     };
     // online softmax of one unit (keys [kbase, kbase+32) x query tile qt); returns the bf16 P^T fragment and
     // leaves acc[qt] rescaled.  The running maximum lives in the scaled (log2) domain: p = exp2(s*c - m).
-    auto softmax = [&](f32x4_t (&s)[2], int kbase, int qt) -> bf16x8_t {
+    auto softmax = [&](f32x4_t (&s)[2], int kbase, int qt, auto interior_c) -> bf16x8_t {
         // masking is only needed on slabs that touch the causal diagonal or the sequence end for this
-        // query tile: the test is wave-uniform and false for almost every slab
+        // query tile: the test is wave-uniform and false for almost every slab (and known false on an interior tile)
         const int row_first = qbase + (16 * FA_QT) * wid + 16 * qt;
-        const bool need_mask = kbase + 31 > row_first + off || kbase + 31 >= lk;
+        const bool need_mask = ((GLM_FA_ABLATE & 64) || decltype(interior_c)::value)
+                                   ? false : (kbase + 31 > row_first + off || kbase + 31 >= lk);
         if (need_mask) {
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
@@ -342,6 +382,65 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
             : "=&v"(mloc)
             : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][3]), "v"(s[1][0]), "v"(s[1][1]), "v"(s[1][2]),
               "v"(s[1][3]));
+#if GLM_FA_CINIT
+        // S' = c*s - m_cur, m_cur = the reference point the accumulators started from (m_run, or 0 before the first unit)
+        float ms = mloc;
+        float shift = 0.f;
+#if GLM_FA_NOCHECK
+        // a query tile's first unit (keys 0..31) is either unmasked — it then sets the reference point of all 16 rows — or
+        // on the causal diagonal, and then every later unit of the tile is masked or dead as well
+        const bool slow = need_mask || kbase == 0;
+#else
+        const bool slow = need_mask || !GLM_FA_LAZYMAX || !__all(ms <= m_thr[qt]);
+#endif
+        if (slow) {
+            float mtmp;
+            asm("v_mov_b32 %1, %0\n\t"
+                "s_nop 1\n\t"
+                "v_permlane16_swap_b32 %0, %1\n\t"
+                "v_max_f32 %0, %0, %1\n\t"
+                "v_mov_b32 %1, %0\n\t"
+                "s_nop 1\n\t"
+                "v_permlane32_swap_b32 %0, %1\n\t"
+                "v_max_f32 %0, %0, %1"
+                : "+v"(ms), "=&v"(mtmp));
+            const float m_cur = m_run[qt] == -INFINITY ? 0.f : m_run[qt];
+            const float cand = m_cur + ms;                                  // this unit's row maximum, absolute (log2) domain
+            const float m_new = cand > m_run[qt] ? cand : m_run[qt];
+            // a row with nothing visible yet keeps m_new = -inf (only possible on a masked slab): 0 is its reference point,
+            // exp2(-inf - 0) = 0 and no NaN appears
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;
+            shift = m_use - m_cur;
+            if (__any(m_new > m_run[qt])) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_use);  // 0 for a row that had seen nothing (acc = 0)
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) acc[qt][dt] *= alpha;
+                acc_l[qt] *= alpha;
+            }
+            m_run[qt] = m_new;
+            m_thr[qt] = m_new == -INFINITY ? -INFINITY : 8.0f;
+            const float cneg = -m_use;
+            cinit[qt] = f32x4_t{cneg, cneg, cneg, cneg};
+            bf16x8_t pfs;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float arg = s[tt][r] - shift;
+                    const float pv = (GLM_FA_ABLATE & 1) ? arg : __builtin_amdgcn_exp2f(arg);
+                    pfs[4 * tt + r] = (__bf16)pv;
+                }
+            return pfs;
+        }
+        bf16x8_t pf;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = (GLM_FA_ABLATE & 1) ? s[tt][r] : __builtin_amdgcn_exp2f(s[tt][r]);
+                pf[4 * tt + r] = (__bf16)pv;
+            }
+#else
         float ms = mloc * scale_log2e;
         float m_use = m_run[qt];
         if (need_mask || !GLM_FA_LAZYMAX || !__all(ms <= m_thr[qt])) {
@@ -378,11 +477,14 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
                 const float pv = (GLM_FA_ABLATE & 1) ? arg : __builtin_amdgcn_exp2f(arg);
                 pf[4 * tt + r] = (__bf16)pv;
             }
+#endif
         return pf;
     };
     // the softmax denominator rides on the matrix pipe: a ones fragment as the A operand gives, in every row of the
     // 16x16 result, the column sums of P^T over all 32 keys of the slab (bf16-rounded p, as used in the numerator)
-    const u32x4_t ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    u32x4_t ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    // opaque: hipcc otherwise keeps ONE register and rebuilds the quad with three v_mov in front of every unit's MFMA
+    asm volatile("" : "+v"(ones_u));
     const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_u);
     auto pv_mfma = [&](bf16x8_t pf, int qt) {
         acc_l[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf, acc_l[qt], 0, 0, 0);
@@ -459,7 +561,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
                 }
                 if constexpr (u == NU - 1) { if (more && t + 2 < ntiles) stage_slot(t & 1, t + 2, 1); }
                 const bool lv = live(kb0 + 32 * slab, qt);
-                if (lv) pf = softmax(sbuf[u & 1], kb0 + 32 * slab, qt);
+                if (lv) pf = softmax(sbuf[u & 1], kb0 + 32 * slab, qt, std::false_type{});
                 // V of this unit's predecessor: slab 0 was read at the end of step 0, slab 1 at the end of step FA_QT
                 if constexpr (u == 1 || u == FA_QT + 1) asm volatile("s_waitcnt lgkmcnt(0)" : FA_V_REGS : : "memory");
                 if (lv_prev) pv_mfma(pf_prev, pq);
@@ -528,7 +630,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
                 if constexpr (u == NU - 1) { if (more && t + 2 < ntiles) stage_slot(t & 1, t + 2, 1); }
                 // ---- softmax and PV of this unit
                 const bool lv = live(kb0 + 32 * slab, qt);
-                if (lv) pf = softmax(sbuf[u & 1], kb0 + 32 * slab, qt);
+                if (lv) pf = softmax(sbuf[u & 1], kb0 + 32 * slab, qt, std::false_type{});
                 if constexpr (u == 0) {
                     if constexpr (FA_QT == 2) asm volatile("s_waitcnt lgkmcnt(8)" : FA_V_REGS : : "memory");  // K of slab 1 may be in flight
                     else asm volatile("s_waitcnt lgkmcnt(0)" : FA_V_REGS : : "memory");
@@ -559,8 +661,115 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
         // a unit whose 32 keys are all past the causal diagonal of its 16 query rows (or past the sequence end)
         // is skipped; wave-uniform.  Only the last tiles of a workgroup have such units.
         auto live = [&](int kbase, int qt) -> bool {
+            if (GLM_FA_ABLATE & 64) return true;
             return kbase <= qbase + (16 * FA_QT) * wid + 16 * qt + 15 + off && kbase < lk;
         };
+#if GLM_FA_LOOP == 1 && !GLM_FA_STAMP
+        // ---- r04 loop ----
+        // interior tiles of THIS wave: every key of the tile is visible to every one of the wave's 32 rows and inside the
+        // sequence (t*64 + 63 <= first row + off, t*64 + 63 < lk).  They come first; the diagonal / last tiles follow.
+        const int r0w = qbase + (16 * FA_QT) * wid;
+        int n_int = min((r0w + off + 1) >> 6, lk >> 6);
+        n_int = max(0, min(n_int, ntiles));
+        // running staging sources (contiguous K/V): byte offset of the tile that slots 2,3 of the current tile stage (t + 1);
+        // slots 0,1 stage t + 2 = one tile stride further
+        const int64_t tstride = (int64_t)FA_BK * row_bytes;
+        const char* ksrc = reinterpret_cast<const char*>(k) + ((int64_t)k0 * nkv + kvh) * FA_ROWB + tstride;
+        const char* vsrc = reinterpret_cast<const char*>(v) + ((int64_t)k0 * nkv + kvh) * FA_ROWB + tstride;
+        auto stage_slot2 = [&](int BUF, int t, int ahead, int slot) {  // pieces of tile t + ahead into buffer BUF
+            if (slot >= FA_SLOTS) return;
+#pragma unroll
+            for (int j = 0; j < FA_PPS; ++j) {
+                const int i = slot * FA_PPS + j;
+                if (PAGED) {
+                    stage_piece(BUF, t + ahead, i);
+                } else {
+                    if (GLM_FA_ABLATE & 32) continue;
+                    if (i == 0 && (t + ahead + 1) * FA_BK > lk) stage_offsets(t + ahead);  // uniform; last tile only
+                    char* kd = smem + BUF * FA_STAGE + (wid * FA_PPW + i) * 1024;
+                    const int64_t o = ahead == 2 ? tstride : 0;
+                    glds16(ksrc + o + soff_k[i], kd);
+                    glds16(vsrc + o + soff_v[i], kd + FA_TILE);
+                }
+            }
+        };
+#define FA_RK(SLAB, BUF) FA_READ_K(SLAB)
+#define FA_RV(SLAB, BUF) FA_READ_V(SLAB)
+        // one tile out of buffer BUF; INT: interior tile (all four units live, nothing masked).  Same schedule as the r02
+        // loop: per unit the S MFMAs of the next unit first, then LDS reads / staging, then softmax + PV of this unit.
+        auto tile = [&](auto intc, int t) {
+            constexpr bool INT = decltype(intc)::value;
+            const int BUF = t & 1;
+            const int kb0 = t * FA_BK;
+            const bool more = t + 1 < ntiles;
+            auto lv = [&](int kbase, int qt) -> bool { return INT ? true : live(kbase, qt); };
+            bf16x8_t pf;
+            // ---- unit (slab 0, q0)
+            if (lv(kb0, 1)) s_mfma(sb, 1);
+            FA_SCHED_FENCE();
+            FA_RV(0, BUF);
+            FA_RK(1, BUF);
+            if (t >= 1 && more) stage_slot2(BUF ^ 1, t, 1, 2);
+            if (lv(kb0, 0)) pf = softmax(sa, kb0, 0, intc);
+            asm volatile("s_waitcnt lgkmcnt(8)" : FA_V_REGS : : "memory");  // V landed, K may be in flight
+            if (lv(kb0, 0)) pv_mfma(pf, 0);
+            FA_SCHED_FENCE();
+            // ---- unit (slab 0, q1)
+            asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
+            if (lv(kb0 + 32, 0)) s_mfma(sa, 0);  // S(slab 1, q0)
+            FA_SCHED_FENCE();
+            if (t >= 1 && more) stage_slot2(BUF ^ 1, t, 1, 3);
+            if (lv(kb0, 1)) {
+                pf = softmax(sb, kb0, 1, intc);
+                pv_mfma(pf, 1);
+            }
+            FA_SCHED_FENCE();
+            // ---- unit (slab 1, q0): V of slab 1 is the last LDS read of this buffer
+            if (lv(kb0 + 32, 1)) s_mfma(sb, 1);  // S(slab 1, q1)
+            FA_SCHED_FENCE();
+            FA_RV(1, BUF);
+            asm volatile("s_waitcnt lgkmcnt(0)" : FA_V_REGS : : "memory");
+            if (more) {
+                // tile t+1 was issued a whole tile ago; after the barrier every wave is done with this buffer, which tile
+                // t+2 may then overwrite
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!(GLM_FA_ABLATE & 2)) __builtin_amdgcn_s_barrier();
+                if (t + 2 < ntiles) stage_slot2(BUF, t, 2, 0);
+                const int flip = BUF ? -FA_STAGE : FA_STAGE;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) k_abs[ks] += flip;
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) v_abs[dt] += flip;
+                FA_RK(0, BUF ^ 1);
+            }
+            if (lv(kb0 + 32, 0)) {
+                pf = softmax(sa, kb0 + 32, 0, intc);
+                pv_mfma(pf, 0);
+            }
+            FA_SCHED_FENCE();
+            // ---- unit (slab 1, q1)
+            if (more) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
+                if (INT || live(kb0 + FA_BK, 0)) s_mfma(sa, 0);  // S(tile t+1 slab 0, q0): live behind an interior tile
+                FA_SCHED_FENCE();
+                if (t + 2 < ntiles) stage_slot2(BUF, t, 2, 1);
+            }
+            if (lv(kb0 + 32, 1)) {
+                pf = softmax(sb, kb0 + 32, 1, intc);
+                pv_mfma(pf, 1);
+            }
+            FA_SCHED_FENCE();
+            ksrc += tstride;
+            vsrc += tstride;
+        };
+        {
+            int t = 0;
+            for (; t < n_int; ++t) tile(std::true_type{}, t);
+            for (; t < ntiles; ++t) tile(std::false_type{}, t);
+        }
+#undef FA_RK
+#undef FA_RV
+#else
 #if GLM_FA_STAMP
         unsigned long long tacc[16] = {}, tprev = 0;
 #endif
@@ -577,7 +786,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
             FA_READ_K(1);
             if (t >= 1 && t + 1 < ntiles) stage_slot((t + 1) & 1, t + 1, 2);
             FA_T(2);  // 1: LDS read + DMA issue
-            if (live(kb0, 0)) pf = softmax(sa, kb0, 0);
+            if (live(kb0, 0)) pf = softmax(sa, kb0, 0, std::false_type{});
             FA_T(3);  // 2: softmax
             asm volatile("s_waitcnt lgkmcnt(8)" : FA_V_REGS : : "memory");  // V landed, K may be in flight
             FA_T(4);  // 3: V wait
@@ -592,7 +801,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
             if (t >= 1 && t + 1 < ntiles) stage_slot((t + 1) & 1, t + 1, 3);
             FA_T(7);  // 6: S issue + DMA
             if (live(kb0, 1)) {
-                pf = softmax(sb, kb0, 1);
+                pf = softmax(sb, kb0, 1, std::false_type{});
                 pv_mfma(pf, 1);
             }
             FA_SCHED_FENCE();
@@ -622,7 +831,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
                 FA_T(13);  // 12: DMA issue + K read issue
             }
             if (live(kb0 + 32, 0)) {
-                pf = softmax(sa, kb0 + 32, 0);
+                pf = softmax(sa, kb0 + 32, 0, std::false_type{});
                 pv_mfma(pf, 0);
             }
             FA_SCHED_FENCE();
@@ -636,7 +845,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
             }
             FA_T(15);  // 14: K wait + S issue + DMA
             if (live(kb0 + 32, 1)) {
-                pf = softmax(sb, kb0 + 32, 1);
+                pf = softmax(sb, kb0 + 32, 1, std::false_type{});
                 pv_mfma(pf, 1);
             }
             FA_SCHED_FENCE();
@@ -648,6 +857,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
             for (int i = 0; i < 16; ++i) g_fa_stamps[i] = tacc[i];
         }
 #endif
+#endif  // GLM_FA_LOOP
     }
 #endif
 #undef FA_READ_K
