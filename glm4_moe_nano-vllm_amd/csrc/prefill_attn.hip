@@ -59,6 +59,11 @@
 #ifndef GLM_FA_LOOP
 #define GLM_FA_LOOP 1
 #endif
+// r04 loop only: 1 = V of slab 1 is requested BEFORE the S MFMAs of unit (slab 1, q1) and waited for behind the softmax of
+// unit (slab 1, q0) (the tile's barrier moves behind that softmax too); 0 = requested behind those MFMAs and waited for at once
+#ifndef GLM_FA_VEARLY
+#define GLM_FA_VEARLY 1
+#endif
 // r04: 1 = Q pre-scaled by scale*log2(e) and the S accumulators INITIALISED with minus the softmax reference point, so
 // that the MFMA chain delivers S' = c*s - m and the fast path is p = exp2(S') with no per-element FMA (8 of a unit's ~30
 // vector instructions) and a constant threshold; 0 = the r02/r03 arithmetic (fp32 scale after the dot product)
@@ -279,6 +284,12 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
 
     f32x4_t acc[FA_QT][8], acc_l[FA_QT];
     float m_run[FA_QT], m_thr[FA_QT];  // softmax reference point (log2 domain) and m_run + 8
+    // `exact` = false would skip the lazy-maximum test of unmasked units (an "optimistic" pass with ONE overflow check at
+    // the end of the workgroup and a second, exact pass behind a detected overflow).  Built and measured in r04: the hot
+    // loop loses 10 of its ~78 instructions per unit (268 per tile), the timing-only form (GLM_FA_NOCHECK) ran +3.9 %, but
+    // the safe two-pass form ran 980-990 against 990 TFLOP/s — two instantiations of the tile loops (one copy with a back
+    // edge spilled 25 registers, two copies 10-21 plus scratch set-up) — and was removed again.
+    const bool exact = true;
 #if GLM_FA_CINIT
     // minus the reference point the S accumulators of tile qt start from (0 while the row has seen nothing); m_thr is then
     // the threshold on S' itself: 8 once a reference point exists, -inf before (the first unit takes the exact path)
@@ -374,17 +385,32 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
         // p = exp2(s*c - m_run) <= 256 and nothing is rescaled — the lane-local maximum and one wave vote decide it.
         // Slow path: exact row maximum over the four 16-lane groups that share a query column (VALU lane swaps, one
         // asm block: hipcc pads every separate asm VALU op with an s_nop), new reference point, rescale.
-        float mloc;
-        asm("v_max3_f32 %0, %1, %2, %3\n\t"
-            "v_max3_f32 %0, %0, %4, %5\n\t"
-            "v_max3_f32 %0, %0, %6, %7\n\t"
-            "v_max_f32 %0, %0, %8"
-            : "=&v"(mloc)
-            : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][3]), "v"(s[1][0]), "v"(s[1][1]), "v"(s[1][2]),
-              "v"(s[1][3]));
+        auto maxchain = [&]() -> float {
+            float mloc;
+#if GLM_FA_CINIT
+            asm("v_max3_f32 %0, %1, %2, %3\n\t"
+                "v_max3_f32 %0, %0, %4, %5\n\t"
+                "v_max3_f32 %0, %0, %6, %7\n\t"
+                "v_max_f32 %0, %0, %8"
+                : "=&v"(mloc)
+                : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][3]), "v"(s[1][0]), "v"(s[1][1]), "v"(s[1][2]),
+                  "v"(s[1][3]));
+#else
+            // (the scale multiply sits inside the block: hipcc pads the boundary of an asm VALU block with an s_nop)
+            asm("v_max3_f32 %0, %1, %2, %3\n\t"
+                "v_max3_f32 %0, %0, %4, %5\n\t"
+                "v_max3_f32 %0, %0, %6, %7\n\t"
+                "v_max_f32 %0, %0, %8\n\t"
+                "v_mul_f32 %0, %9, %0"
+                : "=&v"(mloc)
+                : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]), "v"(s[0][3]), "v"(s[1][0]), "v"(s[1][1]), "v"(s[1][2]),
+                  "v"(s[1][3]), "s"(scale_log2e));
+#endif
+            return mloc;
+        };
 #if GLM_FA_CINIT
         // S' = c*s - m_cur, m_cur = the reference point the accumulators started from (m_run, or 0 before the first unit)
-        float ms = mloc;
+        float ms = maxchain();
         float shift = 0.f;
 #if GLM_FA_NOCHECK
         // a query tile's first unit (keys 0..31) is either unmasked — it then sets the reference point of all 16 rows — or
@@ -441,9 +467,27 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
                 pf[4 * tt + r] = (__bf16)pv;
             }
 #else
-        float ms = mloc * scale_log2e;
+        float ms = 0.f;  // slab maximum, scaled (inside the asm block)
         float m_use = m_run[qt];
-        if (need_mask || !GLM_FA_LAZYMAX || !__all(ms <= m_thr[qt])) {
+        // a query tile's first unit (keys 0..31) is either unmasked — it then sets the reference point of all 16 rows — or on
+        // the causal diagonal, and then every later unit of the tile is masked or dead as well
+        const bool first_unit = decltype(interior_c)::value ? false : kbase == 0;
+        bool slow0;
+#if GLM_FA_NOCHECK
+        slow0 = need_mask || first_unit;  // TIMING STUDY: no overflow check at all
+        if (slow0) ms = maxchain();
+#else
+        if (need_mask || first_unit || !GLM_FA_LAZYMAX) {
+            ms = maxchain();
+            slow0 = true;
+        } else if (exact) {
+            ms = maxchain();
+            slow0 = !__all(ms <= m_thr[qt]);
+        } else {
+            slow0 = false;  // optimistic pass: checked once, at the end of the workgroup
+        }
+#endif
+        if (slow0) {
             float mtmp;
             asm("v_mov_b32 %1, %0\n\t"
                 "s_nop 1\n\t"
@@ -674,9 +718,17 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
         // running staging sources (contiguous K/V): byte offset of the tile that slots 2,3 of the current tile stage (t + 1);
         // slots 0,1 stage t + 2 = one tile stride further
         const int64_t tstride = (int64_t)FA_BK * row_bytes;
-        const char* ksrc = reinterpret_cast<const char*>(k) + ((int64_t)k0 * nkv + kvh) * FA_ROWB + tstride;
-        const char* vsrc = reinterpret_cast<const char*>(v) + ((int64_t)k0 * nkv + kvh) * FA_ROWB + tstride;
-        auto stage_slot2 = [&](int BUF, int t, int ahead, int slot) {  // pieces of tile t + ahead into buffer BUF
+        auto uni = [](const char* ptr) -> const char* {  // provably wave-uniform for the "s" constraints below
+            const unsigned long long u = (unsigned long long)ptr;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+            return (const char*)(((unsigned long long)hi << 32) | lo);
+        };
+        const char* ksrc = uni(reinterpret_cast<const char*>(k) + ((int64_t)k0 * nkv + kvh) * FA_ROWB + tstride);
+        const char* vsrc = uni(reinterpret_cast<const char*>(v) + ((int64_t)k0 * nkv + kvh) * FA_ROWB + tstride);
+        const char* ksrc2 = uni(ksrc + tstride);  // tile t + 2
+        const char* vsrc2 = uni(vsrc + tstride);
+        // NOCHK: the caller vouches that tile t + ahead is a full tile (no row clamping needed)
+        auto stage_slot2 = [&](int BUF, int t, int ahead, int slot, bool nochk) {  // pieces of tile t + ahead into buffer BUF
             if (slot >= FA_SLOTS) return;
 #pragma unroll
             for (int j = 0; j < FA_PPS; ++j) {
@@ -685,23 +737,26 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
                     stage_piece(BUF, t + ahead, i);
                 } else {
                     if (GLM_FA_ABLATE & 32) continue;
-                    if (i == 0 && (t + ahead + 1) * FA_BK > lk) stage_offsets(t + ahead);  // uniform; last tile only
+                    if (!nochk && i == 0 && (t + ahead + 1) * FA_BK > lk) stage_offsets(t + ahead);  // uniform; last tile only
                     char* kd = smem + BUF * FA_STAGE + (wid * FA_PPW + i) * 1024;
-                    const int64_t o = ahead == 2 ? tstride : 0;
-                    glds16(ksrc + o + soff_k[i], kd);
-                    glds16(vsrc + o + soff_v[i], kd + FA_TILE);
+                    glds16((ahead == 2 ? ksrc2 : ksrc) + soff_k[i], kd);
+                    glds16((ahead == 2 ? vsrc2 : vsrc) + soff_v[i], kd + FA_TILE);
                 }
             }
         };
 #define FA_RK(SLAB, BUF) FA_READ_K(SLAB)
 #define FA_RV(SLAB, BUF) FA_READ_V(SLAB)
-        // one tile out of buffer BUF; INT: interior tile (all four units live, nothing masked).  Same schedule as the r02
-        // loop: per unit the S MFMAs of the next unit first, then LDS reads / staging, then softmax + PV of this unit.
+        // one tile out of buffer t & 1.  INT: STRICT interior tile — all four units live, nothing masked, and not among the
+        // first or the last three tiles, so that every staging / barrier / next-tile condition of the general body is true
+        // and tiles t + 1, t + 2 are full tiles: the body has no scalar predicate at all.  Same schedule as the r02 loop:
+        // per unit the S MFMAs of the next unit first, then LDS reads / staging, then softmax + PV of this unit.
         auto tile = [&](auto intc, int t) {
             constexpr bool INT = decltype(intc)::value;
             const int BUF = t & 1;
             const int kb0 = t * FA_BK;
-            const bool more = t + 1 < ntiles;
+            const bool more = INT ? true : t + 1 < ntiles;
+            const bool more2 = INT ? true : t + 2 < ntiles;
+            const bool first = INT ? false : t < 1;
             auto lv = [&](int kbase, int qt) -> bool { return INT ? true : live(kbase, qt); };
             bf16x8_t pf;
             // ---- unit (slab 0, q0)
@@ -709,7 +764,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
             FA_SCHED_FENCE();
             FA_RV(0, BUF);
             FA_RK(1, BUF);
-            if (t >= 1 && more) stage_slot2(BUF ^ 1, t, 1, 2);
+            if (!first && more) stage_slot2(BUF ^ 1, t, 1, 2, INT);
             if (lv(kb0, 0)) pf = softmax(sa, kb0, 0, intc);
             asm volatile("s_waitcnt lgkmcnt(8)" : FA_V_REGS : : "memory");  // V landed, K may be in flight
             if (lv(kb0, 0)) pv_mfma(pf, 0);
@@ -718,23 +773,33 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
             asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
             if (lv(kb0 + 32, 0)) s_mfma(sa, 0);  // S(slab 1, q0)
             FA_SCHED_FENCE();
-            if (t >= 1 && more) stage_slot2(BUF ^ 1, t, 1, 3);
+            if (!first && more) stage_slot2(BUF ^ 1, t, 1, 3, INT);
             if (lv(kb0, 1)) {
                 pf = softmax(sb, kb0, 1, intc);
                 pv_mfma(pf, 1);
             }
             FA_SCHED_FENCE();
             // ---- unit (slab 1, q0): V of slab 1 is the last LDS read of this buffer
+#if GLM_FA_VEARLY
+            FA_RV(1, BUF);
+            if (lv(kb0 + 32, 1)) s_mfma(sb, 1);  // S(slab 1, q1)
+            FA_SCHED_FENCE();
+            bf16x8_t pf_e;
+            const bool lv_e = lv(kb0 + 32, 0);
+            if (lv_e) pf_e = softmax(sa, kb0 + 32, 0, intc);
+            asm volatile("s_waitcnt lgkmcnt(0)" : FA_V_REGS : : "memory");
+#else
             if (lv(kb0 + 32, 1)) s_mfma(sb, 1);  // S(slab 1, q1)
             FA_SCHED_FENCE();
             FA_RV(1, BUF);
             asm volatile("s_waitcnt lgkmcnt(0)" : FA_V_REGS : : "memory");
+#endif
             if (more) {
                 // tile t+1 was issued a whole tile ago; after the barrier every wave is done with this buffer, which tile
                 // t+2 may then overwrite
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (!(GLM_FA_ABLATE & 2)) __builtin_amdgcn_s_barrier();
-                if (t + 2 < ntiles) stage_slot2(BUF, t, 2, 0);
+                if (more2) stage_slot2(BUF, t, 2, 0, INT);
                 const int flip = BUF ? -FA_STAGE : FA_STAGE;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) k_abs[ks] += flip;
@@ -742,17 +807,21 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
                 for (int dt = 0; dt < 8; ++dt) v_abs[dt] += flip;
                 FA_RK(0, BUF ^ 1);
             }
+#if GLM_FA_VEARLY
+            if (lv_e) pv_mfma(pf_e, 0);
+#else
             if (lv(kb0 + 32, 0)) {
                 pf = softmax(sa, kb0 + 32, 0, intc);
                 pv_mfma(pf, 0);
             }
+#endif
             FA_SCHED_FENCE();
             // ---- unit (slab 1, q1)
             if (more) {
                 asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
                 if (INT || live(kb0 + FA_BK, 0)) s_mfma(sa, 0);  // S(tile t+1 slab 0, q0): live behind an interior tile
                 FA_SCHED_FENCE();
-                if (t + 2 < ntiles) stage_slot2(BUF, t, 2, 1);
+                if (more2) stage_slot2(BUF, t, 2, 1, INT);
             }
             if (lv(kb0 + 32, 1)) {
                 pf = softmax(sb, kb0 + 32, 1, intc);
@@ -761,10 +830,17 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
             FA_SCHED_FENCE();
             ksrc += tstride;
             vsrc += tstride;
+            ksrc2 += tstride;
+            vsrc2 += tstride;
+            // keep the four running pointers as such (hipcc otherwise re-forms base + offset in front of every DMA)
+            asm volatile("" : "+s"(ksrc), "+s"(vsrc), "+s"(ksrc2), "+s"(vsrc2));
         };
         {
+            // strict interior range [1, n1): see `tile`
+            const int n1 = min(n_int, ntiles - 3);
             int t = 0;
-            for (; t < n_int; ++t) tile(std::true_type{}, t);
+            if (ntiles > 0) tile(std::false_type{}, t++);
+            for (; t < n1; ++t) tile(std::true_type{}, t);
             for (; t < ntiles; ++t) tile(std::false_type{}, t);
         }
 #undef FA_RK
