@@ -138,6 +138,35 @@ extern "C" int glm_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t 
     return dispatch(GEMM_PLAIN, p, glm_s(stream));
 }
 
+extern "C" int glm_gemm_qkv_rope_store(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, int64_t T,
+                                       int nh, int nkv, int hd, int K, const int64_t* positions, const float* cos_sin_cache,
+                                       int rotary_dim, void* q_out, void* k_out, void* v_out, void* k_cache, void* v_cache,
+                                       const int32_t* slot_mapping, int64_t n_slots, glm_stream_t stream) {
+    GLM_CHECK_ARG(x && w && positions && cos_sin_cache && q_out, GLM_ERR_INVALID, "glm_gemm_qkv_rope_store: null pointer");
+    GLM_CHECK_ARG(T >= 0 && nh > 0 && nkv > 0 && K > 0 && ldx >= K && ldw >= K, GLM_ERR_INVALID,
+                  "glm_gemm_qkv_rope_store: bad shape T=%ld nh=%d nkv=%d K=%d", (long)T, nh, nkv, K);
+    GLM_CHECK_ARG((k_cache == nullptr) == (v_cache == nullptr) && (k_out == nullptr) == (v_out == nullptr), GLM_ERR_INVALID,
+                  "glm_gemm_qkv_rope_store: K and V outputs come in pairs");
+    // the fused epilogue exists for the tiled kernel at head_dim 128 / rotary_dim 64 (GLM-4.5 family); anything else, and row
+    // counts the tiled kernel is not chosen for, is the caller's two-launch path (glm_gemm_bf16 + glm_qkv_split_norm_rope_store)
+    if (hd != 128 || rotary_dim != 64 || T < LARGEM_MIN_AVG_ROWS) {
+        glm_set_error("glm_gemm_qkv_rope_store: not covered (hd=%d rotary_dim=%d T=%ld)", hd, rotary_dim, (long)T);
+        return GLM_ERR_UNSUPPORTED;
+    }
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const bf16_t*)x; p.ldx = ldx;
+    p.w = (const bf16_t*)w; p.ldw = ldw;
+    p.bias = (const bf16_t*)bias;
+    p.R = T; p.N = (nh + 2 * nkv) * hd; p.K = K; p.G = 1;
+    p.qkv_q = (bf16_t*)q_out; p.qkv_k = (bf16_t*)k_out; p.qkv_v = (bf16_t*)v_out;
+    p.qkv_kc = (bf16_t*)k_cache; p.qkv_vc = (bf16_t*)v_cache;
+    p.qkv_slots = slot_mapping; p.qkv_nslots = n_slots;
+    p.qkv_pos = positions; p.qkv_cs = cos_sin_cache;
+    p.qkv_nh = nh; p.qkv_nkv = nkv;
+    return glm_launch_gemm_largem_qkv(p, glm_s(stream));
+}
+
 extern "C" int glm_gemm_bf16_combine_norm(const void* y_prev, int64_t ld_yprev, const int32_t* pair_pos, int64_t T, int k,
                                           int64_t shared_base, const void* residual_in, const void* norm_weight,
                                           float eps, void* residual_out, void* x_out, const void* w, int64_t ldw,

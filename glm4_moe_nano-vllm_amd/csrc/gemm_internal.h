@@ -32,6 +32,19 @@ struct GemmParams {
     int n_scaled;         // GEMM_DOWN: groups [0, n_scaled) multiply by scale
     int ksplit;           // GEMM_PLAIN small-M only: K slices computed by separate workgroups (0/1 = off)
     float* ypart;         // ksplit > 1: fp32 partial sums [ksplit][R][N] instead of y
+    // gemm_largem, GEMM_PLAIN only (r04): the QKV projection's epilogue does what qkv_post_kernel does — split into q / k /
+    // v, partial NeoX rotary on q and k (attention_new.py:329-357), K/V rows into the paged cache (attention.py:10-42) —
+    // instead of storing the packed row.  qkv_q != nullptr switches it on; y is then unused.  head_dim 128, rotary_dim 64.
+    bf16_t* qkv_q;        // [R, nh, 128]
+    bf16_t* qkv_k;        // [R, nkv, 128] or nullptr
+    bf16_t* qkv_v;
+    bf16_t* qkv_kc;       // paged caches viewed as [n_slots, nkv, 128], or nullptr
+    bf16_t* qkv_vc;
+    const int32_t* qkv_slots;    // [R], -1 = no cache row
+    const int64_t* qkv_pos;      // [R]
+    const float* qkv_cs;         // cos_sin_cache [max_pos, 64] = cos(32) | sin(32)
+    int64_t qkv_nslots;
+    int qkv_nh, qkv_nkv;
 };
 
 // weight-streaming kernels for few rows per group (decode); returns GLM_* code
@@ -59,6 +72,8 @@ int glm_launch_gemm_smallm_fp8w(int mode, const GemmParams& p, hipStream_t st);
 // LDS-tiled MFMA kernels for many rows per group (prefill); p.wscale != nullptr: per-weight-row fp32 scale applied to
 // the accumulator before the bf16 roundings (weights expanded from fp8, elementwise.hip)
 int glm_launch_gemm_largem(int mode, const GemmParams& p, hipStream_t st);
+// ... GEMM_PLAIN with the QKV epilogue (p.qkv_*): GLM_ERR_UNSUPPORTED when the shape is outside the product loop's cover
+int glm_launch_gemm_largem_qkv(const GemmParams& p, hipStream_t st);
 // exact fp8 e4m3 -> bf16 expansion of a weight stack [G, rows, cols] (element strides)
 int glm_launch_fp8_expand(const void* q, int64_t ld_q, int64_t gs_q, void* out, int64_t ld_out, int64_t gs_out, int G,
                           int rows, int cols, hipStream_t st);

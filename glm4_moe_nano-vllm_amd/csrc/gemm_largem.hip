@@ -1122,6 +1122,73 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         const int ncol_w = MODE == GEMM_GATEUP ? ntile_c * 128 + wn * 32 : ntile_c * LM_BN + wn * 64;
         const bool scaled = MODE == GEMM_DOWN && grp_c < p.n_scaled;
         const bool do_park = PARK && more && nk >= PARK_N;  // the next tile's K loop has a K tile for every parked store
+        bool qkv_epi = false;
+        if constexpr (MODE == GEMM_PLAIN && WIDE && !WSCALE) qkv_epi = p.qkv_q != nullptr;
+        if (qkv_epi) {
+            // ---- QKV epilogue (r04): bias, bf16 rounding (the packed qkv value of the reference, linear.py:75), rotary on the
+            // first 64 dims of every q / k head, split, cache scatter.  A wave's 64 columns are one half of one head (ncol_w
+            // is a multiple of 64): the rotary half pairs column i with i + 32 = accumulator tiles t and t + 2 in the SAME
+            // lane and register, so the rotation is lane-local.  Arithmetic and rounding points are qkv_post_kernel's
+            // (rope8: products and the difference / sum rounded separately, -ffp-contract=off): bit-identical outputs.
+            const int head = ncol_w >> 7, half = (ncol_w >> 6) & 1;
+            const int nh = p.qkv_nh, nkv = p.qkv_nkv;
+            const bool is_q = head < nh, is_k = !is_q && head < nh + nkv;
+            const bool rot = half == 0 && (is_q || is_k);
+            const int kh = is_q ? head : (is_k ? head - nh : head - nh - nkv);
+            bf16_t* dense = is_q ? p.qkv_q : (is_k ? p.qkv_k : p.qkv_v);
+            bf16_t* cache = is_q ? nullptr : (is_k ? p.qkv_kc : p.qkv_vc);
+            const int64_t ldd = (int64_t)(is_q ? nh : nkv) * 128;
+            const bool col_ok = ncol_w < p.N;
+            u32x2_t bias_p[4];  // four consecutive bias values per tile, packed (N is a whole number of 64-column blocks)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                bias_p[t] = (p.bias && col_ok) ? *reinterpret_cast<const u32x2_t*>(p.bias + ncol_w + 16 * t + 4 * g4) : u32x2_t{0u, 0u};
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt) {
+                const int row = wm * (C::BM / 2) + 16 * mt + c;
+                const bool row_ok = row < mcnt_c && col_ok;
+                const int64_t m = m0_c + (row_ok ? row : 0);
+                float o[4][4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    o[t][0] = rbf(acc[t][mt][0] + bflo(bias_p[t][0]));
+                    o[t][1] = rbf(acc[t][mt][1] + bfhi(bias_p[t][0]));
+                    o[t][2] = rbf(acc[t][mt][2] + bflo(bias_p[t][1]));
+                    o[t][3] = rbf(acc[t][mt][3] + bfhi(bias_p[t][1]));
+                }
+                if (rot) {  // wave-uniform
+                    const float* cs = p.qkv_cs + p.qkv_pos[m] * 64;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const f32x4_t cv = *reinterpret_cast<const f32x4_t*>(cs + 16 * t + 4 * g4);
+                        const f32x4_t sv = *reinterpret_cast<const f32x4_t*>(cs + 32 + 16 * t + 4 * g4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float x1 = o[t][r], x2 = o[t + 2][r];
+                            o[t][r] = x1 * cv[r] - x2 * sv[r];
+                            o[t + 2][r] = x2 * cv[r] + x1 * sv[r];
+                        }
+                    }
+                }
+                u32x2_t v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = u32x2_t{pack2bf(o[t][0], o[t][1]), pack2bf(o[t][2], o[t][3])};
+                int64_t slot = -1;
+                if (cache != nullptr && p.qkv_slots != nullptr && row_ok) slot = p.qkv_slots[m];
+                const bool to_cache = slot >= 0 && slot < p.qkv_nslots;
+#pragma unroll
+                for (int t = 0; t < 4; t += 2) {
+                    const u32x2_t a = __builtin_amdgcn_permlane16_swap(v[t][0], v[t + 1][0], false, false);
+                    const u32x2_t b = __builtin_amdgcn_permlane16_swap(v[t][1], v[t + 1][1], false, false);
+                    const int cw = 64 * half + 16 * (t + (g4 & 1)) + 8 * (g4 >> 1);  // column inside the head
+                    const u32x4_t o4 = u32x4_t{a[0], b[0], a[1], b[1]};
+                    if (row_ok) {
+                        if (dense != nullptr) *reinterpret_cast<u32x4_t*>(dense + m * ldd + kh * 128 + cw) = o4;
+                        if (to_cache) *reinterpret_cast<u32x4_t*>(cache + (slot * nkv + kh) * 128 + cw) = o4;
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt) {
             const int row = wm * (C::BM / 2) + 16 * mt + c;
@@ -1216,7 +1283,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         if constexpr ((VAR & LM_EPIORD) != 0) {
             // exact only when every store instruction of the wave ran: all rows and columns of the tile exist
             const bool full = mcnt_c == C::BM && ncol_w + (MODE == GEMM_GATEUP ? 32 : 64) <= p.N && !NOSTORE &&
-                              !((VAR & LM_LDSEPI) != 0 && NOUT == 4);
+                              !((VAR & LM_LDSEPI) != 0 && NOUT == 4) && !(MODE == GEMM_PLAIN && p.qkv_q != nullptr);
             pending_stores = full ? LM_STORES_FULL - (do_park ? PARK_N : 0) : 0;
         }
         if constexpr (PARK) {
@@ -1315,6 +1382,10 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
         }
     }
     if (!lean_ok) var = 0;
+    if (p.qkv_q != nullptr && ((var & LM_WIDEST) == 0 || p.wscale != nullptr)) {  // 16-byte-store form, bf16 weights only
+        glm_set_error("gemm_largem(qkv epilogue): loop variant %d has no such epilogue", var);
+        return GLM_ERR_UNSUPPORTED;
+    }
 #define GLM_LM_CASE(V)                                                                                         \
     case V:                                                                                                    \
         if (use_b && ((V) & LM_DEEP)) return launch_largem_cfg<MODE, LmCfgB5, V>(p, st);                       \
@@ -1369,6 +1440,22 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
 }
 
 }  // namespace
+
+// QKV projection with the split / rotary / cache-store epilogue: the product loop on the tiled configurations only
+int glm_launch_gemm_largem_qkv(const GemmParams& p, hipStream_t st) {
+    const int Nexp = (p.qkv_nh + 2 * p.qkv_nkv) * 128;
+    if (p.qkv_q == nullptr || p.N != Nexp || p.offs != nullptr || p.K % 64 != 0 || p.R < 1 || p.ldx % 8 != 0 || p.ldw % 8 != 0 ||
+        !glm_aligned16(p.x) || !glm_aligned16(p.w) || !glm_aligned16(p.qkv_q) || !glm_aligned16(p.qkv_cs) ||
+        (p.qkv_k && !glm_aligned16(p.qkv_k)) || (p.qkv_v && !glm_aligned16(p.qkv_v)) || (p.qkv_kc && !glm_aligned16(p.qkv_kc)) ||
+        (p.qkv_vc && !glm_aligned16(p.qkv_vc)) || p.R * p.ldx * 2 >= (1ll << 31) || (int64_t)p.N * p.ldw * 2 >= (1ll << 31)) {
+        glm_set_error("gemm_largem(qkv epilogue): shape not covered (R=%ld N=%d K=%d)", (long)p.R, p.N, p.K);
+        return GLM_ERR_UNSUPPORTED;
+    }
+    GemmParams q = p;
+    q.y = p.qkv_q;  // never stored through; keeps the generic alignment checks meaningful
+    q.ldy = p.N;
+    return launch_largem<GEMM_PLAIN>(q, st);
+}
 
 int glm_launch_gemm_largem(int mode, const GemmParams& p, hipStream_t st) {
     GLM_CHECK_ARG(p.K % 8 == 0 && p.N % 4 == 0 && p.ldx % 8 == 0 && p.ldy % 4 == 0 && p.ldw % 8 == 0 &&

@@ -39,6 +39,9 @@ _SIGNATURES = {
                                               c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                               c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                               c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "glm_gemm_qkv_rope_store": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int64, c_void_p]),
     "glm_silu_and_mul": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "glm_paged_attn_decode_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "glm_paged_attn_decode_splits": (c_int, [c_int64, c_int, c_int, c_int64, c_int, c_int]),
@@ -157,6 +160,7 @@ _HOST_OPTION_ENV = {  # name -> (environment variable, default)
     "fuse_combine_qkv": ("GLM4MOE_FUSE_COMBINE_QKV", 1),    # one token: combine + input norm + QKV in one launch
     "fuse_oproj_router": ("GLM4MOE_FUSE_OPROJ_ROUTER", 1),  # one token: o_proj + norm + router + bucketing in one launch
     "defer_qkv_reduce": ("GLM4MOE_DEFER_QKV_REDUCE", 1),    # QKV as K-slice partial sums reduced by the attention's loads
+    "fuse_qkv_rope": ("GLM4MOE_FUSE_QKV_ROPE", 1),          # prefill: split + rotary + K/V store in the QKV GEMM's epilogue
     "ep_fixed": ("GLM_EP_FIXED", 1),                        # expert parallelism: fixed-capacity dispatch at decode sizes
     "oneshot_allreduce": ("GLM_ONESHOT_ALLREDUCE", 0),      # opt-in one-hop all-reduce over mapped peer buffers
 }
@@ -344,6 +348,36 @@ def qkv_split_norm_rope_store(qkv: torch.Tensor, nh: int, nkv: int, hd: int,
         _p(k_cache) if store else None, _p(v_cache) if store else None,
         _p(slot_mapping) if store else None, n_slots, T, nh, nkv, hd, _stream()),
         "glm_qkv_split_norm_rope_store")
+    return q, k, v
+
+
+def gemm_qkv_rope_store(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None, nh: int, nkv: int, hd: int,
+                        positions: torch.Tensor, cos_sin_cache: torch.Tensor, rotary_dim: int,
+                        k_cache: torch.Tensor | None, v_cache: torch.Tensor | None, slot_mapping: torch.Tensor | None,
+                        need_kv: bool):
+    """Prefill: QKV projection + split + rotary + K/V cache store in ONE launch (glm_gemm_qkv_rope_store).  Returns
+    (q [T,nh,hd], k, v [T,nkv,hd] or None) — or None when the launcher does not cover the shape (nothing was enqueued:
+    the caller takes gemm_bf16 + qkv_split_norm_rope_store)."""
+    if x.dim() != 2 or x.shape[0] < 96 or hd != 128 or rotary_dim != 64 or opt("fuse_qkv_rope") == 0:
+        return None
+    _bf16(x, "x"); _bf16(w, "w")
+    T, K = x.shape
+    assert w.shape == ((nh + 2 * nkv) * hd, K) and w.stride(1) == 1 and positions.dtype == torch.int64
+    assert cos_sin_cache.dtype == torch.float32 and cos_sin_cache.is_contiguous() and cos_sin_cache.shape[-1] == rotary_dim
+    q = torch.empty((T, nh, hd), dtype=x.dtype, device=x.device)
+    k = torch.empty((T, nkv, hd), dtype=x.dtype, device=x.device) if need_kv else None
+    v = torch.empty_like(k) if need_kv else None
+    has_cache = k_cache is not None and slot_mapping is not None and slot_mapping.numel() == T
+    if has_cache:
+        assert k_cache.is_contiguous() and v_cache.is_contiguous() and slot_mapping.dtype == torch.int32
+    n_slots = k_cache.shape[0] * k_cache.shape[1] if has_cache else 0
+    rc = load_library().glm_gemm_qkv_rope_store(
+        _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), T, nh, nkv, hd, K, _p(positions), _p(cos_sin_cache), rotary_dim,
+        _p(q), _p(k), _p(v), _p(k_cache) if has_cache else None, _p(v_cache) if has_cache else None,
+        _p(slot_mapping) if has_cache else None, n_slots, _stream())
+    if rc == GLM_ERR_UNSUPPORTED:
+        return None
+    _check(rc, "glm_gemm_qkv_rope_store")
     return q, k, v
 
 

@@ -101,6 +101,20 @@ class Glm4MoeAttention(nn.Module):
             if skip_o_proj:
                 return o.reshape(o.shape[0], -1)
             return self.o_proj(o.reshape(o.shape[0], -1), defer_reduce=defer_o_reduce)
+        if (qkv is None and ctx.is_prefill and not self.use_qk_norm and self._fusable() and hidden_states.dim() == 2
+                and self.qkv_proj.tp_size >= 1):
+            # prefill row counts: split + rotary + K/V cache store ride in the QKV GEMM's epilogue (bit-identical to the two
+            # launches below; None = shape outside that launch)
+            fused = hip_ops.gemm_qkv_rope_store(
+                hidden_states, self.qkv_proj.weight.data, self.qkv_proj.bias.data if self.qkv_proj.bias is not None else None,
+                self.num_heads, self.num_kv_heads, self.head_dim, positions, self.rotary_emb.cos_sin_cache,
+                self.rotary_emb.rotary_dim, attn.k_cache if has_cache else None, attn.v_cache if has_cache else None,
+                ctx.slot_mapping if has_cache else None, ctx.block_tables is None)
+            if fused is not None:
+                o = attn.attend(*fused)
+                if skip_o_proj:
+                    return o.reshape(o.shape[0], -1)
+                return self.o_proj(o.reshape(o.shape[0], -1), defer_reduce=defer_o_reduce)
         if qkv is None:
             qkv = self.qkv_proj(hidden_states)
         if self._fusable():

@@ -103,6 +103,18 @@ int glm_qkv_split_norm_rope_store(const void* qkv, int64_t qkv_stride,
                                   int64_t n_slots,
                                   int64_t T, int nh, int nkv, int hd, glm_stream_t stream);
 
+/* a5 + a6 + a7 in ONE launch at prefill row counts (r04): the QKV projection (linear.py:74-75, attention_new.py:329) whose
+ *     epilogue splits the packed row, rotates q and k (rotary_embedding.py:39-55, partial NeoX, rotary_dim 64 of head_dim
+ *     128) and writes q [T, nh, 128], k / v [T, nkv, 128] (optional) and the K/V cache rows (attention.py:10-42; slot -1 or
+ *     >= n_slots skipped) — glm_gemm_bf16 followed by glm_qkv_split_norm_rope_store without the packed [T, (nh+2nkv)*128]
+ *     row ever reaching memory, bit-identical to the two launches.  No per-head RMSNorm (use_qk_norm models take the two
+ *     launches).  GLM_ERR_UNSUPPORTED (nothing enqueued): head_dim != 128, rotary_dim != 64, fewer than 96 rows, K % 64 != 0,
+ *     operands beyond 2 GiB, unaligned pointers.                                                                      */
+int glm_gemm_qkv_rope_store(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, int64_t T,
+                            int nh, int nkv, int hd, int K, const int64_t* positions, const float* cos_sin_cache,
+                            int rotary_dim, void* q_out, void* k_out, void* v_out, void* k_cache, void* v_cache,
+                            const int32_t* slot_mapping, int64_t n_slots, glm_stream_t stream);
+
 /* layers/activation.py:12-14  SiluAndMul: y[t,i] = bf16( bf16(silu(x[t,i])) * x[t,I+i] )    */
 int glm_silu_and_mul(const void* x, void* y, int64_t T, int I, glm_stream_t stream);
 

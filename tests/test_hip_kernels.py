@@ -823,6 +823,71 @@ def test_gemm_large_m_quadrant_loop_equals_plain_loop(ops, K):
     assert_close_bf16(got[2], O.linear(xp, wp, bias), 1, 0.05, atol=2 ** -9, what=f"plain K={K}")
 
 
+@pytest.mark.parametrize("T,nh,nkv,K,with_cache,need_kv", [(1024, 12, 2, 512, True, True), (300, 4, 1, 256, True, False),
+                                                          (777, 6, 2, 192, False, True), (4096, 96, 8, 4096, True, True)])
+def test_qkv_gemm_with_rope_store_epilogue(ops, T, nh, nkv, K, with_cache, need_kv):
+    """r04: glm_gemm_qkv_rope_store (QKV projection whose epilogue splits, rotates q / k and scatters K / V into the paged
+    cache) == glm_gemm_bf16 followed by glm_qkv_split_norm_rope_store, bit for bit — q, k, v and every cache row, rows with
+    slot -1 untouched — and both against the oracle (linear.py:74-75, rotary_embedding.py:39-55, attention.py:10-42).  The
+    last case is the Air shape (H = 4096, 96 / 8 heads); ragged T exercises partial row blocks."""
+    hd, rd = 128, 64
+    N = (nh + 2 * nkv) * hd
+    x = rnd(T, K, seed=901)
+    w = rnd(N, K, seed=902, scale=K ** -0.5)
+    b = rnd(N, seed=903)
+    g = torch.Generator().manual_seed(904)
+    pos = torch.randint(0, 2048, (T,), generator=g, dtype=torch.int64)
+    cs = O.build_cos_sin_cache(rd, 2048, 10000.0).reshape(2048, rd).contiguous()
+    nblk = (T + 255) // 256 + 2
+    slots = torch.randperm(nblk * 256, generator=g)[:T].to(torch.int32)
+    slots[::7] = -1
+    kc0 = rnd(nblk, 256, nkv, hd, seed=905)
+    vc0 = rnd(nblk, 256, nkv, hd, seed=906)
+
+    def two_launches():
+        kc, vc = dev(kc0), dev(vc0)
+        qkv = ops.gemm_bf16(dev(x), dev(w), dev(b))
+        q, k, v = ops.qkv_split_norm_rope_store(qkv, nh, nkv, hd, dev(pos), dev(cs), rd, None, None, 1e-5,
+                                                kc if with_cache else None, vc if with_cache else None,
+                                                dev(slots) if with_cache else None, need_kv)
+        return q, k, v, kc, vc
+
+    def one_launch():
+        kc, vc = dev(kc0), dev(vc0)
+        r = ops.gemm_qkv_rope_store(dev(x), dev(w), dev(b), nh, nkv, hd, dev(pos), dev(cs), rd,
+                                    kc if with_cache else None, vc if with_cache else None,
+                                    dev(slots) if with_cache else None, need_kv)
+        assert r is not None, "the fused launch must cover this shape"
+        return (*r, kc, vc)
+
+    q0, k0, v0, kc_a, vc_a = two_launches()
+    for rep in range(2):
+        q1, k1, v1, kc_b, vc_b = one_launch()
+        torch.cuda.synchronize()
+        assert torch.equal(q0, q1), "q differs"
+        if need_kv:
+            assert torch.equal(k0, k1) and torch.equal(v0, v1), "k / v differ"
+        else:
+            assert k1 is None and v1 is None
+        assert torch.equal(kc_a, kc_b) and torch.equal(vc_a, vc_b), "cache rows differ"
+    if with_cache:
+        skipped = (slots < 0)
+        keep = torch.ones(nblk * 256, dtype=torch.bool)
+        keep[slots[~skipped].long()] = False
+        assert torch.equal(kc_b.cpu().view(-1, nkv * hd)[keep], kc0.view(-1, nkv * hd)[keep]), "untouched cache rows changed"
+    # oracle on a sample of rows (the GEMM's fp32 summation order differs from the CPU's by single ulps)
+    rows = torch.arange(0, T, max(1, T // 64))
+    qkv_ref = O.linear(x[rows], w, b)
+    qr, kr, vr = qkv_ref.split([nh * hd, nkv * hd, nkv * hd], dim=-1)
+    qr, kr = O.rope_neox(pos[rows], qr.reshape(-1, nh, hd), kr.reshape(-1, nkv, hd), cs.reshape(2048, 1, rd), rd)
+    assert_close_bf16(q1.cpu()[rows], qr, 2, 0.06, atol=2 ** -6, what="q vs oracle")
+    if need_kv:
+        assert_close_bf16(k1.cpu()[rows], kr, 2, 0.06, atol=2 ** -6, what="k vs oracle")
+        assert_close_bf16(v1.cpu()[rows], vr.reshape(-1, nkv, hd), 1, 0.05, atol=2 ** -9, what="v vs oracle")
+    # below the tiled kernel's row count the caller keeps the two launches
+    assert ops.gemm_qkv_rope_store(dev(x[:32]), dev(w), dev(b), nh, nkv, hd, dev(pos[:32]), dev(cs), rd, None, None, None, True) is None
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_gemm_large_m_quadrant_loop_random_shapes(ops, seed):
     """Random ragged groupings (empty groups, single-row groups, partial row blocks and column tiles), random K in whole
