@@ -313,6 +313,7 @@ def main():
             cpu_base["c1"] = cpu_baseline_c1(hip_ops, dev, cpu_base["cores"])
         except Exception as e:  # noqa: BLE001 - a side leg never takes the headline line down
             cpu_base["c1"] = {"error": repr(e)[:200]}
+        set_context(False, slot_mapping=slot_mapping, context_lens=context_lens, block_tables=block_tables)  # the C1 leg reset it
 
     # ---- fp8 (e4m3, weight-only) experts on the same model, re-quantised in place: LAST, because the bf16 expert
     # stacks are released by the quantisation ----
@@ -320,6 +321,8 @@ def main():
         try:
             extra["fp8_experts"] = measure_fp8(model, cfg, hip_ops, step, B, ctx, L, args, dev)
         except Exception as e:  # noqa: BLE001 - an extra never takes the headline line down
+            import traceback
+            traceback.print_exc(file=sys.stderr)
             extra["fp8_experts"] = {"error": repr(e)[:200]}
 
     if rank == 0:
@@ -337,7 +340,9 @@ def main():
                        "global_batch": B, "seq_len": ctx, "layers": L,
                        "parallelism": f"tp{world}" + (f"+ep{world}" if getattr(cfg, "expert_parallel_size", 1) > 1 else ""),
                        "hip_graph": bool(use_graph), "hip_graph_note": graph_note,
-                       "ms_per_layer": round(ms_per_step / L, 4), "model_build_s": round(t_build, 1)},
+                       "ms_per_layer": round(ms_per_step / L, 4), "model_build_s": round(t_build, 1),
+                       # every launch-path switch of both sides, as read ONCE when the library was loaded
+                       "options": hip_ops.options()},
             "roofline": dom,
             "kernels": kernels,
             "extra": extra,
