@@ -7,7 +7,7 @@
 #   4. rocprofv3 kernel-trace stats of the C3 and the C2 decode loops (csv summaries only; traces stay in /tmp)
 # Copy gpurun_out/<r>/* into profiles/<r>/ afterwards.
 set -o pipefail
-RN=${1:-r03}
+RN=${1:-r04}
 R=$PWD
 OUT=$R/gpurun_out/$RN
 mkdir -p $OUT $R/profiles/$RN
