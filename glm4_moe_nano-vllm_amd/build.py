@@ -19,7 +19,7 @@ OBJ = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libglm4moe_hip.so")
 ARCH = "gfx950"
-SOURCES = ["api", "elementwise", "moe_misc", "paged_attn", "prefill_attn", "gemm_smallm", "gemm_tinym", "gemm_largem",
+SOURCES = ["api", "elementwise", "moe_misc", "paged_attn", "prefill_attn", "prefill_attn64", "gemm_smallm", "gemm_tinym", "gemm_largem",
            "oneshot_allreduce"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}",
          "-Wno-unused-result"]

@@ -140,6 +140,10 @@ __device__ __forceinline__ void glm_locate_block(const int32_t* __restrict__ off
 // Every switch a launch path consults lives in ONE table, filled from the environment ONCE (first use) and changed only
 // through glm_set_option: a launch never reads the environment, so a HIP graph and the eager launches around it cannot see
 // two different settings, and the effective set can be printed (bench.py puts it into its line's `config.options`).
-enum GlmOption { GLM_OPT_TINYM = 0, GLM_OPT_FP8W_NATIVE, GLM_OPT_LARGEM_VARIANT, GLM_OPT_LARGEM_CFG, GLM_OPT_FA_MFMA32, GLM_OPT_COUNT };
+enum GlmOption { GLM_OPT_TINYM = 0, GLM_OPT_FP8W_NATIVE, GLM_OPT_LARGEM_VARIANT, GLM_OPT_LARGEM_CFG, GLM_OPT_FA_MFMA32, GLM_OPT_FA_ROWS64, GLM_OPT_COUNT };
 int glm_option(int id);
+// prefill_attn64.hip: the 64-rows-per-wave prefill attention (arguments validated by glm_varlen_attn_prefill)
+int glm_launch_prefill_attn64(const void* q, const void* k, const void* v, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                              const int32_t* block_tables, int64_t bt_stride, void* out, int64_t B, int max_seqlen_q, int nh, int nkv,
+                              int block_size, float scale, hipStream_t st);
 

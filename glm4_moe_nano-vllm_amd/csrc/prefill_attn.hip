@@ -1340,6 +1340,9 @@ extern "C" int glm_varlen_attn_prefill(const void* q, const void* k, const void*
     // option fa_mfma32 = 1 (GLM_FA_MFMA32 at start-up, glm_set_option afterwards): the 32x32x16 kernel (same grid and workgroup shape as the default 16x16x32
     // kernel).  Parity green (test_varlen_attn_prefill_mfma32); measured r03, one box, interleaved processes: 746-754 against
     // 789-805 TFLOP/s at 4 x 4096 tokens, so it stays opt-in.
+    if (glm_option(GLM_OPT_FA_ROWS64) == 1)
+        return glm_launch_prefill_attn64(q, k, v, cu_seqlens_q, cu_seqlens_k, block_tables, bt_stride, out, B, max_seqlen_q, nh, nkv,
+                                         block_size, scale, glm_s(stream));
     const int o32 = glm_option(GLM_OPT_FA_MFMA32);
     const bool use32 = o32 == 1 || (o32 < 0 && FA_DEFAULT_MFMA32 == 1);
     if (use32 && FA_BQ == 128) {

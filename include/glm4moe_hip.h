@@ -48,7 +48,7 @@ const char* glm_last_error(void);
  * ONCE (at the first use) and changed only through glm_set_option: a launch never reads the environment, so a HIP graph and
  * the eager launches around it see one setting.  Names: "tinym" (GLM4MOE_TINYM), "fp8w_native" (GLM4MOE_FP8W_NATIVE),
  * "largem_variant" (GLM_LARGEM_VARIANT), "largem_cfg" (GLM_LARGEM_CFG: 0 by shape, 1 = A, 2 = B), "fa_mfma32"
- * (GLM_FA_MFMA32).  glm_option_name(i) enumerates them (NULL past the end).  The reference has no switches of its own on
+ * (GLM_FA_MFMA32), "fa_rows64" (GLM_FA_ROWS64: prefill attention with 64 query rows per wave).  glm_option_name(i) enumerates them (NULL past the end).  The reference has no switches of its own on
  * this path (its Config dataclass, config.py:6-26, holds engine sizes only).                                          */
 int         glm_get_option(const char* name, int* value);
 int         glm_set_option(const char* name, int value);

@@ -1009,6 +1009,37 @@ def test_varlen_attn_prefill_mfma32(ops, opt_guard, lens_q, lens_k, nh, nkv, pag
     assert_mixed(out, base, 1.6e-2, 4e-3, "32x32x16 kernel vs default kernel")
 
 
+@pytest.mark.parametrize("lens_q,lens_k,nh,nkv,paged", [
+    ([300, 17, 513, 64], [300, 17, 513, 64], 16, 4, False), ([100, 50], [612, 306], 16, 4, True),
+    ([1025], [1025], 12, 1, False), ([5, 40], [300, 296], 4, 2, True), ([33], [33], 8, 2, False),
+    ([2048, 700], [2048, 700], 8, 2, False), ([600], [1900], 4, 1, True), ([1], [1], 2, 1, False)])
+def test_varlen_attn_prefill_rows64(ops, opt_guard, lens_q, lens_k, nh, nkv, paged):
+    """The opt-in kernel with 64 query rows per wave (option fa_rows64, csrc/prefill_attn64.hip) against the oracle
+    (attention.py:59-75 = flash_attn_varlen_func, causal) on the varlen cases — ragged, chunked prefill over a paged cache,
+    and lengths whose key loop reaches the predicate-free interior tiles — and against the default kernel's output."""
+    g = torch.Generator().manual_seed(sum(lens_k) + nh)
+    hd, bs = 128, 256
+    q = torch.randn(sum(lens_q), nh, hd, generator=g).to(BF)
+    cu_q = torch.tensor([0] + list(torch.tensor(lens_q).cumsum(0)), dtype=torch.int32)
+    cu_k = torch.tensor([0] + list(torch.tensor(lens_k).cumsum(0)), dtype=torch.int32)
+    scale = hd ** -0.5
+    if paged:
+        _, kc, vc, _, bt = _paged_case(lens_k, nh, nkv, seed=5)
+        ref = O.attn_prefill_varlen(q, kc, vc, cu_q, cu_k, scale, bt)
+        run = lambda: ops.varlen_attn_prefill(dev(q), dev(kc), dev(vc), dev(cu_q), dev(cu_k), max(lens_q), scale, dev(bt), bs)
+    else:
+        k = torch.randn(sum(lens_k), nkv, hd, generator=g).to(BF)
+        v = torch.randn(sum(lens_k), nkv, hd, generator=g).to(BF)
+        ref = O.attn_prefill_varlen(q, k, v, cu_q, cu_k, scale)
+        run = lambda: ops.varlen_attn_prefill(dev(q), dev(k), dev(v), dev(cu_q), dev(cu_k), max(lens_q), scale)
+    base = run()
+    opt_guard("fa_rows64", 1)
+    out = run()
+    assert torch.isfinite(out.float()).all()
+    assert_mixed(out, ref, 1.6e-2, 4e-3, f"prefill attn (64 rows per wave) q={lens_q} k={lens_k}")
+    assert_mixed(out, base, 1.6e-2, 4e-3, "64-row kernel vs default kernel")
+
+
 def test_padded_weight_pitch(ops):
     """Row-padded weight storage behind [out, in] / [G, 2I, H] views gives identical results."""
     M, N, K = 32, 512, 4096

@@ -3,7 +3,8 @@ import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "glm4_moe_nano-vllm_amd"))
 from nanovllm import hip_ops as ops
-B, S, nh, nkv, hd = 4, 4096, 96, 8, 128
+B, S = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4, 4096)
+nh, nkv, hd = 96, 8, 128
 q = torch.randn(B * S, nh, hd, device="cuda").to(torch.bfloat16)
 k = torch.randn(B * S, nkv, hd, device="cuda").to(torch.bfloat16)
 v = torch.randn(B * S, nkv, hd, device="cuda").to(torch.bfloat16)
