@@ -56,6 +56,10 @@
 // made hipcc spill 520 registers.)  The r02 loop evaluated ~10 scalar predicates per
 // tile and rebuilt the 64-bit source address per staging slot: ~290 scalar instructions per tile and wave next to 68 MFMAs,
 // and a wave issues one instruction per ~4 cycles whatever its kind.  0 = the r02 loop (kept for A/B).
+#ifndef GLM_FA_EDGE
+#define GLM_FA_EDGE 0  // 1: unmasked tiles behind the strict interior range take a body without liveness / mask tests (2: the
+#endif                 // first tile as well).  Measured r04, one box, 3 rounds: 1655-1658 us against 1636 us without — not kept
+
 #ifndef GLM_FA_LOOP
 #define GLM_FA_LOOP 1
 #endif
@@ -369,7 +373,10 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
         // masking is only needed on slabs that touch the causal diagonal or the sequence end for this
         // query tile: the test is wave-uniform and false for almost every slab (and known false on an interior tile)
         const int row_first = qbase + (16 * FA_QT) * wid + 16 * qt;
-        const bool need_mask = ((GLM_FA_ABLATE & 64) || decltype(interior_c)::value)
+        // interior_c: 0 general tile, 1 unmasked tile (every key visible to every row of the wave), 2 strict interior tile
+        // (unmasked and not the wave's first tile)
+        constexpr int TK = (int)decltype(interior_c)::value;
+        const bool need_mask = ((GLM_FA_ABLATE & 64) || TK >= 1)
                                    ? false : (kbase + 31 > row_first + off || kbase + 31 >= lk);
         if (need_mask) {
 #pragma unroll
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
         float m_use = m_run[qt];
         // a query tile's first unit (keys 0..31) is either unmasked — it then sets the reference point of all 16 rows — or on
         // the causal diagonal, and then every later unit of the tile is masked or dead as well
-        const bool first_unit = decltype(interior_c)::value ? false : kbase == 0;
+        const bool first_unit = TK == 2 ? false : kbase == 0;
         bool slow0;
 #if GLM_FA_NOCHECK
         slow0 = need_mask || first_unit;  // TIMING STUDY: no overflow check at all
@@ -751,13 +758,14 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
         // and tiles t + 1, t + 2 are full tiles: the body has no scalar predicate at all.  Same schedule as the r02 loop:
         // per unit the S MFMAs of the next unit first, then LDS reads / staging, then softmax + PV of this unit.
         auto tile = [&](auto intc, int t) {
-            constexpr bool INT = decltype(intc)::value;
+            constexpr int TK = decltype(intc)::value;  // 0 general, 1 unmasked (all units live, staging conditions at run time), 2 strict interior
+            constexpr bool INT = TK == 2;
             const int BUF = t & 1;
             const int kb0 = t * FA_BK;
             const bool more = INT ? true : t + 1 < ntiles;
             const bool more2 = INT ? true : t + 2 < ntiles;
             const bool first = INT ? false : t < 1;
-            auto lv = [&](int kbase, int qt) -> bool { return INT ? true : live(kbase, qt); };
+            auto lv = [&](int kbase, int qt) -> bool { return TK >= 1 ? true : live(kbase, qt); };
             bf16x8_t pf;
             // ---- unit (slab 0, q0)
             if (lv(kb0, 1)) s_mfma(sb, 1);
@@ -836,12 +844,23 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
             asm volatile("" : "+s"(ksrc), "+s"(vsrc), "+s"(ksrc2), "+s"(vsrc2));
         };
         {
-            // strict interior range [1, n1): see `tile`
+            // strict interior range [1, n1): see `tile`.  GLM_FA_EDGE (study, off): the unmasked tiles on either side of it keep
+            // the run-time staging conditions but none of the per-unit liveness and mask tests.  (A two-shape fit of the r04
+            // timings — 1 x 16384 and 16 x 1024 — puts a workgroup's four non-interior tiles at 2.8 interior ones each, 28 % of
+            // the 4 x 4096 time; the predicates are not where that goes.)
+            using K0 = std::integral_constant<int, 0>;
+            using K1 = std::integral_constant<int, 1>;
+            using K2 = std::integral_constant<int, 2>;
             const int n1 = min(n_int, ntiles - 3);
             int t = 0;
-            if (ntiles > 0) tile(std::false_type{}, t++);
-            for (; t < n1; ++t) tile(std::true_type{}, t);
-            for (; t < ntiles; ++t) tile(std::false_type{}, t);
+            if (ntiles > 0) {
+                if (GLM_FA_EDGE == 2 && n_int >= 1) tile(K1{}, t++);  // (a third copy of the body in front of the loop: spills)
+                else tile(K0{}, t++);
+            }
+            for (; t < n1; ++t) tile(K2{}, t);
+            if (GLM_FA_EDGE)
+                for (; t < n_int; ++t) tile(K1{}, t);
+            for (; t < ntiles; ++t) tile(K0{}, t);
         }
 #undef FA_RK
 #undef FA_RV
