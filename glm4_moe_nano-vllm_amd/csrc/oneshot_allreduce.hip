@@ -39,6 +39,8 @@
 // across GPUs (one-GPU lease); RCCL stays the default (GLM_ONESHOT_ALLREDUCE=1 opts in).
 #include "common.h"
 #include <string.h>
+#include <mutex>
+#include <vector>
 
 namespace {
 constexpr int OS_MAX_WORLD = 8;
@@ -137,11 +139,37 @@ __global__ __launch_bounds__(256) void oneshot_allreduce_kernel(const bf16_t* in
 //   * the owner's loads of rbuf[rank][slot][q] behind the acquire fence (written by rank q's pushes);
 // the peers' stores themselves travel over the fabric either way.  The memory is exported / opened with hipIpc so that it
 // can be mapped by the other ranks' processes exactly like the torch storage it replaces.
+// Blocks handed back by glm_comm_free are kept for the life of the process and reused by glm_comm_alloc (same device, kind and
+// size) instead of going back to the runtime.  r04: with hipFree here, the GPU test suite saw STALE READS of ordinary cached
+// tensors later in the same process — 4-KiB pieces, by host copies and by kernels alike, gone once the caches had been evicted
+// (profiles/r04/c1_stale_readback.txt) — in every run that had allocated and freed MiB-sized uncached blocks before, and in none
+// that had not: pages that were mapped uncached come back to the allocator PyTorch draws its next segments from.
+// Communication buffers are long-lived objects anyway; a block never changes its mapping again this way.
+namespace {
+struct CommBlock { void* p; size_t bytes; int kind; int dev; };
+std::mutex g_comm_mu;
+std::vector<CommBlock> g_comm_free;   // parked blocks
+std::vector<CommBlock> g_comm_live;   // blocks handed out (to know size / kind / device at free time)
+}  // namespace
+
 extern "C" int glm_comm_alloc(void** ptr, size_t bytes, int kind) {
     GLM_CHECK_ARG(ptr && bytes > 0 && (kind == GLM_COMM_UNCACHED || kind == GLM_COMM_FINEGRAINED), GLM_ERR_INVALID,
                   "glm_comm_alloc: bad arguments");
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     void* p = nullptr;
-    hipError_t e = hipExtMallocWithFlags(&p, bytes, kind == GLM_COMM_UNCACHED ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
+    hipError_t e = hipSuccess;
+    {
+        std::lock_guard<std::mutex> lk(g_comm_mu);
+        for (size_t i = 0; i < g_comm_free.size(); ++i)
+            if (g_comm_free[i].bytes == bytes && g_comm_free[i].kind == kind && g_comm_free[i].dev == dev) {
+                p = g_comm_free[i].p;
+                g_comm_free.erase(g_comm_free.begin() + (long)i);
+                break;
+            }
+    }
+    const bool fresh = p == nullptr;
+    if (fresh) e = hipExtMallocWithFlags(&p, bytes, kind == GLM_COMM_UNCACHED ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
     if (e == hipSuccess) e = hipMemset(p, 0, bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
@@ -150,15 +178,25 @@ extern "C" int glm_comm_alloc(void** ptr, size_t bytes, int kind) {
         glm_set_error("glm_comm_alloc(%zu B, kind %d): %s", bytes, kind, hipGetErrorString(e));
         return GLM_ERR_LAUNCH;
     }
+    {
+        std::lock_guard<std::mutex> lk(g_comm_mu);
+        g_comm_live.push_back(CommBlock{p, bytes, kind, dev});
+    }
     *ptr = p;
     return GLM_OK;
 }
 
 extern "C" int glm_comm_free(void* ptr) {
     if (!ptr) return GLM_OK;
-    hipError_t e = hipFree(ptr);
-    GLM_CHECK_ARG(e == hipSuccess, GLM_ERR_LAUNCH, "glm_comm_free: %s", hipGetErrorString(e));
-    return GLM_OK;
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    for (size_t i = 0; i < g_comm_live.size(); ++i)
+        if (g_comm_live[i].p == ptr) {
+            g_comm_free.push_back(g_comm_live[i]);  // parked, not returned to the runtime (see above)
+            g_comm_live.erase(g_comm_live.begin() + (long)i);
+            return GLM_OK;
+        }
+    glm_set_error("glm_comm_free: %p was not allocated by glm_comm_alloc (or freed twice)", ptr);
+    return GLM_ERR_INVALID;
 }
 
 extern "C" int glm_comm_ipc_export(const void* ptr, void* handle) {

@@ -419,7 +419,10 @@ size_t glm_allreduce_oneshot_buffer_elems(int world, int64_t n_max);
  *     ordinary (coarse-grained, L2-cacheable) hipMalloc storage.  Host-only helpers, they synchronise and are not
  *     capturable: glm_comm_alloc = hipExtMallocWithFlags(uncached | fine-grained) + zero fill; the export / open pair
  *     maps it into the peers' processes (hipIpc; handle = GLM_COMM_IPC_HANDLE_BYTES opaque bytes, picklable) the way the
- *     reference's ranks share their POSIX shm segment (engine/model_runner.py:51-54 — control plane there, data here). */
+ *     reference's ranks share their POSIX shm segment (engine/model_runner.py:51-54 — control plane there, data here).
+ *     glm_comm_free PARKS the block for reuse by a later glm_comm_alloc of the same device, kind and size; it does not
+ *     hand it back to the runtime (r04: recycled uncached pages behind PyTorch's allocator gave stale reads of ordinary
+ *     tensors later in the process, profiles/r04/c1_stale_readback.txt).  Freeing a foreign pointer is GLM_ERR_INVALID. */
 #define GLM_COMM_UNCACHED           0
 #define GLM_COMM_FINEGRAINED        1
 #define GLM_COMM_IPC_HANDLE_BYTES  64

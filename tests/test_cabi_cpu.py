@@ -123,3 +123,19 @@ def test_one_token_fusions_refuse_two_rows():
     assert not hip_ops.can_combine_norm_gemm(hip_ops.DeferredCombine(y, pos, 2, 8, 16, (2, 64)), 64)
     assert hip_ops.can_gemm_router_tail(torch.zeros(1, 512, dtype=torch.bfloat16), 4096, 64)
     assert not hip_ops.can_gemm_router_tail(torch.zeros(2, 512, dtype=torch.bfloat16), 4096, 64)
+
+
+def test_asm_mfma_statements_have_no_compiler_placed_hazards():
+    """csrc/prefill_attn64.hip issues its MFMAs from inline asm, which the compiler's hazard recogniser cannot see: a register
+    copy it places right in front of one (VALU write of SrcC) or right behind one (VALU read of the result) silently corrupts
+    two of the four query tiles (seen on the chip in r04).  tools/check_mfma_hazards.py compiles the file to gfx950 ISA (no GPU
+    needed) and scans for both patterns."""
+    import shutil
+    import subprocess
+    import sys
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_mfma_hazards.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 findings" in r.stdout, r.stdout[-500:]

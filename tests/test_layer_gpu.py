@@ -236,14 +236,13 @@ def _evict_device_caches():
 
 
 def _stale_readback(check, what):
-    """Run `check()` (read-backs + asserts).  If it fails, evict the device caches and run it once more: r04 found that on this
-    platform a read-back of tensors a few hundred KiB large — device-to-host copy and gather / clone kernels alike — can
-    return 4-KiB pieces of the zero fill that preceded the kernel which wrote them, for as long as nothing evicts those
-    lines; the data itself is in memory (after touching 1 GiB every reader sees it).  Seen only for this test's shapes
-    (hidden 128: every tensor fits the L2s many times over) and only behind the other GPU test files; the evidence —
-    which launches, which pieces, the three readers before and after the eviction — is profiles/r04/c1_stale_readback.txt.
-    A second failure is a real one and propagates; a first failure healed by the eviction is recorded as a warning and
-    in gpurun_out/parity_fullsize.jsonl."""
+    """Run `check()` (read-backs + asserts); if it fails, evict the device caches and run it once more.  A tripwire left from
+    r04: read-backs of this test's few-hundred-KiB tensors — device-to-host copies and gather / clone kernels alike — returned
+    stale 4-KiB pieces until the caches were evicted, in every suite run that had hipFree'd MiB-sized UNCACHED blocks
+    (hipExtMallocWithFlags; the one-shot all-reduce tests) earlier in the process.  glm_comm_free no longer returns such blocks
+    to the runtime and the effect is gone (0 in 3 suite runs, 6 in 6 before); profiles/r04/c1_stale_readback.txt has the
+    evidence.  A second failure is a real one and propagates; a first failure healed by the eviction is recorded as a warning
+    and in gpurun_out/parity_fullsize.jsonl."""
     try:
         check()
         return False
