@@ -57,11 +57,29 @@ class EPExperts:
     with the reference arithmetic on CPU tensors); `w13`, `w2` are this rank's [E/ep, 2I, H] / [E/ep, H, I] stacks, `shared` a callable
     for the (replicated) shared expert."""
 
-    def __init__(self, ops, ep_size: int, rank: int, n_experts: int, top_k: int, w13, w2, shared):
+    def __init__(self, ops, ep_size: int, rank: int, n_experts: int, top_k: int, w13, w2, shared, fp8=None):
+        """fp8 (r04): (w13_q, w13_scale, w2_q, w2_scale) of this rank's experts — fp8 e4m3 weight-only stacks with per-row
+        fp32 scales (hip_ops.quantize_fp8_rowwise); the grouped GEMMs then stream those (w13 / w2 may be None)."""
         assert n_experts % ep_size == 0, "experts must divide over the expert-parallel ranks"
         self.ops, self.ep, self.rank, self.E, self.k = ops, ep_size, rank, n_experts, top_k
         self.El = n_experts // ep_size
-        self.w13, self.w2, self.shared = w13, w2, shared
+        self.w13, self.w2, self.shared, self.fp8 = w13, w2, shared, fp8
+
+    def _experts(self, rows, offs, gidx, n_rows: int, expected: int | None):
+        """This rank's experts over `rows` (grouped by `offs`, gathered through `gidx`): gate|up + SiLU*mul, then the
+        UNSCALED down projection (the routing weight is applied at the token's home rank).  expected: the fixed-capacity
+        form's row-count hint (None = exact rows)."""
+        ops = self.ops
+        if self.fp8 is not None:
+            # the fp8 launchers walk the groups through `offs` like the bf16 ones: rows past offs[El] are not touched
+            w13_q, w13_s, w2_q, w2_s = self.fp8
+            act = ops.grouped_gemm_gateup_silu_fp8w(rows, w13_q, w13_s, offs, gidx, n_rows)
+            return ops.grouped_gemm_down_fp8w(act, w2_q, w2_s, offs, None, 0)
+        if expected is not None:
+            act = ops.grouped_gemm_gateup_silu_cap(rows, self.w13, offs, gidx, n_rows, expected)
+            return ops.grouped_gemm_down_cap(act, self.w2, offs, expected)
+        act = ops.grouped_gemm_gateup_silu(rows, self.w13, offs, gidx, n_rows)
+        return ops.grouped_gemm_down(act, self.w2, offs, None, 0)
 
     FIXED_MAX_SLICE_PAIRS = 16384  # glm_ep_plan keeps a token slice's pairs in LDS
     # The fixed-capacity form exists for DECODE steps (graph buckets): every buffer has ep*cap rows whatever the routing.
@@ -170,8 +188,7 @@ class EPExperts:
         # 2. my experts over the received rows, in expert order through the gather list; rows beyond recv_offs[El] are
         #    not touched.  The kernel configuration is chosen for the expected row count (T k / ep), not for the capacity.
         expected = max(1, (T * k + ep - 1) // ep)
-        act = ops.grouped_gemm_gateup_silu_cap(recv, self.w13, recv_offs, recv_gidx, ep * cap, expected)
-        y = ops.grouped_gemm_down_cap(act, self.w2, recv_offs, expected)        # unscaled: the weight is applied at home
+        y = self._experts(recv, recv_offs, recv_gidx, ep * cap, expected)       # unscaled: the weight is applied at home
         back = ops.scatter_rows(y, recv_gidx, ep * cap, no_init=True)           # expert order -> arrival slots
         ret = yield ("all_to_all_fixed", back, cap)                             # slot d = my rows back from rank d
         # 3. routing weights, ascending-expert combine, shared expert; then everyone gets every slice
@@ -215,8 +232,7 @@ class EPExperts:
                      for e in range(El) for s in range(ep)]
             gidx = torch.cat(order).to(torch.int32).to(h.device)
             loffs = torch.cat([torch.zeros(1, dtype=torch.long), mine.long().sum(0).cumsum(0)]).to(torch.int32).to(h.device)
-            act = ops.grouped_gemm_gateup_silu(recv, self.w13, loffs, gidx, n_recv)
-            y = ops.grouped_gemm_down(act, self.w2, loffs, None, 0)           # unscaled: the weight is applied at home
+            y = self._experts(recv, loffs, gidx, n_recv, None)                # unscaled: the weight is applied at home
             back = ops.scatter_rows(y, gidx, n_recv)                          # expert order -> arrival order
         else:
             back = h.new_zeros((0, H))

@@ -78,8 +78,6 @@ class Glm4MoeMoE(nn.Module):
         self.expert_weight_dtype = getattr(config, "expert_weight_dtype", None)
         self._fp8 = None
         self._bf16_freed = False
-        if self.ep_size > 1 and self.expert_weight_dtype is not None:
-            raise NotImplementedError("expert parallelism runs the bf16 expert stacks; fp8 experts + EP is not built")
 
     # ---- stacked expert storage ---------------------------------------------------------
     def _mlps(self):
@@ -150,12 +148,25 @@ class Glm4MoeMoE(nn.Module):
         if self.expert_weight_dtype == "fp8_e4m3":  # per layer, right after loading: the bf16 peak is ONE layer's stack
             self.quantize_experts_fp8()
 
-    def _ep_experts(self, ops=hip_ops, rank: int | None = None):
-        w13, w2 = self._stacked()
+    def _shared_fp8(self, h: torch.Tensor) -> torch.Tensor:
+        """The (replicated) shared expert from its fp8 rows of the stack — one group, no gather, unscaled."""
+        w13_q, w13_s, w2_q, w2_s = self._fp8
         El = len(self.experts)
-        return EP.EPExperts(ops, self.ep_size, get_tp_group().rank if rank is None else rank,
-                            self.config.n_routed_experts, self.config.num_experts_per_tok, w13[:El], w2[:El],
-                            self.shared_experts)
+        act = hip_ops.grouped_gemm_gateup_silu_fp8w(h, w13_q[El:El + 1], w13_s[El:El + 1], None, None, h.shape[0])
+        return hip_ops.grouped_gemm_down_fp8w(act, w2_q[El:El + 1], w2_s[El:El + 1], None, None, 0)
+
+    def _ep_experts(self, ops=hip_ops, rank: int | None = None):
+        El = len(self.experts)
+        r = get_tp_group().rank if rank is None else rank
+        E, k = self.config.n_routed_experts, self.config.num_experts_per_tok
+        if self.expert_weight_dtype == "fp8_e4m3":  # r04: this rank's experts (and the shared one) as fp8 e4m3 weight-only
+            if self._fp8 is None:
+                self.quantize_experts_fp8()
+            w13_q, w13_s, w2_q, w2_s = self._fp8
+            return EP.EPExperts(ops, self.ep_size, r, E, k, None, None, self._shared_fp8,
+                                fp8=(w13_q[:El], w13_s[:El], w2_q[:El], w2_s[:El]))
+        w13, w2 = self._stacked()
+        return EP.EPExperts(ops, self.ep_size, r, E, k, w13[:El], w2[:El], self.shared_experts)
 
     # ---- forward ------------------------------------------------------------------------
     def forward(self, hidden_states: torch.Tensor, routing=None, defer_combine: bool = False, aligned=None):

@@ -96,6 +96,32 @@ def grouped_gemm_down(act, w2, offs, scale, n_scaled):
     return y
 
 
+def grouped_gemm_gateup_silu_fp8w(x, w13_q, w13_s, offs, src_idx, R):
+    """fp8 e4m3 weight-only experts (oracle arithmetic: fp32 accumulation, row scale on the sum, one rounding)."""
+    I = w13_q.shape[1] // 2
+    act = torch.zeros((R, I), dtype=x.dtype)
+    if offs is None:  # one group over all rows (the shared expert)
+        return O.silu_and_mul(O.linear_fp8w(x, w13_q[0], w13_s[0]))
+    for g in range(w13_q.shape[0]):
+        lo, hi = int(offs[g]), int(offs[g + 1])
+        if hi > lo:
+            rows = x[src_idx[lo:hi].long()] if src_idx is not None else x[lo:hi]
+            act[lo:hi] = O.silu_and_mul(O.linear_fp8w(rows, w13_q[g], w13_s[g]))
+    return act
+
+
+def grouped_gemm_down_fp8w(act, w2_q, w2_s, offs, scale, n_scaled):
+    assert n_scaled == 0
+    if offs is None:
+        return O.linear_fp8w(act, w2_q[0], w2_s[0])
+    y = torch.zeros((act.shape[0], w2_q.shape[1]), dtype=act.dtype)
+    for g in range(w2_q.shape[0]):
+        lo, hi = int(offs[g]), int(offs[g + 1])
+        if hi > lo:
+            y[lo:hi] = O.linear_fp8w(act[lo:hi], w2_q[g], w2_s[g])
+    return y
+
+
 def grouped_gemm_gateup_silu_cap(x, w13, offs, src_idx, R_cap, R_expected):
     return grouped_gemm_gateup_silu(x, w13, offs, src_idx, R_cap)
 

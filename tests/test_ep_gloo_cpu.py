@@ -69,6 +69,27 @@ def _worker(rank, world, port, q):
             gathered = [torch.empty_like(out) for _ in range(world)]
             dist.all_gather(gathered, out)
             assert all(torch.equal(gathered[0], t) for t in gathered)
+        # ---- fp8 e4m3 weight-only experts under expert parallelism (r04): each rank streams its own quantised stack, the shared
+        # expert comes from its quantised rows; against the oracle's fp8 block on the same bytes and scales ----
+        for fixed in (True, False):
+            ep_cpu_ops.ep_fixed = fixed
+            T, E, k, H, I, seed = 12, 8, 2, 64, 32, 21
+            x, w13, w2, gate_w, bias = _case(T, E, k, H, I, seed)
+            idx, w = O.router(x, gate_w, bias, k, 1.0)
+            idx = torch.sort(idx, dim=1)[0]
+            _, scores, _ = O.router_scores(x, gate_w, bias)
+            sw = scores.gather(1, idx)
+            w = sw / (sw.sum(dim=-1, keepdim=True) + 1e-20)
+            q13, s13 = O.quantize_fp8_rowwise(w13)
+            q2, s2 = O.quantize_fp8_rowwise(w2)
+            El = E // world
+            sl = slice(rank * El, (rank + 1) * El)
+            shared8 = lambda hh: O.mlp_fp8w(hh, q13[E], s13[E], q2[E], s2[E])
+            ex = EP.EPExperts(ep_cpu_ops, world, rank, E, k, None, None, shared8, fp8=(q13[sl], s13[sl], q2[sl], s2[sl]))
+            out = EP.run(ex.forward(x, idx, w))
+            ref = O.moe_fp8w(x, k, idx, w, q13[:E], s13[:E], q2[:E], s2[:E], q13[E], s13[E], q2[E], s2[E])
+            err = (out.float() - ref.float()).abs().max()
+            assert float(err) <= 2 ** -6 * float(ref.float().abs().max()), f"fp8 experts under EP (fixed={fixed}): max err {float(err)}"
         # ---- tight capacity (r04): cap = f x mean rows per slot; a slot that does not fit is reported by the plan's overflow
         # word (same value on every rank), the step is redone with exact splits — what ModelRunner.run does ----
         ep_cpu_ops.ep_fixed = True

@@ -1212,6 +1212,55 @@ def test_expert_parallel_emulated_equals_single_gpu(ops, ep, T, E, k, H, I):
     assert_mixed(outs[0], ref, 2 ** -6, 2 ** -6 * float(ref.float().abs().max()), "expert-parallel vs oracle")
 
 
+@pytest.mark.parametrize("ep,T,E,k,H,I", [(2, 32, 8, 2, 512, 128), (4, 37, 16, 4, 256, 192), (8, 5, 64, 8, 4096, 1408)])
+def test_expert_parallel_fp8_experts_emulated(ops, ep, T, E, k, H, I):
+    """r04 (missing #4): fp8 e4m3 weight-only experts UNDER expert parallelism — ep logical ranks on one device,
+    each streaming its own fp8 expert stack (and the replicated shared expert from its fp8 rows), both dispatch forms —
+    against the single-GPU fp8 MoE block (same quantised weights; single bf16 ulps where a rank's row count selects another
+    K-split of the streaming GEMM) and against the oracle on the DEQUANTISED weights (the N4 bar)."""
+    from nanovllm.distributed import expert_parallel as EP
+    x = rnd(T, H, seed=311)
+    w13, w2 = rnd(E + 1, 2 * I, H, seed=312, scale=H ** -0.5), rnd(E + 1, H, I, seed=313, scale=I ** -0.5)
+    g = torch.Generator().manual_seed(314)
+    idx = torch.stack([torch.randperm(E, generator=g)[:k].sort()[0] for _ in range(T)]).to(torch.int64)
+    w = (torch.rand(T, k, generator=g) + 0.1).to(BF)
+    xd = dev(x)
+    w13_q, w13_s = ops.quantize_fp8_rowwise(dev(w13))
+    w2_q, w2_s = ops.quantize_fp8_rowwise(dev(w2))
+    # single-GPU fp8 block
+    offs, tok, scale, pos = ops.moe_align(dev(idx), dev(w), E, True)
+    R = T * k + T
+    act = ops.grouped_gemm_gateup_silu_fp8w(xd, w13_q, w13_s, offs, tok, R)
+    y = ops.grouped_gemm_down_fp8w(act, w2_q, w2_s, offs, scale, E)
+    ref_dev = ops.moe_combine(y, pos, T, k, T * k)
+    El = E // ep
+
+    def shared(hh):
+        a = ops.grouped_gemm_gateup_silu_fp8w(hh, w13_q[E:E + 1], w13_s[E:E + 1], None, None, hh.shape[0])
+        return ops.grouped_gemm_down_fp8w(a, w2_q[E:E + 1], w2_s[E:E + 1], None, None, 0)
+    both = []
+    for form in ("forward_fixed", "forward_varlen"):
+        gens = [getattr(EP.EPExperts(ops, ep, r, E, k, None, None, shared,
+                                     fp8=(w13_q[r * El:(r + 1) * El], w13_s[r * El:(r + 1) * El],
+                                          w2_q[r * El:(r + 1) * El], w2_s[r * El:(r + 1) * El])), form)
+                (xd, dev(idx), dev(w)) for r in range(ep)]
+        outs = EP.run_emulated(gens)
+        for o in outs:
+            assert torch.equal(o, outs[0])
+        both.append(outs[0])
+    if not torch.equal(both[0], both[1]):
+        # the fp8 launchers have no row-count hint: the capacity-sized row array of the fixed form may select another K-split
+        # of the streaming GEMM than the exact rows of the variable form (another fp32 summation order)
+        assert_close_bf16(both[0], both[1], 2, 0.05, atol=2 ** -5, what="fp8 experts: fixed-capacity vs variable-split dispatch")
+    if not torch.equal(outs[0], ref_dev):
+        assert_close_bf16(outs[0], ref_dev, 2, 0.05, atol=2 ** -5, what="fp8 experts, expert-parallel vs single-GPU kernels")
+    # oracle on the product's own fp8 bytes and scales (what the fp8 block is specified against: weight-only, bf16 arithmetic)
+    q13, s13 = w13_q.cpu().contiguous().view(torch.float8_e4m3fn), w13_s.cpu()
+    q2, s2 = w2_q.cpu().contiguous().view(torch.float8_e4m3fn), w2_s.cpu()
+    ref = O.moe_fp8w(x, k, idx, w, q13[:E], s13[:E], q2[:E], s2[:E], q13[E], s13[E], q2[E], s2[E])
+    assert_mixed(outs[0], ref, 2 ** -6, 2 ** -6 * float(ref.float().abs().max()), "fp8 experts, expert-parallel vs oracle")
+
+
 @pytest.mark.parametrize("T,E,k,ep", [(256, 64, 8, 8), (33, 64, 8, 4), (1, 8, 2, 2), (7, 128, 8, 8), (64, 16, 4, 2)])
 def test_ep_plan_kernel_equals_restatement(ops, T, E, k, ep):
     """glm_ep_plan (one workgroup, device-side plan of the fixed-capacity dispatch) == its Python restatement
