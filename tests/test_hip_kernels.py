@@ -1401,6 +1401,38 @@ def test_oneshot_allreduce_world1_and_two_streams(ops):
         assert torch.equal(x0, exp) and torch.equal(x1, exp)
 
 
+def test_comm_blocks_are_parked_not_freed(ops):
+    """glm_comm_free parks a block for the next glm_comm_alloc of the same device, kind and size instead of returning it to
+    the runtime (r04: hipFree'd MiB-sized uncached blocks made ordinary tensors allocated afterwards read stale,
+    profiles/r04/c1_stale_readback.txt): the same pointer comes back, zero-filled; a pointer the library did not hand out is
+    refused."""
+    import ctypes
+    from nanovllm.distributed.oneshot_allreduce import CommBuffer
+    lib = ops.load_library()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    d2d = 3  # hipMemcpyDeviceToDevice
+    a = CommBuffer(3 << 20, "cuda:0")
+    pa = a.data_ptr()
+    ones = torch.arange(1, 17, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    assert hip.hipMemcpy(pa, ones.data_ptr(), 64, d2d) == 0        # dirty the block
+    a.close()
+    b_ = CommBuffer(3 << 20, "cuda:0")
+    assert b_.data_ptr() == pa, "a parked block of the same size must be reused"
+    probe = torch.full((16,), 7, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    assert hip.hipMemcpy(probe.data_ptr(), b_.data_ptr(), 64, d2d) == 0
+    torch.cuda.synchronize()
+    assert not bool(probe.any()), "a reused block is zero-filled like a fresh one"
+    c_ = CommBuffer(1 << 20, "cuda:0")
+    assert c_.data_ptr() != pa
+    b_.close()
+    c_.close()
+    rc = lib.glm_comm_free(ctypes.c_void_p(probe.data_ptr()))
+    assert rc == -1 and b"not allocated by glm_comm_alloc" in lib.glm_last_error()  # GLM_ERR_INVALID
+
+
 def test_oneshot_allreduce_missing_peer_is_loud(ops):
     """A peer that never arrives: the bounded wait expires, the output is NaN (never stale data), status names the rank,
     check() raises — and the epoch still advances so a later call pairs up again."""
