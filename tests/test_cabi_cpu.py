@@ -139,3 +139,19 @@ def test_asm_mfma_statements_have_no_compiler_placed_hazards():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_mfma_hazards.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 findings" in r.stdout, r.stdout[-500:]
+    # and the checker does see both patterns (the sequences the failing r04 build contained)
+    bad = (
+        "\tv_mov_b64_e32 v[46:47], v[16:17]\n"
+        "\tv_mov_b64_e32 v[44:45], v[14:15]\n"
+        "\tv_mfma_f32_16x16x32_bf16 v[44:47], v[2:5], v[48:51], v[44:47]\n"
+        "\tv_mov_b64_e32 v[14:15], v[44:45]\n"
+        "\ts_endpgm\n")
+    f = tmp_isa = os.path.join(root, "gpurun_out", "_hazard_selftest.s")
+    os.makedirs(os.path.dirname(f), exist_ok=True)
+    with open(f, "w") as fh:
+        fh.write(bad)
+    try:
+        r2 = subprocess.run([sys.executable, os.path.join(root, "tools", "check_mfma_hazards.py"), tmp_isa], capture_output=True, text=True)
+    finally:
+        os.remove(f)
+    assert r2.returncode == 1 and "(a) VALU write" in r2.stdout and "(b) v_mov_b64_e32" in r2.stdout, r2.stdout
