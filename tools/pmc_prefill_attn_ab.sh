@@ -1,5 +1,6 @@
 #!/bin/bash
-# PMC passes over BOTH prefill attention kernels (default 16x16x32 loop, opt-in 32x32x16 kernel) at 4 x 4096 tokens:
+# PMC passes over TWO prefill attention kernels at 4 x 4096 tokens — the default loop (k0) and an opt-in one (k1) selected by the
+# environment variable named in PMC_FA_KNOB (default GLM_FA_MFMA32 = the 32x32x16 kernel; r04: GLM_FA_ROWS64 = 64 rows per wave):
 # wave-cycle buckets, matrix-pipe busy, VALU / LDS instruction activity, LDS bank conflicts.  Each pass is its own rocprofv3
 # run with --kernel-trace only.   bash tools/pmc_prefill_attn_ab.sh  ->  gpurun_out/pmc_fa_ab/summary.txt
 set -e
@@ -8,8 +9,10 @@ export TMPDIR=/tmp
 OUT=$R/gpurun_out/pmc_fa_ab
 mkdir -p $OUT
 cd /tmp
+KNOB=${PMC_FA_KNOB:-GLM_FA_MFMA32}
+LABEL=${PMC_FA_LABEL:-32x32x16 (opt-in)}
 for k in 0 1; do
-  export GLM_FA_MFMA32=$k
+  export $KNOB=$k
   for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
              "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
@@ -27,7 +30,7 @@ for f in glob.glob("$OUT/k*/*/*counter_collection.csv"):
         if "prefill_attn" in r["Kernel_Name"]:
             tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
 names = sorted(set(tot["k0"]) | set(tot["k1"]))
-print(f"{'counter (average per launch)':34s} {'16x16x32 (default)':>20s} {'32x32x16 (opt-in)':>20s}")
+print(f"{'counter (average per launch)':34s} {'default kernel':>20s} {'$LABEL':>20s}")
 for c in names:
     a = tot["k0"][c] / max(1, n["k0"][c]); b = tot["k1"][c] / max(1, n["k1"][c])
     print(f"{c:34s} {a:20.4g} {b:20.4g}")
