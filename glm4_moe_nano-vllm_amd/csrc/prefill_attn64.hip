@@ -23,6 +23,12 @@
 // every LDS read is issued one step before its first use.  Scheduling fences pin the order (inline asm is opaque to hipcc).
 // Arithmetic, rounding points, lazy maximum, masking rules, work order are the 32-row kernel's: same results up to the
 // order of the fp32 sums inside the MFMAs (identical) — the parity tests are shared.
+//
+// STATUS (r04): parity green (test_varlen_attn_prefill_rows64), OPT-IN (option fa_rows64) and SLOWER than the 32-row kernel —
+// 0.32 against 0.40 of the bf16 MFMA peak at 4 x 4096 tokens, 0.41 against 0.45 at 1 x 16384.  One wave per SIMD can issue one
+// ordinary VALU instruction in an MFMA's shadow for free, but a softmax needs an fma AND an exp2 per S MFMA (8.5 + 4.5 + 8.6
+// cycles against the pipe's 16.5; tools/mfma_valu_probe.hip), and one workgroup per CU has nothing to overlap its start and
+// end with.  Measurements, ablations and what was tried: profiles/r04/prefill_attn64_ab.txt, DESIGN.md 4.3.
 #include "common.h"
 #include "gemm_internal.h"
 #include <type_traits>
