@@ -231,8 +231,11 @@ def main():
     # captured (rehearsed on one GPU by tools/tp_graph_rehearsal.py; an eager TP step needs ~0.19 ms of host time
     # per layer, more than its GPU time at TP>=4); the lm_head gather stays eager.  Ranks agree on the outcome,
     # and any failure falls back to eager on every rank.
+    from nanovllm.distributed.parallel_state import get_tp_group
+    get_tp_group().reset_counters()
     step()
     torch.cuda.synchronize()
+    collective = collective_record(get_tp_group(), world, dev) if world > 1 else None
     use_graph = not args.no_graph and (world == 1 or tp_graph_ok)
     whole = world == 1 and not args.graph_body_only
     graph_note = tp_graph_note
@@ -326,7 +329,8 @@ def main():
             extra["fp8_experts"] = {"error": repr(e)[:200]}
 
     if rank == 0:
-        attach_pmc_traffic(kernels)
+        attach_pmc_traffic(kernels, {"world": world, "emulate_tp": args.emulate_tp,
+                                     "expert_parallel": bool(args.expert_parallel and world > 1)})
         dom = kernels.get("grouped_gemm_gateup_silu")
         line = {
             "metric": ("decode tokens/sec/GPU GLM-4-MoE bs=32 seq=4096; grouped-GEMM MFMA util %" if args.emulate_tp == 1 else
@@ -348,6 +352,8 @@ def main():
             "extra": extra,
             "cpu_baseline": cpu_base,
         }
+        if collective is not None:
+            line["collective"] = collective
         print(json.dumps(line))
     if world > 1:
         dist.barrier()  # ranks > 0 wait here while rank 0 finishes its per-kernel measurements
@@ -420,13 +426,49 @@ def measure_c2(model, cfg, kv, dev, L, bs, fp8, steps=30, warmup=5):
             "bytes_model": "QKV + O + router + (k+1) experts x 3*I*H + KV read, per MoE layer (BASELINE.md §3 at bs=1)"}
 
 
-def attach_pmc_traffic(kernels: dict) -> None:
+def collective_record(tp, world: int, dev) -> dict:
+    """What the collectives of ONE eager step were, from the live process group — so that an N > 1 line proves the
+    backend saw N ranks: every rank all-reduces a one (sum must be N) and all-gathers its own view of the world size;
+    the call and byte counts are the TP coordinator's own counters over the step that has just run (all-reduce sites:
+    layers/linear.py:153-154 of the reference, o_proj and the MLP / MoE down projection of every layer, plus the
+    vocabulary-parallel embedding).  Collective: every rank must call it."""
+    one = torch.ones(1, dtype=torch.int32, device=dev)
+    dist.all_reduce(one, group=tp.process_group)
+    mine = torch.tensor([dist.get_world_size(tp.process_group), dist.get_rank(tp.process_group), int(one.item())],
+                        dtype=torch.int32, device=dev)
+    seen = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(seen, mine, group=tp.process_group)
+    views = [[int(v) for v in s.tolist()] for s in seen]
+    return {"backend": dist.get_backend(tp.process_group), "world": dist.get_world_size(tp.process_group),
+            "allreduce_per_step": int(tp.calls), "bytes_per_allreduce": int(tp.bytes_max),
+            "allreduce_bytes_per_step": int(tp.bytes_total), "oneshot": bool(tp.calls_oneshot),
+            "oneshot_calls_per_step": int(tp.calls_oneshot),
+            # per rank: [world size it sees, its rank, sum of ones over the group] — all three must say N / r / N
+            "rccl_world_per_rank": views,
+            "ranks_agree": all(v[0] == world and v[2] == world for v in views) and sorted(v[1] for v in views) == list(range(world)),
+            "measured_on_hardware_note": "filled from the live group of THIS run; with GLM_BENCH_BACKEND=gloo it is a rehearsal"}
+
+
+def _pmc_parallelism(meta: dict) -> dict:
+    """The parallelism a PMC summary was taken at: recorded in `_meta.parallelism` since r05; older files carry only the
+    command line, from which the same three facts are read."""
+    if "parallelism" in meta:
+        return meta["parallelism"]
+    cmd = (meta.get("command") or "").split()
+
+    def flag(name, default):
+        return int(cmd[cmd.index(name) + 1]) if name in cmd and cmd.index(name) + 1 < len(cmd) else default
+    return {"world": flag("--gpus", 1), "emulate_tp": flag("--emulate-tp", 1), "expert_parallel": "--expert-parallel" in cmd}
+
+
+def attach_pmc_traffic(kernels: dict, parallelism: dict | None = None) -> None:
     """`traffic` = HBM bytes per launch from the PMC counters.  The counters need their own `rocprofv3 --pmc` passes
     (FETCH_SIZE and WRITE_SIZE cannot share a pass, and a profiled run is not a timed run), so they come from the
     newest committed summary under profiles/ (tools/pmc_traffic.sh, same workload, TP=1).  The summary records the
     digest of the kernel sources it was taken with; it is attached only when that digest equals the digest of the
-    sources of THIS run, together with the file's git blob id and the commit that last touched it — otherwise
-    `traffic` stays null and `traffic_note` says why."""
+    sources of THIS run AND the parallelism recorded there (`_meta.parallelism`: world, emulate_tp, expert_parallel) is this
+    run's — a TP = N rank launches other shapes than the TP = 1 run the counters saw —, together with the file's git blob id
+    and the commit that last touched it; otherwise `traffic` stays null and `traffic_note` says why."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
     if not files:
@@ -437,13 +479,18 @@ def attach_pmc_traffic(kernels: dict) -> None:
     rel = os.path.relpath(files[-1], ROOT)
     now = _kernel_source_digest()
     fresh = meta.get("kernel_source_digest") == now
+    parallelism = parallelism or {"world": 1, "emulate_tp": 1, "expert_parallel": False}
+    pmc_par = _pmc_parallelism(meta)
+    same_shapes = all(pmc_par.get(k) == parallelism.get(k) for k in ("world", "emulate_tp", "expert_parallel"))
     src = {"file": rel, "git_blob": _git("hash-object", files[-1]), "git_commit": _git("log", "-1", "--format=%h", "--", rel),
            "kernel_source_digest": meta.get("kernel_source_digest"), "this_run_digest": now}
     for name, rec in kernels.items():
         if name in pmc and (rec.get("bound") == "hbm" or "hbm_bytes_corrected" in pmc[name]):
-            if fresh:
+            if fresh and same_shapes:
                 rec["traffic"] = pmc[name]["hbm_bytes_corrected"]
                 rec["traffic_source"] = src
+            elif fresh:  # per-rank kernel shapes differ (TP = N halves ... the intermediate size): not this run's bytes
+                rec["traffic_note"] = f"{rel} was taken at {pmc_par}, this run is {parallelism}: not attached"
             else:
                 rec["traffic_note"] = f"{rel} was taken with other kernel sources ({src['kernel_source_digest']} != {now})"
 

@@ -19,8 +19,11 @@ OBJ = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libglm4moe_hip.so")
 ARCH = "gfx950"
-SOURCES = ["api", "elementwise", "moe_misc", "paged_attn", "prefill_attn", "prefill_attn64", "gemm_smallm", "gemm_tinym", "gemm_largem",
+SOURCES = ["api", "elementwise", "moe_misc", "paged_attn", "prefill_attn", "gemm_smallm", "gemm_tinym", "gemm_largem",
            "oneshot_allreduce"]
+# kernels that were measured against the shipped ones and lost: only in the study library (`--study`), with their tests
+STUDY_SOURCES = ["prefill_attn64"]
+STUDY_TAG = "_study"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}",
          "-Wno-unused-result"]
 
@@ -51,13 +54,14 @@ def _compile(name: str, force: bool, extra=(), tag: str = "") -> str:
     return obj
 
 
-def build_variant(tag: str, defines: list[str]) -> str:
+def build_variant(tag: str, defines: list[str], sources=None) -> str:
     """Timing-only variant library lib/libglm4moe_hip<tag>.so with extra -D flags (ablations)."""
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     extra = [f"-D{d}" for d in defines]
-    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
-        objs = list(ex.map(lambda n: _compile(n, True, extra, tag), SOURCES))
+    sources = sources or (SOURCES + STUDY_SOURCES if any(d.startswith("GLM_STUDY_KERNELS=1") for d in defines) else SOURCES)
+    with ThreadPoolExecutor(max_workers=min(8, len(sources))) as ex:
+        objs = list(ex.map(lambda n: _compile(n, True, extra, tag), sources))
     out = os.path.join(LIBDIR, f"libglm4moe_hip{tag}.so")
     r = subprocess.run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out, *objs],
                        capture_output=True, text=True)
@@ -84,8 +88,15 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_study() -> str:
+    """lib/libglm4moe_hip_study.so: the product sources + the measured-and-lost kernels (options fa_mfma32, fa_rows64)."""
+    return build_variant(STUDY_TAG, ["GLM_STUDY_KERNELS=1"])
+
+
 if __name__ == "__main__":
-    if "--variant" in sys.argv:  # python build.py --variant _abl1 GLM_ABLATE=1
+    if "--study" in sys.argv:
+        print(build_study())
+    elif "--variant" in sys.argv:  # python build.py --variant _abl1 GLM_ABLATE=1
         i = sys.argv.index("--variant")
         print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
     else:

@@ -142,7 +142,13 @@ __device__ __forceinline__ void glm_locate_block(const int32_t* __restrict__ off
 // two different settings, and the effective set can be printed (bench.py puts it into its line's `config.options`).
 enum GlmOption { GLM_OPT_TINYM = 0, GLM_OPT_FP8W_NATIVE, GLM_OPT_LARGEM_VARIANT, GLM_OPT_LARGEM_CFG, GLM_OPT_FA_MFMA32, GLM_OPT_FA_ROWS64, GLM_OPT_COUNT };
 int glm_option(int id);
-// prefill_attn64.hip: the 64-rows-per-wave prefill attention (arguments validated by glm_varlen_attn_prefill)
+// Kernels that were built, measured against the shipped ones and LOST (r03: prefill attention on 32x32x16 MFMAs; r04: prefill
+// attention with 64 query rows per wave) are compiled into the STUDY library only (`build.py --study` ->
+// lib/libglm4moe_hip_study.so, -DGLM_STUDY_KERNELS=1); in the product library their options answer GLM_ERR_UNSUPPORTED.
+#ifndef GLM_STUDY_KERNELS
+#define GLM_STUDY_KERNELS 0
+#endif
+// prefill_attn64.hip (study build): the 64-rows-per-wave prefill attention (arguments validated by glm_varlen_attn_prefill)
 int glm_launch_prefill_attn64(const void* q, const void* k, const void* v, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
                               const int32_t* block_tables, int64_t bt_stride, void* out, int64_t B, int max_seqlen_q, int nh, int nkv,
                               int block_size, float scale, hipStream_t st);

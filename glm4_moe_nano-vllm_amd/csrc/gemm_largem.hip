@@ -1121,9 +1121,9 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         constexpr int NOUT = MODE == GEMM_GATEUP ? 2 : 4;  // 16-column output tiles per wave
         const int ncol_w = MODE == GEMM_GATEUP ? ntile_c * 128 + wn * 32 : ntile_c * LM_BN + wn * 64;
         const bool scaled = MODE == GEMM_DOWN && grp_c < p.n_scaled;
-        const bool do_park = PARK && more && nk >= PARK_N;  // the next tile's K loop has a K tile for every parked store
         bool qkv_epi = false;
         if constexpr (MODE == GEMM_PLAIN && WIDE && !WSCALE) qkv_epi = p.qkv_q != nullptr;
+        const bool do_park = PARK && more && nk >= PARK_N && !qkv_epi;  // the next tile's K loop has a K tile for every parked store
         if (qkv_epi) {
             // ---- QKV epilogue (r04): bias, bf16 rounding (the packed qkv value of the reference, linear.py:75), rotary on the
             // first 64 dims of every q / k head, split, cache scatter.  A wave's 64 columns are one half of one head (ncol_w
@@ -1382,7 +1382,9 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
         }
     }
     if (!lean_ok) var = 0;
-    if (p.qkv_q != nullptr && ((var & LM_WIDEST) == 0 || p.wscale != nullptr)) {  // 16-byte-store form, bf16 weights only
+    // the QKV epilogue does all its stores itself: a variant that parks part of a tile's stores for the next tile's K loop
+    // would flush never-written LDS through p.y (= qkv_q, another row pitch) — refused, not silently wrong
+    if (p.qkv_q != nullptr && ((var & LM_WIDEST) == 0 || (var & LM_PARK) != 0 || p.wscale != nullptr)) {  // 16-byte-store form, bf16 weights only
         glm_set_error("gemm_largem(qkv epilogue): loop variant %d has no such epilogue", var);
         return GLM_ERR_UNSUPPORTED;
     }
@@ -1447,7 +1449,7 @@ int glm_launch_gemm_largem_qkv(const GemmParams& p, hipStream_t st) {
     if (p.qkv_q == nullptr || p.N != Nexp || p.offs != nullptr || p.K % 64 != 0 || p.R < 1 || p.ldx % 8 != 0 || p.ldw % 8 != 0 ||
         !glm_aligned16(p.x) || !glm_aligned16(p.w) || !glm_aligned16(p.qkv_q) || !glm_aligned16(p.qkv_cs) ||
         (p.qkv_k && !glm_aligned16(p.qkv_k)) || (p.qkv_v && !glm_aligned16(p.qkv_v)) || (p.qkv_kc && !glm_aligned16(p.qkv_kc)) ||
-        (p.qkv_vc && !glm_aligned16(p.qkv_vc)) || p.R * p.ldx * 2 >= (1ll << 31) || (int64_t)p.N * p.ldw * 2 >= (1ll << 31)) {
+        (p.qkv_vc && !glm_aligned16(p.qkv_vc)) || (p.bias && (((uintptr_t)p.bias) & 7) != 0) || p.R * p.ldx * 2 >= (1ll << 31) || (int64_t)p.N * p.ldw * 2 >= (1ll << 31)) {
         glm_set_error("gemm_largem(qkv epilogue): shape not covered (R=%ld N=%d K=%d)", (long)p.R, p.N, p.K);
         return GLM_ERR_UNSUPPORTED;
     }

@@ -38,6 +38,7 @@
 // IPC under HIP-graph replay with an odd number of calls per graph (tools/oneshot_allreduce_2proc.py).  It has NOT run
 // across GPUs (one-GPU lease); RCCL stays the default (GLM_ONESHOT_ALLREDUCE=1 opts in).
 #include "common.h"
+#include <stdio.h>
 #include <string.h>
 #include <mutex>
 #include <vector>
@@ -173,7 +174,13 @@ extern "C" int glm_comm_alloc(void** ptr, size_t bytes, int kind) {
     if (e == hipSuccess) e = hipMemset(p, 0, bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
-        if (p) (void)hipFree(p);
+        // a fresh block that could not be cleared goes back to the runtime (it was never handed out, nothing maps it); a
+        // REUSED block is parked again — freeing blocks that were mapped uncached is what this pool exists to avoid
+        if (p && fresh) (void)hipFree(p);
+        else if (p) {
+            std::lock_guard<std::mutex> lk(g_comm_mu);
+            g_comm_free.push_back(CommBlock{p, bytes, kind, dev});
+        }
         (void)hipGetLastError();
         glm_set_error("glm_comm_alloc(%zu B, kind %d): %s", bytes, kind, hipGetErrorString(e));
         return GLM_ERR_LAUNCH;
@@ -193,6 +200,16 @@ extern "C" int glm_comm_free(void* ptr) {
         if (g_comm_live[i].p == ptr) {
             g_comm_free.push_back(g_comm_live[i]);  // parked, not returned to the runtime (see above)
             g_comm_live.erase(g_comm_live.begin() + (long)i);
+            // the pool only grows with DISTINCT (device, kind, size) triples — a serving process has two (buffer, flags);
+            // say so once if something allocates and frees ever-changing sizes
+            size_t parked = 0;
+            for (const CommBlock& b : g_comm_free) parked += b.bytes;
+            static bool warned = false;
+            if (!warned && (g_comm_free.size() > 64 || parked > ((size_t)1 << 30))) {
+                warned = true;
+                fprintf(stderr, "[glm4moe_hip] glm_comm_free: %zu parked communication blocks, %zu MiB — blocks are never "
+                                "returned to the runtime; allocate them once at start-up\n", g_comm_free.size(), parked >> 20);
+            }
             return GLM_OK;
         }
     glm_set_error("glm_comm_free: %p was not allocated by glm_comm_alloc (or freed twice)", ptr);

@@ -977,6 +977,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
 }
 
 
+#if GLM_STUDY_KERNELS
 // ==========================================================================================================================
 // r03 (OPT-IN, GLM_FA_MFMA32=1): the same kernel on v_mfma_f32_32x32x16_bf16 (prefill_attn32_kernel).  Why it was built: with 16x16x32 MFMAs a (32 keys x 32 query
 // rows) step costs 34 MFMA issues (8 of a SIMD's 16 cycles each) next to ~260 cycles of softmax VALU issue — the SIMD's
@@ -1326,6 +1327,8 @@ __global__ __launch_bounds__(256, (QB == 1 ? 2 : 1)) void prefill_attn32_kernel(
     }
 }
 
+#endif  // GLM_STUDY_KERNELS
+
 }  // namespace
 
 extern "C" int glm_varlen_attn_prefill(const void* q, const void* k, const void* v,
@@ -1359,6 +1362,7 @@ extern "C" int glm_varlen_attn_prefill(const void* q, const void* k, const void*
     // option fa_mfma32 = 1 (GLM_FA_MFMA32 at start-up, glm_set_option afterwards): the 32x32x16 kernel (same grid and workgroup shape as the default 16x16x32
     // kernel).  Parity green (test_varlen_attn_prefill_mfma32); measured r03, one box, interleaved processes: 746-754 against
     // 789-805 TFLOP/s at 4 x 4096 tokens, so it stays opt-in.
+#if GLM_STUDY_KERNELS
     if (glm_option(GLM_OPT_FA_ROWS64) == 1)
         return glm_launch_prefill_attn64(q, k, v, cu_seqlens_q, cu_seqlens_k, block_tables, bt_stride, out, B, max_seqlen_q, nh, nkv,
                                          block_size, scale, glm_s(stream));
@@ -1379,6 +1383,13 @@ extern "C" int glm_varlen_attn_prefill(const void* q, const void* k, const void*
         GLM_CHECK_LAUNCH("glm_varlen_attn_prefill");
         return GLM_OK;
     }
+#else
+    if (glm_option(GLM_OPT_FA_ROWS64) == 1 || glm_option(GLM_OPT_FA_MFMA32) == 1) {
+        glm_set_error("glm_varlen_attn_prefill: options fa_rows64 / fa_mfma32 select study kernels (measured slower, DESIGN.md 4.3); "
+                      "this is the product library — build and load lib/libglm4moe_hip_study.so (build.py --study)");
+        return GLM_ERR_UNSUPPORTED;
+    }
+#endif
     if (paged)
         hipLaunchKernelGGL((prefill_attn_kernel<true>), grid, dim3(FA_NT), lds, glm_s(stream), (const bf16_t*)q,
                            (const bf16_t*)k, (const bf16_t*)v, cu_seqlens_q, cu_seqlens_k, block_tables,

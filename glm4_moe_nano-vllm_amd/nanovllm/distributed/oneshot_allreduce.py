@@ -136,7 +136,26 @@ class OneShotAllReduce:
         if not all(oks):
             raise RuntimeError(f"peer mapping failed on ranks {[r for r, o in enumerate(oks) if not o]}"
                                + (f" (here: {err})" if not ok and "err" in dir() else ""))
+        ar._group_made = True
         return ar
+
+    def close(self, group=None) -> None:
+        """Collective teardown (r05).  Order matters: EVERY rank first closes its mappings of the peers' blocks
+        (glm_comm_ipc_close), the ranks meet, and only then does an owner hand its own blocks back (glm_comm_free parks
+        them for the next glm_comm_alloc, which re-zeroes them: a peer that still had the block mapped could write flags or
+        rows of an old epoch into the new owner's buffer).  Without a process group (single process, emulated ranks) the
+        caller closes every rank's object before it allocates again.  Operating rule: a serving
+        process allocates its communication blocks once at start-up and calls this at shutdown only."""
+        torch.cuda.synchronize(self.device)
+        for lst in (self.peer_bufs, self.peer_flags):
+            for b in lst:
+                if b is not None and not b._owner:
+                    b.close()
+        self.peer_bufs, self.peer_flags = [self.buf] * self.world, [self.flags] * self.world
+        if getattr(self, "_group_made", False):   # built by for_group(): the peers are other processes
+            dist.barrier(group=group)
+        self.buf.close()
+        self.flags.close()
 
     # ---- the collective -----------------------------------------------------------------------------------------
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:

@@ -57,10 +57,25 @@ class TPGroup:
         if self._oneshot:
             self._oneshot.check()
 
+    # live counters of the calls this coordinator issued (host side; a captured step counts once, at capture): what
+    # bench.py's `collective` record is filled from, so that an N > 1 line shows what actually ran
+    calls = 0
+    calls_oneshot = 0
+    bytes_total = 0
+    bytes_max = 0
+
+    def reset_counters(self) -> None:
+        self.calls = self.calls_oneshot = self.bytes_total = self.bytes_max = 0
+
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
         if self.world_size > 1:
+            nb = t.numel() * t.element_size()
+            self.calls += 1
+            self.bytes_total += nb
+            self.bytes_max = max(self.bytes_max, nb)
             fast = self._oneshot_for(t)
             if fast is not None:
+                self.calls_oneshot += 1
                 return fast.all_reduce(t)
             dist.all_reduce(t, group=self._group)
         return t

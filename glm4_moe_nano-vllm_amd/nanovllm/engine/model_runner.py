@@ -258,4 +258,9 @@ class ModelRunner:
             self.graphs[bs] = g
             torch.cuda.synchronize()
             reset_context()
+        if self.ep:
+            # the warm-ups and captures above ran on all-zero token ids: every row routes alike, which may have set the
+            # sticky overflow word — the first real step must not be redone for it
+            from nanovllm.distributed.expert_parallel import EPExperts
+            EPExperts.clear_overflow()
         self.graph_vars = gv

@@ -367,7 +367,12 @@ def gemm_qkv_rope_store(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | N
     q = torch.empty((T, nh, hd), dtype=x.dtype, device=x.device)
     k = torch.empty((T, nkv, hd), dtype=x.dtype, device=x.device) if need_kv else None
     v = torch.empty_like(k) if need_kv else None
-    has_cache = k_cache is not None and slot_mapping is not None and slot_mapping.numel() == T
+    has_cache = k_cache is not None and slot_mapping is not None
+    if has_cache and slot_mapping.numel() != T:
+        # never skip the K/V store silently: later decode steps would read unwritten cache rows (kv_store asserts too)
+        raise ValueError(f"gemm_qkv_rope_store: slot_mapping has {slot_mapping.numel()} entries for {T} token rows")
+    if positions.numel() != T or positions.device != x.device or (bias is not None and bias.data_ptr() % 8):
+        return None   # the two-launch path checks / handles these
     if has_cache:
         assert k_cache.is_contiguous() and v_cache.is_contiguous() and slot_mapping.dtype == torch.int32
     n_slots = k_cache.shape[0] * k_cache.shape[1] if has_cache else 0

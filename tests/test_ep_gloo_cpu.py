@@ -103,7 +103,9 @@ def _worker(rank, world, port, q):
         idx_bal = torch.tensor([[t % El, El + (t // 2) % El] for t in range(T)])
         # (b) skewed routing: every pair goes to rank 0's experts => 16 rows per slot against cap 16 x 0.5 x ... = overflow
         idx_skew = torch.tensor([[t % 2, 2 + t % 2] for t in range(T)])
+        min_mean = EP.EPExperts.CAPACITY_MIN_MEAN
         try:
+            EP.EPExperts.CAPACITY_MIN_MEAN = 0.0   # this case exercises the tight form itself on a tiny step (mean load 8)
             EP.EPExperts.set_capacity_factor(2.0)
             ex = mk()
             assert ex.capacity(T) == 16 and ex.capacity(T) < (T // world) * min(k, El) + 1
@@ -111,8 +113,9 @@ def _worker(rank, world, port, q):
             assert EP.EPExperts.overflowed() == 0
             ref = O.moe(x, None, None, k, 1.0, w13[:E], w2[:E], w13[E], w2[E], topk=(idx_bal, w_uni))
             assert float((out.float() - ref.float()).abs().max()) <= 2 ** -6 * float(ref.float().abs().max())
-            EP.EPExperts.set_capacity_factor(1.0)  # cap 8 rows; the skewed routing puts 16 into the slots towards rank 0
+            EP.EPExperts.set_capacity_factor(0.5)  # cap = min(worst 16, mean 8 + 4 sqrt(8)) = 16 ... force 8 through the worst case:
             ex = mk()
+            ex.capacity = lambda T_: 8             # 8 rows per slot; the skewed routing puts 16 into the slots towards rank 0
             assert ex.capacity(T) == 8
             bad = EP.run(ex.forward(x, idx_skew, w_uni))
             worst = EP.EPExperts.overflowed()
@@ -130,6 +133,7 @@ def _worker(rank, world, port, q):
             assert float((out.float() - ref.float()).abs().max()) <= 2 ** -6 * float(ref.float().abs().max())
         finally:
             EP.EPExperts.set_capacity_factor(None)
+            EP.EPExperts.CAPACITY_MIN_MEAN = min_mean
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))
@@ -225,6 +229,46 @@ def test_ep_dispatch_form_by_step_size():
     assert ex.capacity(256) == 256
     EP.EPExperts.set_capacity_factor(2.0)
     try:
-        assert ex.capacity(256) == 64 and ex.capacity(8) == 2 and ex.capacity(1) == 2 and ex.capacity(2048) == 512
+        # mean load 32 rows at B = 256: the factor applies; decode-sized steps (mean < 16) keep the worst case
+        assert ex.capacity(256) == 64 and ex.capacity(2048) == 512
+        assert ex.capacity(8) == 8 and ex.capacity(1) == 8 and ex.capacity(32) == 32 and ex.capacity(64) == 64
+        assert ex.capacity(128) == 32          # mean 16: max(2 x 16, 16 + 4 x 4) = 32 instead of 128
+        EP.EPExperts.set_capacity_factor(1.0)
+        assert ex.capacity(256) == 55          # a small factor cannot cut into the spread: 32 + 4 sqrt(32) = 54.6
+    finally:
+        EP.EPExperts.set_capacity_factor(None)
+
+
+def test_ep_capacity_overflow_rate_under_random_routing():
+    """with cap = 2 x mean at every size, most decode steps at B <= 32 overflowed and ran twice.  Pin the rule
+    that replaced it: simulate glm_ep_plan's per-(source, destination) row counts under uniform random routing (E = 128,
+    k = 8, ep = 8) and under the worst decode case for concentration — every row of the step routed alike, as the padded rows
+    of a graph bucket are.  Steps below the mean-load threshold can NEVER overflow (worst-case slots); from there on the
+    overflow rate under random routing stays below 1 %."""
+    sys.path.insert(0, os.path.join(ROOT, "glm4_moe_nano-vllm_amd"))
+    import ep_cpu_ops
+    from nanovllm.distributed import expert_parallel as EP
+    E, k, ep = 128, 8, 8
+    ex = EP.EPExperts(ep_cpu_ops, ep, 0, E, k, None, None, None)
+    El = E // ep
+    g = torch.Generator().manual_seed(5)
+    EP.EPExperts.set_capacity_factor(2.0)
+    try:
+        for B in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512):
+            cap, per = ex.capacity(B), -(-B // ep)
+            trials, over = 400, 0
+            for _ in range(trials):
+                idx = torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(B)])   # [B, k] distinct experts per token
+                dest = idx // El                                                              # destination rank of every pair
+                src = torch.arange(B).unsqueeze(1).expand(B, k) // per                        # source slice of every pair
+                counts = torch.zeros(ep, ep, dtype=torch.int64)
+                counts.index_put_((src.reshape(-1), dest.reshape(-1)), torch.ones(B * k, dtype=torch.int64), accumulate=True)
+                over += int(counts.max()) > cap
+            rate = over / trials
+            if per * k / ep < EP.EPExperts.CAPACITY_MIN_MEAN:
+                assert cap == per * min(k, El) and rate == 0.0, (B, cap, rate)
+                # identical rows (padded bucket): a slot gets per x (experts of that row on one rank) <= per x min(k, El) = cap
+            else:
+                assert rate < 0.01, (B, cap, rate)
     finally:
         EP.EPExperts.set_capacity_factor(None)

@@ -226,35 +226,22 @@ def test_model_final_norm_variants(tmp_path, without_residual):
     _mixed(h, ref, f"final hidden (without_residual={without_residual})", rows)
 
 
-def _evict_device_caches():
-    """Touch 1 GiB so that every line the GPU caches hold of the small test tensors is evicted (see _stale_readback)."""
-    big = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
-    big.fill_(1)
-    assert int(big[:: 1 << 20].sum()) == 1024
-    torch.cuda.synchronize()
-    del big
-
-
 def _stale_readback(check, what):
-    """Run `check()` (read-backs + asserts); if it fails, evict the device caches and run it once more.  A tripwire left from
-    r04: read-backs of this test's few-hundred-KiB tensors — device-to-host copies and gather / clone kernels alike — returned
-    stale 4-KiB pieces until the caches were evicted, in every suite run that had hipFree'd MiB-sized UNCACHED blocks
-    (hipExtMallocWithFlags; the one-shot all-reduce tests) earlier in the process.  glm_comm_free no longer returns such blocks
-    to the runtime and the effect is gone (0 in 3 suite runs, 6 in 6 before); profiles/r04/c1_stale_readback.txt has the
-    evidence.  A second failure is a real one and propagates; a first failure healed by the eviction is recorded as a warning
-    and in gpurun_out/parity_fullsize.jsonl."""
+    """Run `check()` (read-backs + asserts).  FATAL tripwire left from r04: read-backs of this test's few-hundred-KiB tensors
+    returned 4-KiB pieces of the zero fill that preceded the product's writes in every suite run that had hipFree'd
+    MiB-sized UNCACHED blocks (hipExtMallocWithFlags; the one-shot all-reduce tests) earlier in the process.  glm_comm_free no
+    longer returns such blocks to the runtime (profiles/r04/c1_stale_readback.txt; DESIGN.md section 6 states the operating
+    rule).  Until r05 a first failure was retried behind a cache eviction and downgraded to a warning; now the first failure
+    fails the run — the same fault while serving would be silently corrupted attention.  The failure is still recorded in
+    gpurun_out/parity_fullsize.jsonl so that a recurrence leaves the evidence behind."""
     try:
         check()
-        return False
     except AssertionError as first:
-        _evict_device_caches()
-        check()
-        import json, os, warnings
-        warnings.warn(f"{what}: first read-back stale, correct after evicting the device caches: {str(first)[:200]}")
+        import json, os
         os.makedirs("gpurun_out", exist_ok=True)
         with open("gpurun_out/parity_fullsize.jsonl", "a") as f:
             f.write(json.dumps({"test": what, "stale_readback": True, "first_failure": str(first)[:300]}) + "\n")
-        return True
+        raise
 
 
 def test_decoder_layer_c1():
@@ -327,3 +314,59 @@ def test_decoder_layer_c1():
     else:  # a single row: it may only move when the reference's own top-1 margin is a near-tie
         _, _, choice = O.router_scores(trd["h_router"], lw.gate_w, lw.gate_bias)
         assert float(router_margin(choice, 1)[0]) <= 0.016
+
+
+def _c1_after_ipc_close_worker(rank, world, port, q):
+    try:
+        import sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        root = os.path.dirname(here)
+        for p in (here, root, os.path.join(root, "glm4_moe_nano-vllm_amd")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from nanovllm.distributed.oneshot_allreduce import OneShotAllReduce
+        n = 32 * 4096   # MiB-sized uncached blocks, the size class of the r04 trigger
+        ar = OneShotAllReduce.for_group(n, torch.device("cuda", 0))
+        g = torch.Generator().manual_seed(77)
+        xs = [torch.randn(32, 4096, generator=g).to(torch.bfloat16) for _ in range(world)]
+        mine = xs[rank].cuda()
+        dist.barrier()
+        ar.all_reduce(mine)
+        torch.cuda.synchronize()
+        assert ar.status() == 0
+        assert torch.equal(mine.cpu(), sum(x.float() for x in xs).to(torch.bfloat16))
+        ar.close()      # glm_comm_ipc_close of the peer's blocks, barrier, glm_comm_free (parks) of the own ones
+        del ar, mine
+        torch.cuda.empty_cache()   # the allocator draws fresh segments for what follows
+        import test_layer_gpu as me
+        me.test_decoder_layer_c1()  # ordinary tensors of the C1 sizes: allocate, write (product kernels), re-read — fatal tripwire
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL " + traceback.format_exc()))
+
+
+@pytest.mark.timeout(600)
+def test_c1_after_ipc_close_2proc():
+    """The OTHER way pages that were mapped as communication memory leave a process: a PEER's
+    mapping closed with glm_comm_ipc_close (hipIpcCloseMemHandle).  Two processes on this GPU map each other's uncached
+    receive blocks over hipIpc, run one one-shot all-reduce, tear down in the documented order
+    (OneShotAllReduce.close: peers close, barrier, owners park) and then each runs the whole C1 layer test — whose
+    read-backs fail on the FIRST stale read — on freshly allocated ordinary tensors.  One pass, no retry."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 2
+    ps = [ctx.Process(target=_c1_after_ipc_close_worker, args=(r, world, 29751, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=420) for _ in ps]
+    for p in ps:
+        p.join(30)
+    assert all(m == "ok" for _, m in res), res

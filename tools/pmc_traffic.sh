@@ -52,6 +52,7 @@ sys.path.insert(0, "$R")
 import bench
 out["_meta"] = {"kernel_source_digest": bench._kernel_source_digest(), "git_head": bench._git("rev-parse", "--short", "HEAD"),
                 "command": "bench.py --layers 3 --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-c2 --no-extras --kernel-iters 12",
+                "parallelism": {"world": 1, "emulate_tp": 1, "expert_parallel": False},
                 "passes": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace", "rocprofv3 --pmc WRITE_SIZE --kernel-trace"]}
 json.dump(out, open("$R/gpurun_out/pmc_traffic.json", "w"), indent=1)
 for k, v in out.items():
