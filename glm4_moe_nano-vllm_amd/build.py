@@ -20,7 +20,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libglm4moe_hip.so")
 ARCH = "gfx950"
 SOURCES = ["api", "elementwise", "moe_misc", "paged_attn", "prefill_attn", "gemm_smallm", "gemm_tinym", "gemm_largem",
-           "oneshot_allreduce"]
+           "decode_engine", "oneshot_allreduce"]
 # kernels that were measured against the shipped ones and lost: only in the study library (`--study`), with their tests
 STUDY_SOURCES = ["prefill_attn64"]
 STUDY_TAG = "_study"

@@ -13,7 +13,7 @@ void glm_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int glm_abi_version(void) { return 9; }
+extern "C" int glm_abi_version(void) { return 10; }
 extern "C" const char* glm_last_error(void) { return g_err; }
 
 // ---- launch-path options: name, environment variable read once, default ------------------------------------------------

@@ -225,6 +225,7 @@ class ModelRunner:
                 self.ep_redone_steps = getattr(self, "ep_redone_steps", 0) + 1
         from nanovllm import hip_ops
         hip_ops.check_router_tail(self.device)  # a bounded in-launch wait that expired (cannot while the GPU makes progress)
+        hip_ops.check_decode_engine(self.device)
         if self.world_size > 1:
             # a one-shot all-reduce that gave up waiting poisoned its output and set a status word: surface it here, where
             # rank 0 has just synchronised on the tokens anyway (no-op on RCCL)

@@ -92,6 +92,11 @@ _SIGNATURES = {
     "glm_gemm_bf16_router_tail": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "glm_decode_mlp_engine_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "glm_decode_mlp_engine": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int,
+                                      c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "glm_gemm_bf16_partial_slices": (c_int, [c_int, c_int]),
     "glm_gemm_bf16_partial": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
                                       c_int, c_void_p]),
@@ -161,6 +166,8 @@ _HOST_OPTION_ENV = {  # name -> (environment variable, default)
     "fuse_oproj_router": ("GLM4MOE_FUSE_OPROJ_ROUTER", 1),  # one token: o_proj + norm + router + bucketing in one launch
     "defer_qkv_reduce": ("GLM4MOE_DEFER_QKV_REDUCE", 1),    # QKV as K-slice partial sums reduced by the attention's loads
     "fuse_qkv_rope": ("GLM4MOE_FUSE_QKV_ROPE", 1),          # prefill: split + rotary + K/V store in the QKV GEMM's epilogue
+    "t1_engine": ("GLM4MOE_T1_ENGINE", 0),                  # one token: o_proj .. down projection as ONE persistent launch (r05; opt-in:
+                                                            # bit-identical, 5-6 us per layer slower — profiles/r05/decode_engine_stamps.txt)
     "ep_fixed": ("GLM_EP_FIXED", 1),                        # expert parallelism: fixed-capacity dispatch at decode sizes
     "oneshot_allreduce": ("GLM_ONESHOT_ALLREDUCE", 0),      # opt-in one-hop all-reduce over mapped peer buffers
 }
@@ -998,6 +1005,68 @@ def gemm_add_rmsnorm_router_topk_align(x: torch.Tensor, w: torch.Tensor, residua
         return None
     _check(rc, "glm_gemm_bf16_router_tail")
     return y.view(residual.shape), ro.view(residual.shape), idx, tw, (offs, tok, scale, pos)
+
+
+_engine_ws: dict = {}
+_engine_ws_retired: list = []
+
+
+def can_decode_mlp_engine(x: torch.Tensor, H: int, E: int, k: int, I: int) -> bool:
+    return (opt("t1_engine") != 0 and x.dim() == 2 and x.shape[0] == 1 and H in (2048, 4096) and x.shape[1] % 2048 == 0
+            and E <= 256 and k <= 64 and 1024 <= I <= 1536 and I % 8 == 0 and x.is_contiguous())
+
+
+def decode_mlp_engine(x: torch.Tensor, w_o: torch.Tensor, residual: torch.Tensor, norm_weight: torch.Tensor, eps: float,
+                      gate_w: torch.Tensor, bias: torch.Tensor, k: int, routed_scaling_factor: float, w13: torch.Tensor,
+                      w2: torch.Tensor, want_act: bool = False):
+    """ONE token: o_proj + post-attention add-RMSNorm + router + bucketing + grouped gate|up + SiLU*mul + grouped down x
+    routing weight in ONE persistent launch (glm_decode_mlp_engine, csrc/decode_engine.hip).  x [1, K]; w_o [H, K];
+    w13 [E+1, 2I, H], w2 [E+1, H, I] (group E = the shared expert).  Returns (y_norm, residual_out, topk_idx, topk_w,
+    (offs, tok, scale, pos), y [k+1, H], act or None) — exactly what gemm_add_rmsnorm_router_topk_align +
+    grouped_gemm_gateup_silu + grouped_gemm_down return, bit for bit — or None when the launcher does not cover the shape
+    (nothing was enqueued)."""
+    _bf16(x, "x"); _bf16(w_o, "w_o"); _bf16(residual, "residual"); _bf16(norm_weight, "norm_weight"); _bf16(gate_w, "gate_w")
+    _bf16(w13, "w13"); _bf16(w2, "w2")
+    assert bias.dtype == torch.float32 and x.shape[0] == 1 and w_o.stride(1) == 1 and w13.stride(2) == 1 and w2.stride(2) == 1
+    K, H, E = x.shape[1], w_o.shape[0], gate_w.shape[0]
+    I = w2.shape[2]
+    assert w13.shape[0] == E + 1 and w13.shape[1] == 2 * I and w13.shape[2] == H and w2.shape[0] == E + 1 and w2.shape[1] == H
+    dev = x.device
+    r2 = residual.reshape(1, H).contiguous()
+    y_norm, ro = torch.empty_like(r2), torch.empty_like(r2)
+    idx = torch.empty((1, k), dtype=torch.int64, device=dev)
+    tw = torch.empty((1, k), dtype=torch.bfloat16, device=dev)
+    offs = torch.empty(E + 2, dtype=torch.int32, device=dev)
+    tok = torch.empty(k + 1, dtype=torch.int32, device=dev)
+    scale = torch.empty(k + 1, dtype=torch.bfloat16, device=dev)
+    pos = torch.empty(k, dtype=torch.int32, device=dev)
+    y = torch.empty((k + 1, H), dtype=x.dtype, device=dev)
+    act = torch.empty((k + 1, I), dtype=x.dtype, device=dev) if want_act else None
+    lib = load_library()
+    ws = _grow_only(_engine_ws, _engine_ws_retired, dev, lib.glm_decode_mlp_engine_workspace_bytes(H, E, k, I),
+                    "decode engine workspace")
+    rc = lib.glm_decode_mlp_engine(
+        _p(x), _p(w_o), w_o.stride(0), K, H, _p(r2), _p(norm_weight), eps, _p(y_norm), _p(ro), _p(gate_w), _p(bias), E, k,
+        routed_scaling_factor, _p(idx), _p(tw), _p(offs), _p(tok), _p(scale), _p(pos), _p(w13), w13.stride(0), w13.stride(1),
+        _p(w2), w2.stride(0), w2.stride(1), I, _p(act), _p(y), y.stride(0), ws.data_ptr(), _stream())
+    if rc == GLM_ERR_UNSUPPORTED:
+        return None
+    _check(rc, "glm_decode_mlp_engine")
+    return y_norm.view(residual.shape), ro.view(residual.shape), idx, tw, (offs, tok, scale, pos), y, act
+
+
+def check_decode_engine(device=None) -> None:
+    """Raise if a bounded wait inside a glm_decode_mlp_engine launch expired since the last call (word 1 of its workspace is
+    the sticky status; y was NaN-filled).  One 4-byte read; the workspace is re-zeroed."""
+    for key, ws in list(_engine_ws.items()):
+        if device is not None and torch.device(device).index not in (None, key[1]):
+            continue
+        st = int(ws[4:8].view(torch.int32).item())
+        if st:
+            torch.cuda.synchronize(torch.device(key[0], key[1]))
+            ws.zero_()
+            raise RuntimeError(f"one-token decode engine: a bounded wait expired (code 0x{st & 0xf00:x}, workgroup {st & 0xff}); "
+                               "the outputs of that step are NaN")
 
 
 class PartialSum:

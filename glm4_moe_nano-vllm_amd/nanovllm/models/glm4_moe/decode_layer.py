@@ -72,6 +72,22 @@ class Glm4MoeDecoderLayer(nn.Module):
             o = self.self_attn(hidden_states, positions, qkv=qkv, skip_o_proj=True)
             ln = self.post_attention_layernorm
             fused = None
+            if (o.dim() == 2 and o.shape[0] == 1 and o.is_contiguous()
+                    and getattr(self.mlp, "expert_weight_dtype", None) is None
+                    and hip_ops.can_decode_mlp_engine(o, residual.shape[-1], gate.weight.shape[0], gate.top_k,
+                                                      self.mlp.config.moe_intermediate_size)):
+                # r05: ... and the grouped gate|up and down projections too — the whole MLP half of the layer as ONE
+                # persistent launch (csrc/decode_engine.hip), bit-identical to the three launches below
+                w13, w2 = self.mlp._stacked()
+                eng = hip_ops.decode_mlp_engine(o, op.weight.data, residual, ln.weight.data, ln.eps, gate.weight.data,
+                                                gate.e_score_correction_bias, gate.top_k, float(gate.routed_scaling_factor),
+                                                w13, w2)
+                if eng is not None:
+                    hidden_states, residual, idx, w, aligned, y, _ = eng
+                    # the block's module call stays (hooks, same return types): the expert rows are already there
+                    hidden_states = self.mlp(hidden_states, routing=(idx, w), aligned=aligned, defer_combine=defer_combine,
+                                             expert_rows=y)
+                    return hidden_states, residual
             if o.dim() == 2 and o.shape[0] == 1 and o.is_contiguous():
                 fused = hip_ops.gemm_add_rmsnorm_router_topk_align(
                     o, op.weight.data, residual, ln.weight.data, ln.eps, gate.weight.data, gate.e_score_correction_bias,

@@ -169,11 +169,13 @@ class Glm4MoeMoE(nn.Module):
         return EP.EPExperts(ops, self.ep_size, r, E, k, w13[:El], w2[:El], self.shared_experts)
 
     # ---- forward ------------------------------------------------------------------------
-    def forward(self, hidden_states: torch.Tensor, routing=None, defer_combine: bool = False, aligned=None):
+    def forward(self, hidden_states: torch.Tensor, routing=None, defer_combine: bool = False, aligned=None, expert_rows=None):
         """routing: (topk_idx, topk_w) already computed for these rows (decode_layer's fused norm + router).
         aligned: hip_ops.moe_align(topk_idx, topk_w, E, True) of that routing, when the same launch produced it.
         defer_combine: the caller hands the result straight to the next layer's RMSNorm.forward(x, residual) and
-        accepts a hip_ops.DeferredCombine (TP=1 only)."""
+        accepts a hip_ops.DeferredCombine (TP=1 only).
+        expert_rows: y [T k + T, H] of this routing, when the caller's launch has already run the grouped projections
+        (one token: hip_ops.decode_mlp_engine); only the combine is left."""
         shape = hidden_states.shape
         h = hidden_states.view(-1, shape[-1])
         T = h.shape[0]
@@ -184,7 +186,10 @@ class Glm4MoeMoE(nn.Module):
             return EP.run(self._ep_experts().forward(h, topk_idx, topk_w), group=get_tp_group().process_group).view(shape)
         offs, tok, scale, pos = aligned if aligned is not None else hip_ops.moe_align(topk_idx, topk_w, E, True)
         R = T * k + T
-        if self.expert_weight_dtype == "fp8_e4m3":
+        if expert_rows is not None:
+            assert self.ep_size == 1 and aligned is not None and expert_rows.shape[0] == R
+            y = expert_rows
+        elif self.expert_weight_dtype == "fp8_e4m3":
             if self._fp8 is None:
                 self.quantize_experts_fp8()
             w13_q, w13_s, w2_q, w2_s = self._fp8

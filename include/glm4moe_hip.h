@@ -230,6 +230,32 @@ int glm_gemm_bf16_router_tail(const void* x, const void* w, int64_t ldw, int K, 
                               int32_t* sorted_token, void* sorted_scale, int32_t* pair_pos, int with_shared,
                               glm_stream_t stream);
 
+/* a10 + a3 + a11 + bucketing + a12/a13 for ONE token in ONE persistent launch (r05; BASELINE configs[1], greedy bs = 1):
+ *     what glm_gemm_bf16_router_tail, glm_grouped_gemm_gateup_silu and glm_grouped_gemm_down do for one token row —
+ *     attention_new.py o_proj, decode_layer.py:86-93, moe.py:28-50, the expert loop moe.py:135-151 with mlp.py:49-54 —
+ *     and what the reference replays as one CUDA graph (engine/model_runner.py:223-258).  Every output is bit-identical
+ *     to those three launches.  One 512-thread workgroup per CU streams o_proj -> shared + routed gate|up -> down with the
+ *     next weight unit always requested before the current one's activations are waited for; the o_proj row, the E logits
+ *     and the act rows travel between workgroups as 8-byte {epoch, value} granules (csrc/decode_engine.hip).
+ *     x [K] attention output row; w_o [H, K]; w13 [E+1, 2I, H] / w2 [E+1, H, I] stacked experts, group E = the shared
+ *     expert (required); act [k+1, I] optional (NULL = not stored); y [k+1, H]: row j = the j-th selected expert in
+ *     ascending id (scaled by its routing weight), row k = the shared expert — what glm_moe_combine / the next layer's
+ *     glm_gemm_bf16_combine_norm read through pair_pos with shared_base = k.
+ *     workspace: glm_decode_mlp_engine_workspace_bytes(H, E, k, I) bytes, 16-byte aligned, ZERO before the first launch and
+ *     never touched by anything else: word 0 = the launch counter (epoch; tags are never reset, so no memset node), word 1 =
+ *     sticky status — 0, or a code | workgroup when a bounded wait expired (it cannot while the GPU makes progress): y is
+ *     then NaN-filled by that workgroup and the host must raise (hip_ops.check_router_tail) and re-zero the workspace.
+ *     GLM_ERR_UNSUPPORTED (nothing enqueued): H outside [2048, 4096], I > 1536, E > 256 or E > CUs, k > 64, K / H / I not
+ *     multiples of 8, unaligned buffers.                                                                              */
+size_t glm_decode_mlp_engine_workspace_bytes(int H, int E, int k, int I);
+int glm_decode_mlp_engine(const void* x, const void* w_o, int64_t ldw_o, int K, int H, const void* residual_in,
+                          const void* norm_weight, float eps, void* y_norm, void* residual_out, const void* gate_w,
+                          const float* e_score_correction_bias, int E, int k, float routed_scaling_factor,
+                          int64_t* topk_idx, void* topk_w, int32_t* expert_offsets, int32_t* sorted_token,
+                          void* sorted_scale, int32_t* pair_pos, const void* w13, int64_t w13_group_stride,
+                          int64_t w13_row_stride, const void* w2, int64_t w2_group_stride, int64_t w2_row_stride, int I,
+                          void* act, void* y, int64_t ldy, void* workspace, glm_stream_t stream);
+
 /* N4 (no reference counterpart; BASELINE config 5): the same two grouped projections with the
  *     expert weights stored as OCP fp8 e4m3 (1 byte/element) plus one fp32 scale per weight row:
  *     W'[n,k] = scale[n] * fp8(Wq[n,k]).  Weight-only quantisation: activations stay bf16, the

@@ -39,7 +39,7 @@ def test_binding_table_matches_header(lib_path):
     from nanovllm import hip_ops
     assert sorted(hip_ops.EXPORTED_SYMBOLS) == declared_symbols()
     lib = hip_ops.load_library(lib_path)
-    assert lib.glm_abi_version() == 9
+    assert lib.glm_abi_version() == 10
 
 
 def test_host_only_entry_points(lib_path):
@@ -76,7 +76,7 @@ def test_options_are_read_once_and_listed(lib_path):
     from nanovllm import hip_ops
     o = hip_ops.options()
     assert set(o) == {"tinym", "fp8w_native", "largem_variant", "largem_cfg", "fa_mfma32", "fa_rows64", "fuse_combine_qkv",
-                      "fuse_oproj_router", "defer_qkv_reduce", "fuse_qkv_rope", "ep_fixed", "oneshot_allreduce"}
+                      "fuse_oproj_router", "t1_engine", "defer_qkv_reduce", "fuse_qkv_rope", "ep_fixed", "oneshot_allreduce"}
     assert o["tinym"] == 1 and o["largem_variant"] == -1 and o["oneshot_allreduce"] == 0
     os.environ["GLM4MOE_TINYM"] = "0"
     os.environ["GLM4MOE_FUSE_COMBINE_QKV"] = "0"

@@ -690,6 +690,83 @@ def test_oproj_router_tail_one_launch(ops, K, H, E, k, shared):
     assert int(head.abs().sum()) == 0, "both counters must be back at zero"
 
 
+@pytest.mark.parametrize("K,H,E,k,I", [(12288, 4096, 128, 8, 1408), (12288, 4096, 64, 8, 1408), (4096, 2048, 16, 4, 1024),
+                                        (6144, 2048, 72, 3, 1536)])
+def test_decode_mlp_engine_one_launch(ops, K, H, E, k, I):
+    """r05, BASELINE configs[1]: glm_decode_mlp_engine — o_proj, post-attention add-RMSNorm, router, bucketing, grouped
+    gate|up + SiLU*mul and grouped down x routing weight of ONE token in one persistent launch (loader run-ahead over the
+    seams, granule hand-offs) — against the three launches it replaces (glm_gemm_bf16_router_tail,
+    glm_grouped_gemm_gateup_silu, glm_grouped_gemm_down on the one-token GEMV body): EVERY stage bit for bit at its own
+    scale (normalised row, residual, routing, bucketing, act rows, y rows).  New inputs and new weights' rows in use every
+    repetition, unrelated launches in between (a stale granule of an earlier epoch, or a hand-off read early, would show);
+    then the same launch replayed from a HIP graph with fresh inputs (the epoch lives in device memory)."""
+    wo = dev(rnd(H, K, seed=411, scale=K ** -0.5))
+    nw = dev(rnd(H, seed=412) * 0.1 + 1.0)
+    gw = dev(rnd(E, H, seed=413, scale=H ** -0.5))
+    bias = dev((torch.rand(E, generator=torch.Generator().manual_seed(414)) * 0.2 - 0.1).float())
+    w13 = ops.padded_weight(2 * I, H, E + 1, dtype=BF, device="cuda")
+    w2 = ops.padded_weight(H, I, E + 1, dtype=BF, device="cuda")
+    gg = torch.Generator(device="cuda").manual_seed(415)   # GBs at Air dims: drawn on the device
+    w13.normal_(0.0, H ** -0.5, generator=gg)
+    w2.normal_(0.0, I ** -0.5, generator=gg)
+
+    def three_launches(x, res):
+        r = ops.gemm_add_rmsnorm_router_topk_align(x, wo, res, nw, 1e-5, gw, bias, k, 2.5, True)
+        assert r is not None
+        yn, ro, idx, tw, (offs, tok, scale, pos) = r
+        act = ops.grouped_gemm_gateup_silu(yn.view(1, H), w13, offs, tok, k + 1, max_rows_per_group=1)
+        y = ops.grouped_gemm_down(act, w2, offs, scale, E, max_rows_per_group=1)
+        return yn, ro, idx, tw, (offs, tok, scale, pos), y, act
+
+    def compare(a, b, what):
+        names = ("y_norm", "residual_out", "topk_idx", "topk_w")
+        for n, u, v in zip(names, a[:4], b[:4]):
+            assert torch.equal(u, v), f"{what}: {n} differs"
+        for n, u, v in zip(("offsets", "sorted_token", "sorted_scale", "pair_pos"), a[4], b[4]):
+            assert torch.equal(u, v), f"{what}: {n} differs"
+        assert torch.equal(a[6], b[6]), f"{what}: act rows differ ({int((a[6] != b[6]).sum())} elements)"
+        assert torch.equal(a[5], b[5]), f"{what}: y rows differ ({int((a[5] != b[5]).sum())} elements)"
+
+    with ops.option("t1_engine", 1):
+        assert ops.can_decode_mlp_engine(dev(rnd(1, K, seed=1)), H, E, k, I)
+    for rep in range(6):
+        x, res = dev(rnd(1, K, seed=420 + rep)), dev(rnd(1, H, seed=430 + rep))
+        ref = three_launches(x, res)
+        got = ops.decode_mlp_engine(x, wo, res, nw, 1e-5, gw, bias, k, 2.5, w13, w2, want_act=True)
+        assert got is not None, "the engine must cover this shape"
+        ops.rmsnorm(dev(rnd(64, 4096, seed=rep)), dev(rnd(4096, seed=7)), 1e-5)
+        torch.cuda.synchronize()
+        ops.check_decode_engine()
+        compare(ref, got, f"rep {rep}")
+        _check_align(*got[4], got[2].cpu(), got[3].cpu(), E, True)
+    # against the oracle: expert rows of the last repetition (routing taken from the product; GEMV fp32 order differs from the CPU's)
+    yn, idx, tw = got[0].cpu(), got[2].cpu()[0], got[3].cpu()[0]
+    for j in range(k):
+        e = int(idx[j])
+        ref_row = (O.mlp(yn.view(1, H), w13[e].cpu(), w2[e].cpu()).float() * tw[j].float()).to(BF)
+        assert_close_bf16(got[5][j].cpu().view(1, H), ref_row, 2, 0.06, atol=2 ** -7, what=f"expert row {j} vs oracle")
+    assert_close_bf16(got[5][k].cpu().view(1, H), O.mlp(yn.view(1, H), w13[E].cpu(), w2[E].cpu()), 2, 0.06, atol=2 ** -7,
+                      what="shared row vs oracle")
+    # HIP-graph replay: static inputs refilled between replays; every replay is a new epoch
+    xs, rs = dev(rnd(1, K, seed=450)), dev(rnd(1, H, seed=451))
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ops.decode_mlp_engine(xs, wo, rs, nw, 1e-5, gw, bias, k, 2.5, w13, w2, want_act=True)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        out = ops.decode_mlp_engine(xs, wo, rs, nw, 1e-5, gw, bias, k, 2.5, w13, w2, want_act=True)
+    for rep in range(4):
+        xs.copy_(rnd(1, K, seed=460 + rep)); rs.copy_(rnd(1, H, seed=470 + rep))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        ops.check_decode_engine()
+        compare(three_launches(xs, rs), out, f"graph replay {rep}")
+    st = next(iter(ops._engine_ws.values()))[:8].view(torch.int32)
+    assert int(st[1]) == 0 and int(st[0]) > 0, "status clean, epoch advanced"
+
+
 @pytest.mark.parametrize("M,N,K,want", [(32, 4096, 12288, 8), (5, 256, 1024, 3), (1, 64, 136, 2), (17, 512, 4096, 64)])
 def test_gemm_partial_and_fused_add_rmsnorm(ops, M, N, K, want):
     """K-slice partial sums + the add-RMSNorm that reduces them == linear -> add_rms_forward of the oracle."""
