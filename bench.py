@@ -641,7 +641,13 @@ def measure_kernels(model, cfg, ops, B, ctx, world, iters, dev, only_experts=Fal
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense
 
 
-def measure_prefill_gemm(layer, cfg, ops, world, dev, T=16384, iters=10, warm=5, fp8=False):
+FP8_MFMA_PEAK_TFLOPS = 5000.0  # MI355X_MICROARCH.md: ~5 PF dense fp8 (block-scaled MFMA, 2x the bf16 rate)
+
+
+def measure_prefill_gemm(layer, cfg, ops, world, dev, T=16384, iters=10, warm=5, fp8=False, a8=False):
+    """fp8: weight-only (fp8 bytes as the bf16 MFMA kernel's weight operand).  a8 (r05): OPT-IN W8A8 — activations quantised to
+    e4m3 too (per token for gate|up, MX per 32 columns for down, produced by the gate|up epilogue), both GEMMs on the
+    block-scaled fp8 MFMA; the activation quantisation launch is timed with the pair and reported."""
     import torch
     H, E, k, I = cfg.hidden_size, cfg.n_routed_experts, cfg.num_experts_per_tok, cfg.moe_intermediate_size // world
     x = torch.randn(T, H, device=dev).to(torch.bfloat16)
@@ -665,7 +671,20 @@ def measure_prefill_gemm(layer, cfg, ops, world, dev, T=16384, iters=10, warm=5,
         torch.cuda.synchronize()
         return a.elapsed_time(b) / iters * 1e3
 
-    if fp8:  # the fp8 bytes are the tiled kernel's weight operand (no expansion pass)
+    peak = MFMA_PEAK_TFLOPS
+    quant_us = None
+    if a8:
+        peak = FP8_MFMA_PEAK_TFLOPS
+        w13_q, w13_s, w2_q, w2_s = layer.mlp._fp8
+        xq, xs = ops.quantize_fp8_rows(x)
+        gu = lambda: ops.grouped_gemm_gateup_silu_fp8a8(xq, xs, w13_q, w13_s, offs, tok, R)
+        r = gu()
+        if r is None:
+            raise RuntimeError("the fp8 x fp8 kernel does not cover this shape")
+        act_q, act_bs = r
+        dn = lambda: ops.grouped_gemm_down_fp8a8(act_q, act_bs, w2_q, w2_s, offs, scale, E)
+        quant_us = timed(lambda: ops.quantize_fp8_rows(x))
+    elif fp8:  # the fp8 bytes are the tiled kernel's weight operand (no expansion pass)
         w13_q, w13_s, w2_q, w2_s = layer.mlp._fp8
         gu = lambda: ops.grouped_gemm_gateup_silu_fp8w(x, w13_q, w13_s, offs, tok, R)
         act = gu()
@@ -679,17 +698,21 @@ def measure_prefill_gemm(layer, cfg, ops, world, dev, T=16384, iters=10, warm=5,
                             ("grouped_gemm_down@prefill16k", dn, 2.0 * R * H * I)):
         us = timed(fn)
         tf = flops / (us * 1e-6) / 1e12
-        out[name] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel_us_mean": round(us, 1),
+        out[name] = {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(tf / peak, 4), "traffic": None, "kernel_us_mean": round(us, 1),
                      "algorithmic_flops": flops, "flops_model": f"2*R*N*K with R={R} rows (T={T}, k={k}, +shared)"}
     # the grouped expert GEMM as ONE figure: both launches' FLOPs over both launches' time
     a, b = out["grouped_gemm_gateup_silu@prefill16k"], out["grouped_gemm_down@prefill16k"]
     fl, us = a["algorithmic_flops"] + b["algorithmic_flops"], a["kernel_us_mean"] + b["kernel_us_mean"]
     tf = fl / (us * 1e-6) / 1e12
-    out["grouped_gemm@prefill16k"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                      "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+    out["grouped_gemm@prefill16k"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s",
+                                      "frac": round(tf / peak, 4), "traffic": None,
                                       "kernel_us_mean": round(us, 1), "algorithmic_flops": fl,
                                       "flops_model": "gate|up + down launches together"}
+    if quant_us is not None:  # the one extra launch of the W8A8 pair: x -> e4m3 rows + per-token scales (16384 x 4096)
+        tfq = fl / ((us + quant_us) * 1e-6) / 1e12
+        out["grouped_gemm@prefill16k"].update(quantize_x_us=round(quant_us, 1), achieved_incl_quantize_x=round(tfq, 1),
+                                              frac_incl_quantize_x=round(tfq / peak, 4))
     return out
 
 
@@ -800,13 +823,35 @@ def measure_fp8(model, cfg, ops, step, B, ctx, L, args, dev):
     ks = measure_kernels(model, cfg, ops, B, ctx, 1, args.kernel_iters, dev, only_experts=True)
     moe_layer = next(l for l in model.model.layers if hasattr(l.mlp, "gate"))
     pf = measure_prefill_gemm(moe_layer, cfg, ops, 1, dev, iters=6, warm=3, fp8=True)
+    try:  # r05: the same pair as W8A8 on the block-scaled fp8 MFMA (opt-in path; parity unpinned)
+        pa = measure_prefill_gemm(moe_layer, cfg, ops, 1, dev, iters=6, warm=3, a8=True)
+        a8 = {"prefill16k_pair_tflops": pa["grouped_gemm@prefill16k"]["achieved"],
+              "prefill16k_pair_frac_of_5pf_fp8_peak": pa["grouped_gemm@prefill16k"]["frac"],
+              "prefill16k_pair_us": pa["grouped_gemm@prefill16k"]["kernel_us_mean"],
+              "prefill16k_gateup_tflops": pa["grouped_gemm_gateup_silu@prefill16k"]["achieved"],
+              "prefill16k_down_tflops": pa["grouped_gemm_down@prefill16k"]["achieved"],
+              "quantize_x_us": pa["grouped_gemm@prefill16k"].get("quantize_x_us"),
+              "prefill16k_pair_tflops_incl_quantize_x": pa["grouped_gemm@prefill16k"].get("achieved_incl_quantize_x"),
+              "prefill16k_model": "W8A8, e4m3 x e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4: x quantised per token (one extra launch, "
+                                  "timed), act quantised per (row, 32 columns) with E8M0 scales by the gate|up epilogue, the down "
+                                  "projection takes those block scales inside the MFMA; peak = 5 PFLOP/s dense fp8"}
+    except Exception as e:  # noqa: BLE001
+        a8 = {"error": repr(e)[:200]}
     return {"workload": f"same model and decode step (bs={B} ctx={ctx} L={L}), experts as fp8 e4m3 weight-only",
+            # the pair on the fp8 MFMA (W8A8, opt-in) is THE prefill figure of this entry since r05; the weight-only pair (bf16
+            # MFMA, the parity path) keeps its own keys
+            "prefill16k_pair_tflops": a8.get("prefill16k_pair_tflops", pf["grouped_gemm@prefill16k"]["achieved"]),
+            "prefill16k_pair_frac_of_5pf_fp8_peak": a8.get("prefill16k_pair_frac_of_5pf_fp8_peak"),
+            "prefill16k_pair_us": a8.get("prefill16k_pair_us", pf["grouped_gemm@prefill16k"]["kernel_us_mean"]),
+            "w8a8": a8,
+            "weight_only": {"prefill16k_gateup_tflops": pf["grouped_gemm_gateup_silu@prefill16k"]["achieved"],
+                            "prefill16k_down_tflops": pf["grouped_gemm_down@prefill16k"]["achieved"],
+                            "prefill16k_pair_tflops": pf["grouped_gemm@prefill16k"]["achieved"],
+                            "prefill16k_pair_us": pf["grouped_gemm@prefill16k"]["kernel_us_mean"]},
             "prefill16k_gateup_tflops": pf["grouped_gemm_gateup_silu@prefill16k"]["achieved"],
             "prefill16k_down_tflops": pf["grouped_gemm_down@prefill16k"]["achieved"],
-            "prefill16k_pair_tflops": pf["grouped_gemm@prefill16k"]["achieved"],
-            "prefill16k_pair_us": pf["grouped_gemm@prefill16k"]["kernel_us_mean"],
-            "prefill16k_model": "grouped gate|up + down at T=16384 with the fp8 bytes as the tiled kernel's weight operand "
-                                "(bf16 MFMA, fp32 accumulate, per-row scale in the epilogue); no expansion pass, no scratch",
+            "prefill16k_model": "weight_only: grouped gate|up + down at T=16384 with the fp8 bytes as the tiled kernel's weight "
+                                "operand (bf16 MFMA, fp32 accumulate, per-row scale in the epilogue); w8a8: see there",
             "tokens_per_s": round(B / dt, 2), "ms_per_step": round(dt * 1e3, 4), "ms_per_layer": round(dt * 1e3 / L, 4),
             "steps": steps, "hip_graph": True,
             "gateup_hbm_frac": ks["grouped_gemm_gateup_silu"]["frac"], "gateup_us": ks["grouped_gemm_gateup_silu"]["kernel_us_mean"],

@@ -413,6 +413,55 @@ extern "C" int glm_grouped_gemm_down_fp8w(const void* act, const void* w2_q, int
     return glm_launch_gemm_smallm_fp8w(GEMM_DOWN, p, glm_s(stream));
 }
 
+// r05: fp8 x fp8 on the block-scaled MFMA (BASELINE configs[4]); prefill-sized groups only
+extern "C" int glm_grouped_gemm_gateup_silu_fp8a8(const void* x_q, int64_t ldx, const float* x_scale, const void* w13_q,
+                                                  int64_t w13_group_stride, int64_t w13_row_stride, const float* w13_scale,
+                                                  int64_t w13_scale_group_stride, const int32_t* expert_offsets,
+                                                  const int32_t* sorted_token, void* act_q, int64_t ld_act, void* act_bscale,
+                                                  int64_t R, int H, int I, int G, glm_stream_t stream) {
+    GLM_CHECK_ARG(x_q && x_scale && w13_q && w13_scale && act_q && act_bscale && expert_offsets, GLM_ERR_INVALID,
+                  "glm_grouped_gemm_gateup_silu_fp8a8: null pointer");
+    GLM_CHECK_ARG(R >= 0 && H > 0 && I > 0 && G >= 1 && ldx >= H && w13_row_stride >= H && ld_act >= I &&
+                      (G == 1 || (w13_group_stride >= (int64_t)2 * I * w13_row_stride && w13_scale_group_stride >= (int64_t)2 * I)),
+                  GLM_ERR_INVALID, "glm_grouped_gemm_gateup_silu_fp8a8: bad shape");
+    if (R == 0) return GLM_OK;
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.a8 = 1;
+    p.x = (const bf16_t*)x_q; p.ldx = ldx; p.xscale = x_scale;
+    p.w = (const bf16_t*)w13_q; p.w_gstride = w13_group_stride; p.ldw = w13_row_stride;
+    p.wscale = w13_scale; p.wscale_gstride = w13_scale_group_stride;
+    p.offs = expert_offsets; p.src = sorted_token;
+    p.y = (bf16_t*)act_q; p.ldy = ld_act; p.ybscale = (unsigned char*)act_bscale;
+    p.R = R; p.N = I; p.K = H; p.G = G;
+    return glm_launch_gemm_largem_a8(GEMM_GATEUP, p, glm_s(stream));
+}
+
+extern "C" int glm_grouped_gemm_down_fp8a8(const void* act_q, int64_t ld_act, const void* act_bscale, const void* w2_q,
+                                           int64_t w2_group_stride, int64_t w2_row_stride, const float* w2_scale,
+                                           int64_t w2_scale_group_stride, const int32_t* expert_offsets,
+                                           const void* sorted_scale, int n_scaled_groups, void* y, int64_t ldy, int64_t R,
+                                           int H, int I, int G, glm_stream_t stream) {
+    GLM_CHECK_ARG(act_q && act_bscale && w2_q && w2_scale && y && expert_offsets, GLM_ERR_INVALID,
+                  "glm_grouped_gemm_down_fp8a8: null pointer");
+    GLM_CHECK_ARG(R >= 0 && H > 0 && I > 0 && G >= 1 && ldy >= H && w2_row_stride >= I && ld_act >= I &&
+                      (G == 1 || (w2_group_stride >= (int64_t)H * w2_row_stride && w2_scale_group_stride >= H)) &&
+                      (n_scaled_groups == 0 || sorted_scale != nullptr),
+                  GLM_ERR_INVALID, "glm_grouped_gemm_down_fp8a8: bad shape");
+    if (R == 0) return GLM_OK;
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.a8 = 1;
+    p.x = (const bf16_t*)act_q; p.ldx = ld_act; p.xbscale = (const unsigned char*)act_bscale;
+    p.w = (const bf16_t*)w2_q; p.w_gstride = w2_group_stride; p.ldw = w2_row_stride;
+    p.wscale = w2_scale; p.wscale_gstride = w2_scale_group_stride;
+    p.offs = expert_offsets; p.src = nullptr;
+    p.scale = (const bf16_t*)sorted_scale; p.n_scaled = n_scaled_groups;
+    p.y = (bf16_t*)y; p.ldy = ldy;
+    p.R = R; p.N = H; p.K = I; p.G = G;
+    return glm_launch_gemm_largem_a8(GEMM_DOWN, p, glm_s(stream));
+}
+
 extern "C" size_t glm_fp8w_expand_scratch_bytes(int G, int rows, int cols) {
     // 0: the tiled kernel takes this stack's fp8 bytes directly (K a multiple of its 64-wide K tile)
     if (fp8w_native_enabled() && cols % 64 == 0) return 0;

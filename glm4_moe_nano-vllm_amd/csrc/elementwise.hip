@@ -766,3 +766,66 @@ int glm_launch_fp8_expand(const void* q, int64_t ld_q, int64_t gs_q, void* out, 
     return GLM_OK;
 }
 
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// r05, N4 / BASELINE configs[4]: dynamic per-row quantisation of activation rows to OCP fp8 e4m3 for the fp8 x fp8 expert
+// GEMM (csrc/gemm_largem.hip, LmCfgC88):  s[t] = max(amax(|x[t]|) / 448, 2^-126),  q[t, :] = RNE(clamp(x[t, :] / s[t], +-448)).
+// One wave per row (H / 8 sixteen-byte pieces over its lanes, H <= 16384), the row is read once and kept in registers.
+// No reference counterpart (its quantised path is int4 AWQ dequant-then-GEMM, layers/linear_awq_new.py:254-255).
+constexpr int QF8_MAX_VEC = 32;   // 16-byte pieces per lane: H <= 64 * 8 * 32 = 16384
+__global__ __launch_bounds__(256) void quantize_fp8_rows_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                                unsigned char* __restrict__ q, int64_t ldq,
+                                                                float* __restrict__ scale, int64_t T, int H) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const int nvec = H >> 3;
+    const u32x4_t* xr = reinterpret_cast<const u32x4_t*>(x + t * ldx);
+    u32x4_t v[QF8_MAX_VEC];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < QF8_MAX_VEC; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = u32x4_t{0, 0, 0, 0};
+        if (c < nvec) {
+            v[i] = xr[c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(bflo(v[i][j])), fabsf(bfhi(v[i][j]))));
+        }
+    }
+    amax = wave_max(amax);
+    const float s = fmaxf(amax / 448.0f, 1.17549435e-38f);
+    if (lane == 0) scale[t] = s;
+    unsigned char* qr = q + t * ldq;
+#pragma unroll
+    for (int i = 0; i < QF8_MAX_VEC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvec) {
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f[2 * j] = fminf(fmaxf(bflo(v[i][j]) / s, -448.0f), 448.0f);
+                f[2 * j + 1] = fminf(fmaxf(bfhi(v[i][j]) / s, -448.0f), 448.0f);
+            }
+            int d0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+            d0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], d0, true);
+            int d1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+            d1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], d1, true);
+            *reinterpret_cast<u32x2_t*>(qr + (int64_t)c * 8) = u32x2_t{(unsigned)d0, (unsigned)d1};
+        }
+    }
+}
+
+extern "C" int glm_quantize_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int64_t T, int H,
+                                     glm_stream_t stream) {
+    GLM_CHECK_ARG(x && q && scale, GLM_ERR_INVALID, "glm_quantize_fp8_rows: null pointer");
+    GLM_CHECK_ARG(T >= 0 && H > 0 && ldx >= H && ldq >= H, GLM_ERR_INVALID, "glm_quantize_fp8_rows: bad shape");
+    GLM_CHECK_ARG(H % 8 == 0 && H <= 64 * 8 * QF8_MAX_VEC && ldx % 8 == 0 && ldq % 8 == 0 && glm_aligned16(x) && (((uintptr_t)q) & 7) == 0,
+                  GLM_ERR_UNSUPPORTED, "glm_quantize_fp8_rows: needs H %% 8 == 0, H <= 16384, 16-byte aligned rows (H=%d)", H);
+    if (T == 0) return GLM_OK;
+    hipLaunchKernelGGL(quantize_fp8_rows_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, glm_s(stream), (const bf16_t*)x, ldx,
+                       (unsigned char*)q, ldq, scale, T, H);
+    GLM_CHECK_LAUNCH("glm_quantize_fp8_rows");
+    return GLM_OK;
+}

@@ -17,6 +17,14 @@ struct GemmParams {
     const float* wscale;  // fp8 weights only: per-row dequantisation scale, group g at + g*wscale_gstride
     int64_t wscale_gstride;
     int w_fp8;            // gemm_largem only: w points at OCP fp8 e4m3 BYTES (strides in bytes), converted on the fragment read
+    // gemm_largem, r05 (glm_launch_gemm_largem_a8): BOTH operands fp8 e4m3 on the block-scaled MFMA.  x, w: bytes, ldx / ldw /
+    // w_gstride in bytes; wscale: per weight row.  GATEUP: xscale = per SOURCE token row fp32 scale (block scales 1); the
+    // epilogue quantises act per (row, 32 columns) — y = fp8 bytes [R, I] (ldy in bytes), ybscale = E8M0 bytes [R, 64] at
+    // (block & 3) * 16 + (block >> 2).  DOWN: xbscale = that table for the act rows, y = bf16 as ever.
+    int a8;
+    const float* xscale;
+    const unsigned char* xbscale;
+    unsigned char* ybscale;
     const int32_t* offs;  // [G+1] row offsets per group, or nullptr (one group of R rows)
     const int32_t* src;   // source row of sorted row r, or nullptr (identity)
     const bf16_t* scale;  // [R] per-row scale (GEMM_DOWN) or nullptr
@@ -72,6 +80,8 @@ int glm_launch_gemm_smallm_fp8w(int mode, const GemmParams& p, hipStream_t st);
 // LDS-tiled MFMA kernels for many rows per group (prefill); p.wscale != nullptr: per-weight-row fp32 scale applied to
 // the accumulator before the bf16 roundings (weights expanded from fp8, elementwise.hip)
 int glm_launch_gemm_largem(int mode, const GemmParams& p, hipStream_t st);
+// ... fp8 x fp8 (p.a8): grouped GATEUP / DOWN on 256-row blocks only; GLM_ERR_UNSUPPORTED otherwise (nothing enqueued)
+int glm_launch_gemm_largem_a8(int mode, const GemmParams& p, hipStream_t st);
 // ... GEMM_PLAIN with the QKV epilogue (p.qkv_*): GLM_ERR_UNSUPPORTED when the shape is outside the product loop's cover
 int glm_launch_gemm_largem_qkv(const GemmParams& p, hipStream_t st);
 // exact fp8 e4m3 -> bf16 expansion of a weight stack [G, rows, cols] (element strides)

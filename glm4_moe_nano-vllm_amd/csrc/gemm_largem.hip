@@ -55,16 +55,22 @@ int g_largem_band = GLM_LM_BAND;  // row blocks per L2 supertile band (glm_debug
 // Tile configurations (the kernel is written once over these):
 //   CfgA 256(n) x 128(m) x 64(k), 3-stage ring, wave tile 64x64  (16 LDS reads + 6 DMA per 32 MFMA)
 //   CfgB 256(n) x 256(m) x 32(k), 4-stage ring, wave tile 64x128 (12 LDS reads + 4 DMA per 32 MFMA)
-template <int BM_, int BK_, int NSTAGE_, bool PH8_ = false, bool W8_ = false>
+template <int BM_, int BK_, int NSTAGE_, bool PH8_ = false, bool W8_ = false, bool A8_ = false>
 struct LmCfg {
     static constexpr int BM = BM_, BK = BK_, NSTAGE = NSTAGE_;
     static constexpr bool PH8 = PH8_;              // quadrant-phase main loop (CfgC)
+    // A8 (r05): BOTH operands are OCP fp8 e4m3 in memory and in LDS, BK = 128 elements = 128-byte tile rows — the LDS image,
+    // the DMA pieces, the swizzle and the two ds_read_b128 per 16-row tile are byte for byte those of the bf16 CfgC (chunk g4
+    // and chunk 4 + g4 of a row are exactly the two register halves of a v_mfma_scale_f32_16x16x128_f8f6f4 operand:
+    // profiles/r05/mfma_f8f6f4_probe_v2.txt); a quadrant is 8 block-scaled MFMAs of K = 128 instead of 16 of K = 32.
+    static constexpr bool A8 = A8_;
+    static_assert(!A8 || (BK_ == 128 && !W8_), "fp8 x fp8: 128-byte rows of 128 elements");
     // W8: the weight operand is OCP fp8 e4m3 in memory AND in LDS (half the DMA instructions, half the LDS bytes and
     // fragment-read bytes of the weight tile); a fragment is converted to bf16 (exactly: every e4m3 value is a bf16
     // value) between its ds_read and the MFMA, and the per-row dequantisation scale multiplies the fp32 accumulator in the
     // epilogue (WSCALE) — the arithmetic of the expansion pass + bf16 kernel it replaces, bit for bit.
     static constexpr bool W8 = W8_;
-    static constexpr int RB = BK * 2;              // bytes per ACTIVATION tile row (and per weight tile row unless W8)
+    static constexpr int RB = A8 ? BK : BK * 2;    // bytes per ACTIVATION tile row (and per weight tile row unless W8)
     static constexpr int CPR = RB / 16;            // 16-B chunks per row
     static constexpr int RPI = 1024 / RB;          // rows per DMA instruction
     static constexpr int WRB = W8 ? BK : RB;       // bytes per WEIGHT tile row
@@ -74,7 +80,7 @@ struct LmCfg {
     static constexpr int W_DMA = LM_BN / WRPI / 8; // weight DMA instructions per wave per tile
     static constexpr int X_DMA = BM / RPI / 8;     // activation DMA instructions per wave per tile
     static constexpr int DPW = W_DMA + X_DMA;
-    static constexpr int KS = BK / 32;             // MFMA k-steps per tile
+    static constexpr int KS = A8 ? 2 : BK / 32;    // MFMA k-steps per tile (A8: the two 16-byte halves of ONE K = 128 operand)
     static constexpr int MT = BM / 2 / 16;         // 16-token MFMA tiles per wave (2 waves along m)
     static constexpr int WT = LM_BN * WRB;         // weight tile bytes
     static constexpr int XT = BM * RB;
@@ -103,6 +109,7 @@ using LmCfgB5 = LmCfg<256, 32, 5>;  // variant LM_DEEP: prefetch distance 4
 using LmCfgC = LmCfg<256, 64, 2, true>;
 using LmCfgC8 = LmCfg<256, 64, 2, true, true>;  // fp8 weight operand (two 48-KiB buffers)
 using LmCfgA8 = LmCfg<128, 64, 3, false, true>;
+using LmCfgC88 = LmCfg<256, 128, 2, true, false, true>;  // fp8 x fp8 on the block-scaled MFMA (two 64-KiB buffers)
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
@@ -369,7 +376,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         if (LEAN) {
             // descriptor of the group's weights (wave-uniform; grp came through LDS, so make that provable)
             const int64_t goff = (int64_t)__builtin_amdgcn_readfirstlane(grp) * p.w_gstride;
-            if constexpr (C::W8) wrs = make_rsrc(reinterpret_cast<const char*>(p.w) + goff);  // fp8: strides in bytes
+            if constexpr (C::W8 || C::A8) wrs = make_rsrc(reinterpret_cast<const char*>(p.w) + goff);  // fp8: strides in bytes
             else wrs = make_rsrc(p.w + goff);
 #pragma unroll
             for (int i = 0; i < C::W_DMA; ++i) {
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                 int wr;
                 if (MODE == GEMM_GATEUP) wr = (row >> 7) * p.N + min(ntile * 128 + (row & 127), p.N - 1);
                 else wr = min(ntile * LM_BN + row, p.N - 1);
-                if constexpr (C::W8) wvo[i] = (unsigned)(wr * (int)p.ldw + ch * 16);
+                if constexpr (C::W8 || C::A8) wvo[i] = (unsigned)(wr * (int)p.ldw + ch * 16);
                 else wvo[i] = (unsigned)(wr * (int)p.ldw + ch * 8) * 2u;
             }
 #pragma unroll
@@ -387,7 +394,8 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                 const int ch = (lane % C::CPR) ^ C::swz(row);
                 const int mr = row < mcnt ? row : 0;
                 const int srow = p.src ? p.src[m0 + mr] : m0 + mr;
-                xvo[i] = (unsigned)(srow * (int)p.ldx + ch * 8) * 2u;
+                if constexpr (C::A8) xvo[i] = (unsigned)(srow * (int)p.ldx + ch * 16);  // fp8 activations: ldx in bytes
+                else xvo[i] = (unsigned)(srow * (int)p.ldx + ch * 8) * 2u;
             }
             return;
         }
@@ -422,10 +430,10 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         constexpr int j = decltype(jc)::value;
         const int k0 = kt * C::BK;
         if constexpr (j < C::W_DMA)
-            blds16(wrs, smem + slot * C::STAGE + wid * C::W_DMA * 1024 + j * 1024, wvo[j], k0 * (C::W8 ? 1 : 2));
+            blds16(wrs, smem + slot * C::STAGE + wid * C::W_DMA * 1024 + j * 1024, wvo[j], k0 * ((C::W8 || C::A8) ? 1 : 2));
         else
             blds16(xrs, smem + slot * C::STAGE + C::WT + wid * C::X_DMA * 1024 + (j - C::W_DMA) * 1024,
-                   xvo[j - C::W_DMA], k0 * 2);
+                   xvo[j - C::W_DMA], k0 * (C::A8 ? 1 : 2));
     };
     auto stage = [&](int slot, int kt) {
         char* wdst = smem + slot * C::STAGE + wid * C::W_DMA * 1024;
@@ -434,10 +442,10 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         if (LEAN) {
 #pragma unroll
             for (int i = 0; i < C::W_DMA; ++i)
-                blds16(wrs, wdst + i * 1024, wvo[i], k0 * (C::W8 ? 1 : 2));
+                blds16(wrs, wdst + i * 1024, wvo[i], k0 * ((C::W8 || C::A8) ? 1 : 2));
 #pragma unroll
             for (int i = 0; i < C::X_DMA; ++i)
-                blds16(xrs, xdst + i * 1024, xvo[i], k0 * 2);
+                blds16(xrs, xdst + i * 1024, xvo[i], k0 * (C::A8 ? 1 : 2));
             return;
         }
 #pragma unroll
@@ -445,7 +453,26 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
 #pragma unroll
         for (int i = 0; i < C::X_DMA; ++i) glds16(k0 + xch[i] * 8 < K ? xsrc[i] + k0 : zero, xdst + i * 1024);
     };
+    // A8 DOWN: the E8M0 block scales of the tile's activation rows behind the tile table (16 KiB), two 1-KiB LDS-DMA pieces
+    // per wave.  LDS image: 16-byte slot (g * 256 + row) = the scales of (row, natural block 4 kt + g) for kt = 0 .. 15 — a
+    // lane (row c of X tile mt, lane row g4) reads ONE dword of its slot every four K tiles (bytes kt & ~3 .. + 3) and shifts
+    // the byte of the K tile into place (r05 first form: one ds_read_u8 per X tile and K tile out of [row][64 B] records —
+    // 8-way bank conflicts, the down projection gained nothing over bf16: profiles/r05/fp8a8_probe.txt).
+    constexpr bool XBS = C::A8 && MODE == GEMM_DOWN;
+    constexpr int XBS_OFF = C::NSTAGE * C::STAGE + 16 + 64 * 16;
+    auto stage_scales = [&]() {
+        if constexpr (XBS) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int slot = (wid * 2 + i) * 64 + lane;       // lane-linear destination: slot = g * 256 + row
+                const int row = slot & 255, g = slot >> 8;
+                const int mr = row < mcnt ? row : 0;
+                glds16(p.xbscale + (int64_t)(m0 + mr) * 64 + g * 16, smem + XBS_OFF + (wid * 2 + i) * 1024);
+            }
+        }
+    };
     auto fill_ring = [&]() {
+        stage_scales();
         if constexpr (C::PH8) {
             // both operands of K tile 0 and the weights of K tile 1 (their slot is the first one the loop refills)
             static_for<C::DPW>([&](auto jc) { stage_one(0, 0, jc); });
@@ -617,6 +644,28 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         static_assert(!(P3X && QW), "LM_P3X refills the X slot while LM_QW still reads it");
         if (wid >= 4) __builtin_amdgcn_s_barrier();   // the stagger
         u32x4_t fw[8], fx[8];  // [k-step][W tile 0-3], [k-step][X tile of the current part]
+        int sxw[8] = {127, 127, 127, 127, 127, 127, 127, 127};  // A8: per X tile, the E8M0 scale bytes of four K tiles (127 = 2^0:
+                                                                 // gate|up, whose activation scale is per token)
+        int ksh = 0;                                             // 8 * (K tile & 3): the byte of the current K tile
+        const unsigned sx_base = lds_addr(smem) + XBS_OFF + (g4 * 256 + wm * (C::BM / 2) + c) * 16;
+        auto rd_s_ = [&](int (&w)[8], int kt_) {  // every fourth K tile, in its phase 0 (behind the same lgkmcnt wait)
+            if constexpr (XBS) {
+                if ((kt_ & 3) == 0) {
+                    const unsigned a_ = sx_base + kt_;
+#define GLM_RD_S(J) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(w[J]) : "v"(a_), "i"((J) * 256))
+                    GLM_RD_S(0); GLM_RD_S(1); GLM_RD_S(2); GLM_RD_S(3); GLM_RD_S(4); GLM_RD_S(5); GLM_RD_S(6); GLM_RD_S(7);
+#undef GLM_RD_S
+                }
+            }
+        };
+#define rd_s(KT) rd_s_(sxw, KT)
+        auto pin_s_ = [&](int (&w)[8]) {
+            if constexpr (XBS) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(w[j]));
+            }
+        };
+#define pin_s() pin_s_(sxw)
         u32x2_t fwr[C::W8 ? 8 : 1];  // W8: the fragments as read (fp8), converted into fw behind the read wait
         auto cvt_w = [&]() {
             if constexpr (C::W8) {
@@ -660,6 +709,22 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             constexpr int mt0 = decltype(m0c)::value, NX = decltype(nxc)::value, XB = decltype(xbc)::value;
             if constexpr ((VAR & LM_LOADPRIO) != 0) __builtin_amdgcn_s_setprio(0);
             else if constexpr ((VAR & LM_NOPRIO) == 0) __builtin_amdgcn_s_setprio(1);
+            if constexpr (C::A8) {
+                // ONE K = 128 MFMA per (W tile, X tile): registers 0-3 = chunk g4, registers 4-7 = chunk 4 + g4 of the row
+                typedef int v8i_t __attribute__((ext_vector_type(8)));
+                typedef unsigned u32x8_t __attribute__((ext_vector_type(8)));
+                static_assert(NX == 2, "the scale registers follow the 4 x 2-tile quadrants");
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) {
+                        const u32x8_t a8 = __builtin_shufflevector(fw[t0 + tt], fw[4 + t0 + tt], 0, 1, 2, 3, 4, 5, 6, 7);
+                        const u32x8_t b8 = __builtin_shufflevector(fx[XB + j], fx[XB + NX + j], 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[t0 + tt][mt0 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                            __builtin_bit_cast(v8i_t, a8), __builtin_bit_cast(v8i_t, b8), acc[t0 + tt][mt0 + j], 0, 0, 0, 127, 0,
+                            XBS ? (int)((unsigned)sxw[mt0 + j] >> ksh) : 127);
+                    }
+            } else
 #pragma unroll
             for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
@@ -698,7 +763,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         //           (vmcnt leaves the 6 younger pieces X(kt+1) 0-3, W(kt+2) 0,1 in flight), i.e. before barrier 8kt+6
         //           at the latest, and first read in load interval 4kt+3 (epoch >= 8kt+6).
         static_assert(!P3X && !QW, "LM_MIR is its own schedule");
-        static_assert(!C::W8, "fp8 weight operand: product loop only");
+        static_assert(!C::W8 && !C::A8, "fp8 operands: product loop only");
         static_assert(!PARK, "LM_PARK is wired into the plain quadrant loop only");
         auto ktile = [&](int kt, auto parc) {
             constexpr int PAR = decltype(parc)::value;
@@ -773,7 +838,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         //           (retired by the lgkmcnt(0) before its closing barrier, epoch <= 8kt+6) and refilled from load
         //           interval 4kt+4 (epoch >= 8kt+8); W(kt) is last read in load interval 4kt as under LM_QW.
         static_assert(QW, "LM_RPRE is a schedule of the LM_QW quadrants");
-        static_assert(!C::W8, "fp8 weight operand: product loop only");
+        static_assert(!C::W8 && !C::A8, "fp8 operands: product loop only");
         static_assert(!PARK, "LM_PARK is wired into the plain quadrant loop only");
         auto pre_x = [&](unsigned so, auto m0c, auto xbc) {  // issue the reads, keep the MFMAs behind them
             rd_x(so, m0c, I2{}, xbc);
@@ -833,6 +898,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         //           issues then run under the LDS round trip of the reads instead of in front of it.
         constexpr bool RF = (VAR & LM_RFIRST) != 0;
         static_assert(!C::W8 || (QW && !P3X && !PARK), "fp8 weight operand: wired into the product quadrant loop");
+        static_assert(!C::A8 || (QW && !P3X && !PARK), "fp8 x fp8: wired into the product quadrant loop");
 #if GLM_LM_STAMP
         unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
 #endif
@@ -841,6 +907,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             const unsigned so = b * C::STAGE;
             const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
             auto mid = [&]() { __builtin_amdgcn_sched_barrier(0); };
+            ksh = (kt & 3) * 8;
             // ---- phase 0
             auto dma0 = [&]() { if (!P3X && has1) dma2(b ^ 1, kt + 1, XP0{}); };
             LM_T(0);
@@ -848,6 +915,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             if constexpr (QW) {
                 rd_w(so, I0{}, I4{});
                 rd_x(so, I0{}, I2{}, I0{});
+                rd_s(kt);
             } else {
                 rd_w(so, I0{}, I2{});
                 rd_x(so, I0{}, I4{}, I0{});
@@ -862,6 +930,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                 for (int i = 0; i < 8; ++i) pin(fw[i]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) pin(fx[i]);
+                pin_s();
             } else {
                 pin(fw[0]); pin(fw[1]); pin(fw[4]); pin(fw[5]);
 #pragma unroll
@@ -1089,6 +1158,8 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         // waves 4-7 are past every LDS read of this tile here, waves 0-3 finished theirs before the last barrier
 #endif
         }  // !C::PH8
+#undef rd_s
+#undef pin_s
 
         // per-row scales of the finished tile: requested before the ring fill (waiting for a load issued after the fill
         // would drain the fill first)
@@ -1109,12 +1180,23 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         ++ti;
         const bool more = find_tile();
         LM_TS(3);  // 2: tile search
+        // A8 (r05): the epilogue of the fp8 x fp8 kernels LOADS (weight-row scales, token scales) and vector-memory results
+        // return in issue order — behind the ring fill they cost a whole fill latency per tile (stamps of the first form:
+        // epilogue 23.5k cycles against 6.0k for bf16, and the late stores then drain into the next tile's short K loop:
+        // profiles/r05/largem_stamps_fp8a8_first_form.txt).  There the next tile's fill is issued once the first 16-row
+        // block of the epilogue has its loads back, i.e. behind them and in front of the bulk of the stores.
+        constexpr bool LATE_FILL = C::A8;
         if (more) {
-            setup_sources();
+            setup_sources();   // (its own loads — the gathered source rows — go out here, in front of the epilogue's)
             LM_TS(4);  // 3: source set-up
-            fill_ring();
-            LM_TS(5);  // 4: ring fill issue
         }
+        auto start_next = [&]() {
+            if (more) {
+                fill_ring();
+                LM_TS(5);  // 4: ring fill issue
+            }
+        };
+        if constexpr (!LATE_FILL) start_next();
 
         // ---- epilogue of the finished tile ----
         constexpr bool WIDE = (VAR & LM_WIDEST) != 0, NOSTORE = (VAR & LM_NOSTORE) != 0;
@@ -1188,9 +1270,85 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                     }
                 }
             }
-        } else
+        } else if constexpr (C::A8 && MODE == GEMM_GATEUP) {
+            // ---- fp8 x fp8 gate|up (r05): the accumulator x weight-row scale x token scale is the bf16 GEMM's value up to the
+            // fp8 roundings of its inputs; same rounding points behind it (mlp.py:49-53: bf16 gate_up, bf16 silu, bf16
+            // product).  The product is then quantised for the down projection's fp8 operand in MX form, decided locally:
+            // a wave's 32 act columns of a token ARE one 32-element block (ncol_w is a multiple of 32) — amax over the lane's 8
+            // values and the 3 other lane rows of the token, E8M0 scale 2^(floor(log2 amax) - 8) (OCP MX: e4m3 emax = 8) or,
+            // where that would push amax past 448, the next power of two (nothing saturates), e4m3 = RNE(v / scale).  act8 [R, I] bytes + one scale byte per (row, block) at
+            // (block & 3) * 16 + (block >> 2) of the row's 64-byte record — the order the down kernel's lanes read it in.
+            const float* ws = p.wscale + (int64_t)grp_c * p.wscale_gstride;
+            float wsg[2][4], wsu[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n1 = min(ncol_w + 16 * t + 4 * g4 + r, p.N - 1);
+                    wsg[t][r] = ws[n1];
+                    wsu[t][r] = ws[p.N + n1];
+                }
+            unsigned char* y8 = reinterpret_cast<unsigned char*>(p.y);
+            const bool col_ok = ncol_w < p.N;
+            float xs_all[C::MT];   // token scales of the wave's 8 row blocks: all requested in front of the ring fill
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt) {
+                const int row = wm * (C::BM / 2) + 16 * mt + c;
+                const int64_t m = m0_c + ((row < mcnt_c && col_ok) ? row : 0);
+                xs_all[mt] = p.xscale[p.src ? p.src[m] : m];
+            }
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt) {
+                const int row = wm * (C::BM / 2) + 16 * mt + c;
+                const bool row_ok = row < mcnt_c && col_ok;
+                const int64_t m = m0_c + (row_ok ? row : 0);
+                const float xs = xs_all[mt];
+                float v[2][4];
+                float amax = 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float ga = acc[t][mt][r] * wsg[t][r] * xs, ua = acc[t + 2][mt][r] * wsu[t][r] * xs;
+                        v[t][r] = rbf(rbf(glm_silu(rbf(ga))) * rbf(ua));
+                        amax = fmaxf(amax, fabsf(v[t][r]));
+                    }
+                amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+                amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                const unsigned ab = __float_as_uint(amax);
+                const int eb = (int)((ab >> 23) & 0xffu);   // biased exponent (0: zero or subnormal block)
+                // 2^(floor(log2 amax) - 8) maps amax into [256, 512); above 448 = 1.75 x 2^8 it would saturate: one step up then
+                const int sb = eb == 0 ? 127 : min(max(eb - 8 + ((ab & 0x7fffffu) > 0x600000u ? 1 : 0), 1), 253);
+                const float inv = __uint_as_float((unsigned)(254 - sb) << 23);    // 2^(127 - sb), exact
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float q[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q[r] = fminf(fmaxf(v[t][r] * inv, -448.0f), 448.0f);
+                    int d = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
+                    d = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], d, true);
+                    const int n = ncol_w + 16 * t + 4 * g4;
+                    if (row_ok && !NOSTORE && n < p.N) *reinterpret_cast<int*>(y8 + m * p.ldy + n) = d;
+                }
+                if (row_ok && !NOSTORE && g4 == 0) p.ybscale[m * 64 + wn * 16 + ntile_c] = (unsigned char)sb;
+                if (mt == 0) start_next();
+            }
+        } else {
+        // weight-row scales of this wave's output columns: loaded ONCE, in front of the row blocks (and, for the fp8 x fp8
+        // kernels, in front of the next tile's ring fill)
+        float wsv[WSCALE && MODE != GEMM_GATEUP ? 4 : 1][4];
+        if constexpr (WSCALE && MODE != GEMM_GATEUP) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    wsv[t][r] = p.wscale[(int64_t)grp_c * p.wscale_gstride + min(ncol_w + 16 * t + 4 * g4 + r, p.N - 1)];
+        }
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt) {
+            if constexpr (LATE_FILL) {
+                if (mt == 1) start_next();
+            }
             const int row = wm * (C::BM / 2) + 16 * mt + c;
             const bool row_ok = row < mcnt_c;
             bf16_t* yrow = p.y + (int64_t)(m0_c + (row_ok ? row : 0)) * p.ldy;
@@ -1214,7 +1372,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                         o[r] = rbf(glm_silu(rbf(ga))) * rbf(ua);
                     } else {
                         float a = acc[t][mt][r];
-                        if constexpr (WSCALE) a *= p.wscale[(int64_t)grp_c * p.wscale_gstride + min(ncol_w + 16 * t + 4 * g4 + r, p.N - 1)];
+                        if constexpr (WSCALE) a *= wsv[t][r];
                         if (MODE == GEMM_PLAIN && p.bias) a += bf2f(p.bias[min(ncol_w + 16 * t + 4 * g4 + r, p.N - 1)]);
                         if (scaled) a = rbf(a) * sc;
                         o[r] = a;
@@ -1280,9 +1438,10 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                 }
             }
         }
+        }
         if constexpr ((VAR & LM_EPIORD) != 0) {
             // exact only when every store instruction of the wave ran: all rows and columns of the tile exist
-            const bool full = mcnt_c == C::BM && ncol_w + (MODE == GEMM_GATEUP ? 32 : 64) <= p.N && !NOSTORE &&
+            const bool full = !LATE_FILL && mcnt_c == C::BM && ncol_w + (MODE == GEMM_GATEUP ? 32 : 64) <= p.N && !NOSTORE &&
                               !((VAR & LM_LDSEPI) != 0 && NOUT == 4) && !(MODE == GEMM_PLAIN && p.qkv_q != nullptr);
             pending_stores = full ? LM_STORES_FULL - (do_park ? PARK_N : 0) : 0;
         }
@@ -1321,8 +1480,8 @@ int launch_largem_cfg(const GemmParams& p, hipStream_t st) {
     GLM_CHECK_ARG(total < (1ll << 31), GLM_ERR_UNSUPPORTED, "gemm_largem: grid too large");
     // the per-row scale of fp8-expanded weights is its own instantiation: as a run-time test it sat inside the epilogue's
     // element loop (a branch per accumulator register)
-    auto kern = (C::W8 || p.wscale) ? gemm_largem_kernel<MODE, C, VAR, true> : gemm_largem_kernel<MODE, C, VAR, !C::W8 ? false : true>;
-    constexpr int LDS_BYTES = (C::PH8 && (VAR & LM_PARK) != 0) ? 160 * 1024 : C::LDS;
+    auto kern = (C::W8 || C::A8 || p.wscale) ? gemm_largem_kernel<MODE, C, VAR, true> : gemm_largem_kernel<MODE, C, VAR, !(C::W8 || C::A8) ? false : true>;
+    constexpr int LDS_BYTES = (C::PH8 && (VAR & LM_PARK) != 0) ? 160 * 1024 : C::LDS + ((C::A8 && MODE == GEMM_DOWN) ? 16 * 1024 : 0);
     GLM_SET_MAX_LDS(kern, LDS_BYTES, "gemm_largem");
     // one workgroup per CU (the ring takes most of the LDS), a multiple of 8 so that every XCD gets the same count
     static int n_cu = 0;
@@ -1442,6 +1601,26 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
 }
 
 }  // namespace
+
+// fp8 x fp8 grouped expert projections on the block-scaled MFMA (r05; BASELINE configs[4]): the product quadrant loop on
+// 256-row blocks.  Strides of x / w in BYTES.
+int glm_launch_gemm_largem_a8(int mode, const GemmParams& p, hipStream_t st) {
+    constexpr int V88 = LM_LEAN | LM_WIDEST | LM_PH8 | LM_QW | LM_RFIRST | LM_NOPRIO | LM_EPIORD;
+    const int64_t avg_rows = (p.R_hint > 0 ? p.R_hint : p.R) / (p.G > 0 ? p.G : 1);
+    const int64_t wrows = mode == GEMM_GATEUP ? 2 * (int64_t)p.N : (int64_t)p.N;
+    const bool ok = (mode == GEMM_GATEUP || mode == GEMM_DOWN) && p.a8 && p.wscale != nullptr && p.offs != nullptr && avg_rows >= 192 &&
+                    p.K % 128 == 0 && p.N % 8 == 0 && p.ldx % 16 == 0 && p.ldw % 16 == 0 && p.w_gstride % 16 == 0 &&
+                    p.R * p.ldx < (1ll << 31) && wrows * p.ldw < (1ll << 31) && glm_aligned16(p.x) && glm_aligned16(p.w) &&
+                    (mode == GEMM_GATEUP ? (p.xscale != nullptr && p.ybscale != nullptr && p.ldy % 4 == 0 && (((uintptr_t)p.y) & 3) == 0 &&
+                                            p.N % 32 == 0 && p.N <= 2048)
+                                         : (p.xbscale != nullptr && glm_aligned16(p.xbscale) && p.K <= 2048 && p.ldy % 8 == 0 && glm_aligned16(p.y)));
+    if (!ok) {
+        glm_set_error("gemm_largem(fp8 x fp8): shape not covered (mode %d R=%ld G=%d N=%d K=%d)", mode, (long)p.R, p.G, p.N, p.K);
+        return GLM_ERR_UNSUPPORTED;
+    }
+    if (mode == GEMM_GATEUP) return launch_largem_cfg<GEMM_GATEUP, LmCfgC88, V88>(p, st);
+    return launch_largem_cfg<GEMM_DOWN, LmCfgC88, V88>(p, st);
+}
 
 // QKV projection with the split / rotary / cache-store epilogue: the product loop on the tiled configurations only
 int glm_launch_gemm_largem_qkv(const GemmParams& p, hipStream_t st) {

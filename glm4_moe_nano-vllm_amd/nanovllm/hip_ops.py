@@ -92,6 +92,13 @@ _SIGNATURES = {
     "glm_gemm_bf16_router_tail": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "glm_quantize_fp8_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
+    "glm_grouped_gemm_gateup_silu_fp8a8": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                                                   c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
+                                                   c_int, c_void_p]),
+    "glm_grouped_gemm_down_fp8a8": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                                            c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
+                                            c_void_p]),
     "glm_decode_mlp_engine_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "glm_decode_mlp_engine": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -756,6 +763,55 @@ def quantize_fp8_rowwise(w: torch.Tensor):
     view = store[..., :cols]
     view.copy_(q.view(torch.uint8))
     return view, s.contiguous()
+
+
+def quantize_fp8_rows(x: torch.Tensor):
+    """Dynamic per-row e4m3 quantisation of activation rows (glm_quantize_fp8_rows): x [T, H] bf16 ->
+    (q [T, H] uint8, scale [T] fp32) with x ~ q * scale[:, None]."""
+    _bf16(x, "x")
+    assert x.dim() == 2 and x.stride(1) == 1
+    T, H = x.shape
+    q = torch.empty((T, H), dtype=torch.uint8, device=x.device)
+    s = torch.empty(T, dtype=torch.float32, device=x.device)
+    _check(load_library().glm_quantize_fp8_rows(_p(x), x.stride(0), _p(q), q.stride(0), _p(s), T, H, _stream()),
+           "glm_quantize_fp8_rows")
+    return q, s
+
+
+def grouped_gemm_gateup_silu_fp8a8(x_q, x_scale, w13_q, w13_s, expert_offsets, sorted_token, R: int):
+    """fp8 x fp8 gate|up on the block-scaled MFMA (glm_grouped_gemm_gateup_silu_fp8a8).  x_q [T, H] uint8 + x_scale [T];
+    w13_q [G, 2I, H] uint8 + w13_s [G, 2I].  Returns (act_q [R, I] uint8, act_bscale [R, 64] uint8: E8M0 per 32 columns) — or
+    None when the launcher does not cover the shape (nothing enqueued: take the weight-only path)."""
+    G, I2, H = w13_q.shape
+    I = I2 // 2
+    assert x_q.dtype == torch.uint8 and w13_q.dtype == torch.uint8 and x_q.stride(1) == 1 and w13_q.stride(2) == 1
+    assert x_scale.dtype == torch.float32 and w13_s.dtype == torch.float32 and w13_s.stride(1) == 1
+    act = torch.empty((R, I), dtype=torch.uint8, device=x_q.device)
+    bs = torch.zeros((R, 64), dtype=torch.uint8, device=x_q.device)
+    rc = load_library().glm_grouped_gemm_gateup_silu_fp8a8(
+        _p(x_q), x_q.stride(0), _p(x_scale), _p(w13_q), w13_q.stride(0), w13_q.stride(1), _p(w13_s), w13_s.stride(0),
+        _p(expert_offsets), _p(sorted_token), _p(act), act.stride(0), _p(bs), R, H, I, G, _stream())
+    if rc == GLM_ERR_UNSUPPORTED:
+        return None
+    _check(rc, "glm_grouped_gemm_gateup_silu_fp8a8")
+    return act, bs
+
+
+def grouped_gemm_down_fp8a8(act_q, act_bscale, w2_q, w2_s, expert_offsets, sorted_scale, n_scaled_groups: int):
+    """fp8 x fp8 down projection with the act rows' E8M0 block scales inside the MFMA; y [R, H] bf16, or None (shape not
+    covered)."""
+    G, H, I = w2_q.shape
+    R = act_q.shape[0]
+    assert act_q.dtype == torch.uint8 and w2_q.dtype == torch.uint8 and act_bscale.dtype == torch.uint8
+    assert act_bscale.shape == (R, 64) and act_bscale.is_contiguous() and w2_q.stride(2) == 1 and w2_s.stride(1) == 1
+    y = torch.empty((R, H), dtype=torch.bfloat16, device=act_q.device)
+    rc = load_library().glm_grouped_gemm_down_fp8a8(
+        _p(act_q), act_q.stride(0), _p(act_bscale), _p(w2_q), w2_q.stride(0), w2_q.stride(1), _p(w2_s), w2_s.stride(0),
+        _p(expert_offsets), _p(sorted_scale), n_scaled_groups, _p(y), y.stride(0), R, H, I, G, _stream())
+    if rc == GLM_ERR_UNSUPPORTED:
+        return None
+    _check(rc, "glm_grouped_gemm_down_fp8a8")
+    return y
 
 
 _FP8_LARGE_MIN_AVG_ROWS = 96  # api.hip LARGEM_MIN_AVG_ROWS

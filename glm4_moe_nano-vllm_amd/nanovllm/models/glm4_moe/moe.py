@@ -76,6 +76,11 @@ class Glm4MoeMoE(nn.Module):
         # N4: `config.expert_weight_dtype = "fp8_e4m3"` streams the experts as OCP fp8 (weight-only,
         # per-row scale); quantised lazily from the loaded bf16 weights at the first forward
         self.expert_weight_dtype = getattr(config, "expert_weight_dtype", None)
+        # r05, OPT-IN (default off; the weight-only path stays the parity path): `config.expert_activation_dtype = "fp8_e4m3"`
+        # with fp8 expert weights runs prefill-sized steps as W8A8 on the block-scaled fp8 MFMA — x quantised per token, act
+        # per (row, 32 columns) by the gate|up epilogue (hip_ops.grouped_gemm_*_fp8a8); decode-sized steps are HBM-bound
+        # and keep the weight-only kernels
+        self.expert_activation_dtype = getattr(config, "expert_activation_dtype", None)
         self._fp8 = None
         self._bf16_freed = False
 
@@ -193,8 +198,15 @@ class Glm4MoeMoE(nn.Module):
             if self._fp8 is None:
                 self.quantize_experts_fp8()
             w13_q, w13_s, w2_q, w2_s = self._fp8
-            act = hip_ops.grouped_gemm_gateup_silu_fp8w(h, w13_q, w13_s, offs, tok, R)
-            y = hip_ops.grouped_gemm_down_fp8w(act, w2_q, w2_s, offs, scale, E)
+            y = None
+            if self.expert_activation_dtype == "fp8_e4m3" and R // (E + 1) >= 192:
+                xq, xs = hip_ops.quantize_fp8_rows(h)
+                r = hip_ops.grouped_gemm_gateup_silu_fp8a8(xq, xs, w13_q, w13_s, offs, tok, R)
+                if r is not None:
+                    y = hip_ops.grouped_gemm_down_fp8a8(r[0], r[1], w2_q, w2_s, offs, scale, E)
+            if y is None:
+                act = hip_ops.grouped_gemm_gateup_silu_fp8w(h, w13_q, w13_s, offs, tok, R)
+                y = hip_ops.grouped_gemm_down_fp8w(act, w2_q, w2_s, offs, scale, E)
         else:
             w13, w2 = self._stacked()
             # a token's k experts are distinct and the shared group holds T rows: no group exceeds T rows (T = 1 selects

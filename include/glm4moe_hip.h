@@ -230,6 +230,33 @@ int glm_gemm_bf16_router_tail(const void* x, const void* w, int64_t ldw, int K, 
                               int32_t* sorted_token, void* sorted_scale, int32_t* pair_pos, int with_shared,
                               glm_stream_t stream);
 
+/* N4 on the fp8 MFMA (r05; BASELINE configs[4] "fp8 weight-quantised experts on CDNA4 fp8 MFMA"; OPT-IN, W8A8 — the
+ *     weight-only entry points above stay the parity path).  No reference counterpart: the reference's quantised linears are
+ *     int4 AWQ dequant-then-GEMM (layers/linear_awq_new.py:254-255); the expert arithmetic replaced is mlp.py:49-54 / moe.py:149.
+ *     Both operands OCP e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4, fp32 accumulation:
+ *     glm_quantize_fp8_rows          x [T, H] bf16 -> x_q [T, H] e4m3 + one fp32 scale per row (amax / 448);
+ *     glm_grouped_gemm_gateup_silu_fp8a8   acc[r, n] = sum_k w13_q[g, n, k] x_q[tok(r), k] (block scales 2^0);
+ *         gate / up = acc * w13_scale[g, n] * x_scale[tok(r)]; act = bf16(bf16(silu(bf16 gate)) * bf16 up) as a13, then quantised
+ *         in MX form by the epilogue: per (row, 32 columns) an E8M0 scale 2^(floor(log2 amax) - 8), one step up where amax would
+ *         pass 448 (nothing saturates), and e4m3 = RNE(v / scale).
+ *         act_q [R, I] bytes (row stride ld_act); act_bscale [R, 64] bytes, block b at (b & 3) * 16 + (b >> 2) of the row's record.
+ *     glm_grouped_gemm_down_fp8a8    y[r, :] = bf16(bf16(sum_k w2_q[g, n, k] act_q[r, k] 2^(bscale[r, k / 32] - 127) * w2_scale[g, n])
+ *         * scale[r]) for groups < n_scaled_groups, unscaled otherwise — the block scales go into the MFMA itself.
+ *     Strides of the fp8 tensors in BYTES (= elements).  Grouped only, 256-row blocks: GLM_ERR_UNSUPPORTED (nothing enqueued)
+ *     when R / G < 192, H or I not multiples of 128, I > 2048 — the caller then takes the weight-only path.            */
+int glm_quantize_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int64_t T, int H,
+                          glm_stream_t stream);
+int glm_grouped_gemm_gateup_silu_fp8a8(const void* x_q, int64_t ldx, const float* x_scale, const void* w13_q,
+                                       int64_t w13_group_stride, int64_t w13_row_stride, const float* w13_scale,
+                                       int64_t w13_scale_group_stride, const int32_t* expert_offsets,
+                                       const int32_t* sorted_token, void* act_q, int64_t ld_act, void* act_bscale,
+                                       int64_t R, int H, int I, int G, glm_stream_t stream);
+int glm_grouped_gemm_down_fp8a8(const void* act_q, int64_t ld_act, const void* act_bscale, const void* w2_q,
+                                int64_t w2_group_stride, int64_t w2_row_stride, const float* w2_scale,
+                                int64_t w2_scale_group_stride, const int32_t* expert_offsets, const void* sorted_scale,
+                                int n_scaled_groups, void* y, int64_t ldy, int64_t R, int H, int I, int G,
+                                glm_stream_t stream);
+
 /* a10 + a3 + a11 + bucketing + a12/a13 for ONE token in ONE persistent launch (r05; BASELINE configs[1], greedy bs = 1):
  *     what glm_gemm_bf16_router_tail, glm_grouped_gemm_gateup_silu and glm_grouped_gemm_down do for one token row —
  *     attention_new.py o_proj, decode_layer.py:86-93, moe.py:28-50, the expert loop moe.py:135-151 with mlp.py:49-54 —

@@ -408,3 +408,68 @@ def moe_fp8w(x, top_k, idx, w, q13, s13, q2, s2, sq13, ss13, sq2, ss2):
         y = mlp_fp8w(h[rows], q13[e], s13[e], q2[e], s2[e])
         acc.index_add_(0, rows, y * w[rows, slot].unsqueeze(-1))
     return acc + mlp_fp8w(h, sq13, ss13, sq2, ss2)
+
+
+# ---------------------------------------------------------------------------------------------
+# N4 on the fp8 MFMA (r05): W8A8 — fp8 e4m3 activations next to the fp8 weights, block-scaled MFMA.  PARITY UNPINNED by
+# construction: the reference has no fp8 path at all (its quantised linears are int4 AWQ dequant-then-GEMM,
+# layers/linear_awq_new.py:254-255).  The oracle is the reference's expert arithmetic (mlp.py:49-54, moe.py:149) evaluated
+# on the DEQUANTISED weights AND the DEQUANTISED activations, with the quantisers restated here (OCP MX for the act rows);
+# tests/test_hip_kernels.py reports the distance of this leg to the bf16-activation oracle (linear_fp8w) next to it.
+def quantize_fp8_rows(x: torch.Tensor):
+    """glm_quantize_fp8_rows: per-row scale s = max(amax / 448, 2^-126) in fp32, q = e4m3fn(RNE(clamp(x / s)))."""
+    xf = x.to(torch.float32)
+    s = (xf.abs().amax(dim=-1) / FP8_MAX).clamp_min(1.17549435e-38)
+    q = (xf / s.unsqueeze(-1)).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    return q, s
+
+
+def quantize_mxfp8(v: torch.Tensor):
+    """The gate|up epilogue's MX quantiser: per (row, 32 columns) an E8M0 scale byte sb with
+    2^(sb - 127) = 2^(floor(log2 amax) - 8) (OCP MX, e4m3 emax = 8) or the next power of two where amax would pass 448
+    (nothing saturates); sb = 127 for an all-zero or subnormal block, clamped to [1, 253]; q = e4m3fn(RNE(v * 2^(127 - sb))).  Returns (q [R, I] float8, sb [R, I / 32] uint8)."""
+    R, I = v.shape
+    assert I % 32 == 0
+    vf = v.to(torch.float32).view(R, I // 32, 32)
+    amax = vf.abs().amax(dim=-1)
+    bits = amax.view(torch.int32)
+    eb = (bits >> 23) & 0xff
+    bump = ((bits & 0x7fffff) > 0x600000).to(torch.int32)   # amax / 2^(e - 8) > 448: one step up so that nothing saturates
+    sb = torch.where(eb == 0, torch.full_like(eb, 127), (eb - 8 + bump).clamp(1, 253))
+    inv = ((254 - sb) << 23).to(torch.int32).view(torch.float32)
+    q = (vf * inv.unsqueeze(-1)).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).view(R, I)
+    return q, sb.to(torch.uint8)
+
+
+def mx_scale_record(sb: torch.Tensor) -> torch.Tensor:
+    """[R, nblk] scale bytes -> the [R, 64] record of the C-ABI: block b at (b & 3) * 16 + (b >> 2)."""
+    R, nb = sb.shape
+    rec = torch.zeros(R, 64, dtype=torch.uint8)
+    b = torch.arange(nb)
+    rec[:, (b & 3) * 16 + (b >> 2)] = sb
+    return rec
+
+
+def mx_scale_unrecord(rec: torch.Tensor, nblk: int) -> torch.Tensor:
+    b = torch.arange(nblk)
+    return rec[:, (b & 3) * 16 + (b >> 2)]
+
+
+def dequant_mxfp8(q: torch.Tensor, sb: torch.Tensor) -> torch.Tensor:
+    R, I = q.shape
+    sc = torch.exp2(sb.to(torch.float32) - 127.0)
+    return (q.to(torch.float32).view(R, I // 32, 32) * sc.unsqueeze(-1)).view(R, I)
+
+
+def gateup_silu_fp8a8(xq, xs, q13, s13):
+    """act = bf16(bf16(silu(bf16 gate)) * bf16 up) (mlp.py:49-53 via activation.py:13-15) with
+    gate|up = (fp32 sum of fp8 x fp8 products) * weight-row scale * token scale, one rounding to bf16."""
+    acc = torch.matmul(xq.to(torch.float32), q13.to(torch.float32).t())
+    gu = (acc * s13.unsqueeze(0) * xs.unsqueeze(-1)).to(torch.bfloat16)
+    return silu_and_mul(gu)
+
+
+def down_fp8a8(act_q, act_sb, q2, s2):
+    """y = bf16((fp32 sum over k of w2_q * act_q * 2^(sb - 127)) * weight-row scale) — mlp.py:53 on the dequantised operands."""
+    acc = torch.matmul(dequant_mxfp8(act_q, act_sb), q2.to(torch.float32).t())
+    return (acc * s2.unsqueeze(0)).to(torch.bfloat16)

@@ -426,6 +426,117 @@ def test_c5_fp8_expert_gemms_full_size(ops, T):
     F.report(f"C5.fp8_expert_gemms_T{T}", rows=R, worst=worst)
 
 
+def test_quantize_fp8_rows(ops):
+    """glm_quantize_fp8_rows (dynamic per-row e4m3 quantisation of the activations of the fp8 x fp8 expert GEMM) against its
+    restatement in the oracle: scales bit-equal, bytes bit-equal (fp32 division, RNE, clamp at +-448)."""
+    for T, H, seed in ((5, 4096, 1), (300, 1408, 2), (64, 128, 3)):
+        x = F.randn_bf16(T, H, seed=seed, scale=3.0)
+        x[0, : H // 2] = 0
+        if T > 2:
+            x[2] = 0
+        q, s = ops.quantize_fp8_rows(x)
+        qr, sr = O.quantize_fp8_rows(x.cpu())
+        assert torch.equal(s.cpu(), sr), "row scales differ"
+        assert torch.equal(q.cpu(), qr.view(torch.uint8)), f"{int((q.cpu() != qr.view(torch.uint8)).sum())} fp8 bytes differ"
+
+
+@pytest.mark.parametrize("T", [4096, 16384])
+def test_c5_fp8a8_expert_gemms_full_size(ops, T):
+    """r05, BASELINE configs[4] ("fp8 weight-quantised experts on CDNA4 fp8 MFMA") at Air dims (H=4096, I=1408, G=65), OPT-IN
+    W8A8: e4m3 x e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4.  gate|up with a per-token activation scale (block scales 2^0)
+    and the MX quantisation of act in its epilogue; down with the act rows' E8M0 block scales inside the MFMA.
+    PARITY UNPINNED (the reference has no fp8 path: layers/linear_awq_new.py:254-255 is int4 dequant-then-GEMM); the oracle
+    leg is the reference's expert arithmetic (mlp.py:49-54, moe.py:149) on the SAME dequantised bytes, activations
+    included (oracle.gateup_silu_fp8a8 / down_fp8a8, the quantisers restated there).  Sampled rows of sampled groups:
+      * act (dequantised) vs the oracle's act BEFORE its MX quantisation: within one e4m3 step of the block (2^-3 relative
+        to the block maximum) + the bf16 rounding-order slack of the weight-only test;
+      * the act BYTES and scale bytes vs the oracle's quantiser applied to the oracle's act: equal wherever the two bf16
+        act values are equal (counted), since the quantiser itself is exact arithmetic;
+      * y vs the oracle's down projection fed with the KERNEL's act bytes: <= 1 bf16 ulp on a few elements.
+    Reported next to it: the distance of the W8A8 result to the weight-only (bf16-activation) oracle on the same rows."""
+    cfg = F.air_cfg()
+    H, E, k, I = cfg.hidden_size, cfg.n_routed_experts, cfg.num_experts_per_tok, cfg.moe_intermediate_size
+    x, idx, w, offs, tok, scale, pos = _bench_routing(ops, cfg, T, seed=431)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    w13 = torch.empty(E + 1, 2 * I, H, device="cuda", dtype=BF).normal_(0.0, 0.02, generator=g)
+    w2 = torch.empty(E + 1, H, I, device="cuda", dtype=BF).normal_(0.0, 0.02, generator=g)
+    q13, s13 = ops.quantize_fp8_rowwise(w13)
+    q2, s2 = ops.quantize_fp8_rowwise(w2)
+    del w13, w2
+    R = T * k + T
+    xq, xs = ops.quantize_fp8_rows(x)
+    r = ops.grouped_gemm_gateup_silu_fp8a8(xq, xs, q13, s13, offs, tok, R)
+    assert r is not None, "the fp8 x fp8 kernel must cover the Air prefill shape"
+    act_q, act_bs = r
+    y = ops.grouped_gemm_down_fp8a8(act_q, act_bs, q2, s2, offs, scale, E)
+    assert y is not None
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all()
+    offs_c, scale_c = offs.cpu(), scale.cpu()
+    nblk = I // 32
+    worst = {}
+    for e in (0, 31, 63, 64):
+        lo, hi = int(offs_c[e]), int(offs_c[e + 1])
+        n = hi - lo
+        if n == 0:
+            continue
+        rr = (torch.cat([torch.arange(0, min(256, n)), torch.arange(max(0, n - 150), n)]).unique() + lo)
+        rg = rr.cuda()
+        src = tok[rg].long()
+        qe13 = q13[e].cpu().contiguous().view(torch.float8_e4m3fn)
+        qe2 = q2[e].cpu().contiguous().view(torch.float8_e4m3fn)
+        xq_c, xs_c = xq[src].cpu().view(torch.float8_e4m3fn), xs[src].cpu()
+        a_ref = O.gateup_silu_fp8a8(xq_c, xs_c, qe13, s13[e].cpu())              # bf16, before the MX quantisation
+        got_q = act_q[rg].cpu().view(torch.float8_e4m3fn)
+        got_sb = O.mx_scale_unrecord(act_bs[rg].cpu(), nblk)
+        a_got = O.dequant_mxfp8(got_q, got_sb)
+        blockmax = a_ref.float().view(-1, nblk, 32).abs().amax(-1, keepdim=True).expand(-1, -1, 32).reshape(a_ref.shape)
+        err = (a_got - a_ref.float()).abs()
+        # RNE to e4m3: half a step = 2^-4 of the element's binade (normals), 2^-10 of the scaled block for subnormals (the
+        # scaled block maximum is >= 224); + three bf16 ulps for the two evaluations' fp32 summation orders
+        # ... and the absolute slack of the weight-only test (atol 2^-7: where the gate is far below zero silu is ill-conditioned
+        # in ulp terms and the two evaluations' gate values differ by an ulp)
+        lim = (2 ** -4 + 2 ** -6) * a_ref.float().abs() + 2 ** -15 * blockmax + 2 ** -7
+        bad = err > lim
+        assert not bool(bad.any()), (f"fp8a8 T={T} act group {e}: {int(bad.sum())}/{bad.numel()} outside one e4m3 step; worst err/lim "
+                                     f"{float((err / lim).max()):.3g} at ref {float(a_ref.float().flatten()[(err / lim).argmax()]):.4g}, "
+                                     f"rows {sorted(set(torch.where(bad)[0].tolist()))[:8]} cols {sorted(set(torch.where(bad)[1].tolist()))[:8]}")
+        ref_q, ref_sb = O.quantize_mxfp8(a_ref)
+        sb_equal = float((got_sb == ref_sb).float().mean())
+        q_equal = float((got_q.view(torch.uint8) == ref_q.view(torch.uint8)).float().mean())
+        # the kernel's and the CPU's fp32 summation orders differ: a bf16 act value may move by an ulp, its byte with it
+        assert sb_equal >= 0.99 and q_equal >= 0.97, (sb_equal, q_equal)
+        y_ref = O.down_fp8a8(got_q, got_sb, qe2, s2[e].cpu())
+        # the block-scaled MFMA's K = 128 dot product is not a plain fp32 fma chain (exact on small integers,
+        # profiles/r05/mfma_f8f6f4_probe_v2.txt; on real data a few results sit up to ~2^-11 of the sum of the products'
+        # magnitudes away from the fp32 sum): bound = 1 bf16 ulp + 2^-10 of sum_k |w| |act| — measured and reported
+        mag = torch.matmul(O.dequant_mxfp8(got_q, got_sb).abs(), qe2.to(torch.float32).abs().t()) * s2[e].cpu().unsqueeze(0)
+        if e < E:
+            y_ref = y_ref * scale_c[rr].unsqueeze(-1)
+            mag = mag * scale_c[rr].float().unsqueeze(-1)
+        yerr = (y[rg].cpu().float() - y_ref.float()).abs()
+        ylim = 2 ** -7 * y_ref.float().abs() + 2 ** -10 * mag + 1e-30
+        ybad = torch.nonzero(yerr > ylim)
+        ratio = yerr / mag.clamp_min(1e-30)
+        assert ybad.numel() == 0, (f"fp8a8 T={T} y group {e}: {ybad.shape[0]} outside, worst err / sum|terms| {float(ratio.max()):.3g}; "
+                                   f"quantiles of err/sum|terms| 50/99/99.99 %: {[float(ratio.flatten().float().quantile(q)) for q in (0.5, 0.99)]} "
+                                   f"{float(ratio.flatten().kthvalue(max(1, int(ratio.numel() * 0.9999))).values):.3g}; first bad (row, col, got, ref, mag): "
+                                   f"{[(int(r_), int(c_), float(y[rg].cpu()[r_, c_]), float(y_ref[r_, c_]), float(mag[r_, c_])) for r_, c_ in ybad[:6].tolist()]}")
+        # distance to the weight-only oracle (bf16 activations) on the same rows
+        a_w = O.silu_and_mul(O.linear_fp8w(x[src].cpu(), qe13, s13[e].cpu()))
+        y_w = O.linear_fp8w(a_w, qe2, s2[e].cpu())
+        if e < E:
+            y_w = y_w * scale_c[rr].unsqueeze(-1)
+        rel = lambda a, b: float((a.float() - b.float()).pow(2).mean().sqrt() / b.float().pow(2).mean().sqrt())
+        worst[f"group{e}"] = {"act_vs_fp8a8_oracle": F.err_stats(a_got.to(BF), a_ref), "y_vs_fp8a8_oracle": F.err_stats(y[rg].cpu(), y_ref),
+                              "act_bytes_equal": q_equal, "scale_bytes_equal": sb_equal,
+                              "y_worst_err_over_sum_of_term_magnitudes": float((yerr / mag.clamp_min(1e-30)).max()),
+                              "rms_rel_y_w8a8_vs_weight_only_oracle": rel(y[rg].cpu(), y_w),
+                              "rms_rel_act_w8a8_vs_weight_only_oracle": rel(a_got, a_w)}
+        assert worst[f"group{e}"]["rms_rel_y_w8a8_vs_weight_only_oracle"] < 0.06
+    F.report(f"C5.fp8a8_expert_gemms_T{T}", rows=R, parity="unpinned (no fp8 path in the reference)", worst=worst)
+
+
 def test_c3_paged_attention_full_size(ops):
     """(iv) paged decode attention at B=32, nh=96, nkv=8, ctx=4096 (the no-split instantiation bench.py times) and at
     B=1 ctx=1024 (split + reduce), stand-alone and fused-from-QKV."""

@@ -44,3 +44,9 @@ def show(tag):
               ", ".join(f"{names[i]} {buf[g*8+i]/max(nk,1):.0f}" for i in range(7)))
 act = ops.grouped_gemm_gateup_silu(x, w13, offs, tok, R); show("gate|up")
 ops.grouped_gemm_down(act, w2, offs, scale, E); show("down")
+# r05: the same for the W8A8 pair on the block-scaled fp8 MFMA
+layer.mlp.expert_weight_dtype = "fp8_e4m3"; layer.mlp.quantize_experts_fp8()
+w13_q, w13_s, w2_q, w2_s = layer.mlp._fp8
+xq, xs = ops.quantize_fp8_rows(x)
+r = ops.grouped_gemm_gateup_silu_fp8a8(xq, xs, w13_q, w13_s, offs, tok, R); show("gate|up fp8a8")
+ops.grouped_gemm_down_fp8a8(r[0], r[1], w2_q, w2_s, offs, scale, E); show("down fp8a8")

@@ -2,11 +2,12 @@
 # PMC passes over the prefill-shape grouped GEMMs (tools/prefill_gemm_only.py, T = 16384): HBM traffic, matrix-pipe
 # busy cycles, wave wait buckets, LDS activity, clock under load.  Separate rocprofv3 --pmc passes with --kernel-trace
 # only (MI355X_MICROARCH.md, rocprofv3 PMC slots).  Run on the GPU box: bash tools/pmc_prefill_gemm.sh
-# Writes gpurun_out/pmc_prefill_gemm.json (copy it to profiles/rNN/).
+# Writes gpurun_out/pmc_prefill_gemm${PG_MODE:+_$PG_MODE}.json (copy it to profiles/rNN/).  PG_MODE=a8: the W8A8 pair (r05).
 set -e
 R=$PWD
 export TMPDIR=/tmp
-OUT=$R/gpurun_out/pmc_pg
+OUT=$R/gpurun_out/pmc_pg${PG_MODE:+_$PG_MODE}
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp
 i=0
@@ -39,6 +40,8 @@ for key, d in vals.items():
     if "GRBM_GUI_ACTIVE" in m and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
         cyc = m["GRBM_GUI_ACTIVE"] / 8.0            # per-XCD active cycles (the counter sums the 8 XCDs)
         rec["mfma_pipe_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 256 * 4)
+        if "SQ_INSTS_MFMA" in m:
+            rec["mfma_busy_cycles_per_mfma_inst"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / max(m["SQ_INSTS_MFMA"], 1.0)
         if dur[key]:
             rec["clock_ghz_under_load"] = cyc / rec["duration_ns_median_profiled"]
     out[key] = rec
@@ -48,7 +51,8 @@ import bench
 out["_meta"] = {"kernel_source_digest": bench._kernel_source_digest(), "git_head": bench._git("rev-parse", "--short", "HEAD"),
                 "command": "tools/prefill_gemm_only.py under 4 rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ set | GRBM + instruction counts)",
                 "notes": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), KB x 1024; pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs)"}
-json.dump(out, open("$R/gpurun_out/pmc_prefill_gemm.json", "w"), indent=1)
+out["_meta"]["mode"] = "${PG_MODE:-bf16}"
+json.dump(out, open("$R/gpurun_out/pmc_prefill_gemm${PG_MODE:+_$PG_MODE}.json", "w"), indent=1)
 for k, v in out.items():
     if k != "_meta":
         print(k, {x: v.get(x) for x in ("hbm_bytes_corrected", "mfma_pipe_busy_frac", "clock_ghz_under_load")})
