@@ -713,7 +713,6 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                 // ONE K = 128 MFMA per (W tile, X tile): registers 0-3 = chunk g4, registers 4-7 = chunk 4 + g4 of the row
                 typedef int v8i_t __attribute__((ext_vector_type(8)));
                 typedef unsigned u32x8_t __attribute__((ext_vector_type(8)));
-                static_assert(NX == 2, "the scale registers follow the 4 x 2-tile quadrants");
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
@@ -891,6 +890,65 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             }
             close_load();
             quad(I0{}, I4{}, I6{}, I2{}, I4{});
+            __builtin_amdgcn_s_barrier();
+        }
+        } else
+#ifndef GLM_LM_A8_PHASES
+#define GLM_LM_A8_PHASES 2   // 2: the two-phase fp8 x fp8 loop below (r05); 4: the bf16 product loop's four quadrant phases
+#endif
+        if constexpr (C::A8 && GLM_LM_A8_PHASES == 2) {
+        // ---- fp8 x fp8, TWO phases per K tile (r05).  A block-scaled MFMA does the work of four bf16 ones, so a 4 x 2-tile
+        // quadrant is 8 instructions (256 pipe cycles) behind the same two barriers: PMC of the four-phase form says the
+        // matrix pipe is 42 % busy at 2.15 GHz (profiles/r05/pmc_prefill_gemm_a8_four_phase.json) — not the clock, the
+        // barriers.  Here a phase is 4 W tiles x 4 X tiles = 16 MFMAs:
+        //   phase   fragment reads (K tile kt, buffer b)        DMA issued                          MFMAs
+        //     A     W tiles 0-3 (8) + X tiles 0-3 (8) [+ scales]  X(kt+1) pieces 0-3 -> buffer !b    W0-3 x X0-3
+        //     B     X tiles 4-7 (8)                               W(kt+2) pieces 0-3 -> buffer b     W0-3 x X4-7
+        //           then the counted wait for this wave's share of K tile kt+1 (W(kt+2) stays in flight)
+        // Barrier epochs: waves 0-3 run load interval P (= 2 kt + phase) in epoch 2P, waves 4-7 in epoch 2P+1.
+        //   WAR  W(kt) is last read in load interval 2kt (retired by the end of epoch 4kt+1) and its slot refilled from load
+        //        interval 2kt+1 (epoch >= 4kt+2).  X(kt-1) is last read in load interval 2kt-1 (epoch <= 4kt-1) and its slot
+        //        refilled from load interval 2kt (epoch >= 4kt).
+        //   RAW  K tile kt+1 is first read in load interval 2kt+2 (epoch >= 4kt+4); every wave waited for its own pieces of
+        //        it at the end of load interval 2kt+1 (epoch <= 4kt+3), i.e. before barrier 4kt+4.
+        static_assert(QW && !P3X && !PARK && (VAR & LM_RFIRST) != 0, "fp8 x fp8: the product variant's switches");
+        for (int kt = 0; kt < nk; ++kt) {
+            const int b = kt & 1;
+            const unsigned so = b * C::STAGE;
+            const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
+            ksh = (kt & 3) * 8;
+            // ---- phase A
+            rd_w(so, I0{}, I4{});
+            rd_x(so, I0{}, I4{}, I0{});
+            rd_s(kt);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has1) {
+                dma2(b ^ 1, kt + 1, XP0{});
+                dma2(b ^ 1, kt + 1, XP2{});
+            }
+            reads_done();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pin(fw[i]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pin(fx[i]);
+            pin_s();
+            close_load();
+            quad(I0{}, I4{}, I0{}, I4{}, I0{});
+            __builtin_amdgcn_s_barrier();
+            // ---- phase B
+            rd_x(so, I4{}, I4{}, I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (has2) {
+                dma2(b, kt + 2, I0{});
+                dma2(b, kt + 2, I2{});
+            }
+            reads_done();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pin(fx[i]);
+            if (has2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(C::W_DMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            close_load();
+            quad(I0{}, I4{}, I4{}, I4{}, I0{});
             __builtin_amdgcn_s_barrier();
         }
         } else {

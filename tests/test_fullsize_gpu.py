@@ -507,21 +507,16 @@ def test_c5_fp8a8_expert_gemms_full_size(ops, T):
         # the kernel's and the CPU's fp32 summation orders differ: a bf16 act value may move by an ulp, its byte with it
         assert sb_equal >= 0.99 and q_equal >= 0.97, (sb_equal, q_equal)
         y_ref = O.down_fp8a8(got_q, got_sb, qe2, s2[e].cpu())
-        # the block-scaled MFMA's K = 128 dot product is not a plain fp32 fma chain (exact on small integers,
-        # profiles/r05/mfma_f8f6f4_probe_v2.txt; on real data a few results sit up to ~2^-11 of the sum of the products'
-        # magnitudes away from the fp32 sum): bound = 1 bf16 ulp + 2^-10 of sum_k |w| |act| — measured and reported
+        # the block-scaled MFMA's dot product on these bytes agrees with float64 arithmetic to bf16 rounding (tools/fp8a8_outlier.py,
+        # profiles/r05/fp8a8_outlier.txt: 97.5 % of the unscaled results equal bf16(float64), the rest are one ulp away, and the
+        # scaled rows equal bf16(unscaled * routing weight) bit for bit).  One flip of the intermediate bf16(acc * scale_row)
+        # can move bf16(that * routing weight) by TWO ulps: max 2 ulp here where the unscaled weight-only test has 1
         mag = torch.matmul(O.dequant_mxfp8(got_q, got_sb).abs(), qe2.to(torch.float32).abs().t()) * s2[e].cpu().unsqueeze(0)
         if e < E:
             y_ref = y_ref * scale_c[rr].unsqueeze(-1)
             mag = mag * scale_c[rr].float().unsqueeze(-1)
+        assert_close_bf16(y[rg].cpu(), y_ref, 2 if e < E else 1, 0.06, atol=2 ** -9, what=f"fp8a8 T={T} y group {e}")
         yerr = (y[rg].cpu().float() - y_ref.float()).abs()
-        ylim = 2 ** -7 * y_ref.float().abs() + 2 ** -10 * mag + 1e-30
-        ybad = torch.nonzero(yerr > ylim)
-        ratio = yerr / mag.clamp_min(1e-30)
-        assert ybad.numel() == 0, (f"fp8a8 T={T} y group {e}: {ybad.shape[0]} outside, worst err / sum|terms| {float(ratio.max()):.3g}; "
-                                   f"quantiles of err/sum|terms| 50/99/99.99 %: {[float(ratio.flatten().float().quantile(q)) for q in (0.5, 0.99)]} "
-                                   f"{float(ratio.flatten().kthvalue(max(1, int(ratio.numel() * 0.9999))).values):.3g}; first bad (row, col, got, ref, mag): "
-                                   f"{[(int(r_), int(c_), float(y[rg].cpu()[r_, c_]), float(y_ref[r_, c_]), float(mag[r_, c_])) for r_, c_ in ybad[:6].tolist()]}")
         # distance to the weight-only oracle (bf16 activations) on the same rows
         a_w = O.silu_and_mul(O.linear_fp8w(x[src].cpu(), qe13, s13[e].cpu()))
         y_w = O.linear_fp8w(a_w, qe2, s2[e].cpu())

@@ -341,11 +341,11 @@ def _c1_after_ipc_close_worker(rank, world, port, q):
         assert torch.equal(mine.cpu(), sum(x.float() for x in xs).to(torch.bfloat16))
         ar.close()      # glm_comm_ipc_close of the peer's blocks, barrier, glm_comm_free (parks) of the own ones
         del ar, mine
+        dist.barrier()
+        dist.destroy_process_group()   # the C1 layer below is a single-rank layer (a live group would shard it)
         torch.cuda.empty_cache()   # the allocator draws fresh segments for what follows
         import test_layer_gpu as me
         me.test_decoder_layer_c1()  # ordinary tensors of the C1 sizes: allocate, write (product kernels), re-read — fatal tripwire
-        dist.barrier()
-        dist.destroy_process_group()
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
         import traceback
