@@ -837,6 +837,36 @@ def measure_fp8(model, cfg, ops, step, B, ctx, L, args, dev):
                                   "projection takes those block scales inside the MFMA; peak = 5 PFLOP/s dense fp8"}
     except Exception as e:  # noqa: BLE001
         a8 = {"error": repr(e)[:200]}
+    # ... and the whole 16384-token prefill step through 3 MoE layers (as extra.prefill_step_16k) with fp8 experts: weight-only
+    # against W8A8 (LAST: it overwrites K/V rows)
+    try:
+        from nanovllm.utils.context import set_context
+        T, S = 16384, 4096
+        layers = [l for l in model.model.layers if hasattr(l.mlp, "gate")][:3]
+        h0 = torch.randn(T, cfg.hidden_size, device=dev).to(torch.bfloat16)
+        pos = torch.arange(S, device=dev).repeat(T // S)
+        cu = torch.arange(0, T + 1, S, dtype=torch.int32, device=dev)
+        set_context(True, cu, cu, S, S, torch.arange(T, dtype=torch.int32, device=dev), None, None)
+
+        @torch.inference_mode()
+        def pstep():
+            hs, res = h0, None
+            for l in layers:
+                hs, res = l(pos, hs, res, defer_combine=True)
+            return hs
+
+        ms = {}
+        for tag, act_dtype in (("weight_only", None), ("w8a8", "fp8_e4m3")):
+            for l in layers:
+                l.mlp.expert_activation_dtype = act_dtype
+            ms[tag] = round(_events_us(pstep, 3, 1) / 1e3 / len(layers), 4)
+        for l in layers:
+            l.mlp.expert_activation_dtype = None
+        a8["prefill_step_16k_ms_per_layer"] = ms["w8a8"]
+        a8["prefill_step_16k_ms_per_layer_weight_only"] = ms["weight_only"]
+        del h0
+    except Exception as e:  # noqa: BLE001
+        a8["prefill_step_error"] = repr(e)[:200]
     return {"workload": f"same model and decode step (bs={B} ctx={ctx} L={L}), experts as fp8 e4m3 weight-only",
             # the pair on the fp8 MFMA (W8A8, opt-in) is THE prefill figure of this entry since r05; the weight-only pair (bf16
             # MFMA, the parity path) keeps its own keys
