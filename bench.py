@@ -301,6 +301,19 @@ def main():
     extra = {}
     if world == 1 and not args.no_c2 and (B, ctx) != (1, 1024) and args.emulate_tp == 1:
         extra["c2_bs1_ctx1024"] = measure_c2(model, cfg, kv, dev, L, bs, args.fp8_experts)
+        if not args.fp8_experts and hip_ops.opt("t1_engine") == 0:
+            # r05: the same step with the one-launch MLP half (glm_decode_mlp_engine, opt-in): measured beside the default
+            # five-launch layer so that the driver line carries the comparison
+            try:
+                with hip_ops.option("t1_engine", 1):
+                    eng = measure_c2(model, cfg, kv, dev, L, bs, False)
+                hip_ops.check_decode_engine(dev)
+                extra["c2_bs1_ctx1024"]["one_launch_mlp_half"] = {
+                    "tokens_per_s": eng["tokens_per_s"], "ms_per_layer": eng["ms_per_layer"], "layer_hbm_frac": eng["layer_hbm_frac"],
+                    "launches_per_moe_layer": 3, "default_launches_per_moe_layer": 5,
+                    "note": "option t1_engine = 1: o_proj .. down projection as ONE persistent launch, bit-identical; default off"}
+            except Exception as e:  # noqa: BLE001 - a side leg never takes the headline line down
+                extra["c2_bs1_ctx1024"]["one_launch_mlp_half"] = {"error": repr(e)[:200]}
         set_context(False, slot_mapping=slot_mapping, context_lens=context_lens, block_tables=block_tables)
 
     # ---- the other numbers README.md / DESIGN.md quote, on the driver line (rank 0, TP=1, after the timed region):
@@ -353,6 +366,12 @@ def main():
             "cpu_baseline": cpu_base,
         }
         if collective is not None:
+            if getattr(cfg, "expert_parallel_size", 1) > 1:
+                from nanovllm.distributed.expert_parallel import EPExperts
+                collective["expert_parallel"] = {"capacity_factor": EPExperts.capacity_factor,
+                                                 "overflowed_slots_worst_rows": EPExperts.overflowed(reset=False),
+                                                 "note": "bench.py runs the worst-case capacity (no factor): an overflow is impossible; "
+                                                         "ModelRunner applies the factor from a mean slot load of 16 rows on and counts redone steps"}
             line["collective"] = collective
         print(json.dumps(line))
     if world > 1:

@@ -532,6 +532,58 @@ def test_c5_fp8a8_expert_gemms_full_size(ops, T):
     F.report(f"C5.fp8a8_expert_gemms_T{T}", rows=R, parity="unpinned (no fp8 path in the reference)", worst=worst)
 
 
+def test_c5_moe_block_w8a8_through_the_module(ops):
+    """The opt-in W8A8 path through the product's own module (`config.expert_weight_dtype = expert_activation_dtype =
+    "fp8_e4m3"`, models/glm4_moe/moe.py): a prefill-sized MoE block at Air dims takes the fp8 x fp8 kernels, a decode-sized
+    step keeps the weight-only ones (the launcher refuses < 192 rows per group and the module never asks below that), and
+    the prefill result stays within the activation-quantisation distance of the weight-only result on the same routing
+    (rms 2-3 %; bound 6 %).  Parity of the path itself: test_c5_fp8a8_expert_gemms_full_size."""
+    from nanovllm.models.glm4_moe.moe import Glm4MoeMoE
+    cfg = F.air_cfg(expert_weight_dtype="fp8_e4m3")
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(BF)
+    try:
+        with torch.device("cuda"):
+            blk = Glm4MoeMoE(cfg)
+    finally:
+        torch.set_default_dtype(old)
+    F.init_seeded(blk, 3)
+    blk.quantize_experts_fp8()
+    seen = []
+    orig = ops.grouped_gemm_gateup_silu_fp8a8
+
+    def spy(*a, **kw):
+        r = orig(*a, **kw)
+        seen.append(r is not None)
+        return r
+    ops.grouped_gemm_gateup_silu_fp8a8 = spy
+    try:
+        x = F.randn_bf16(4096, cfg.hidden_size, seed=77)
+        with torch.inference_mode():
+            y_w = blk(x)
+            assert seen == [], "weight-only configuration must not touch the fp8 x fp8 kernels"
+            blk.expert_activation_dtype = "fp8_e4m3"
+            y_a = blk(x)
+            assert seen == [True], "a prefill-sized step must take the fp8 x fp8 kernels"
+            y_d = blk(x[:32])
+            assert seen == [True], "a decode-sized step keeps the weight-only kernels"
+            blk.expert_activation_dtype = None
+            y_dw = blk(x[:32])
+        torch.cuda.synchronize()
+        assert torch.equal(y_d, y_dw)
+        rel = float((y_a.float() - y_w.float()).norm() / y_w.float().norm())
+        assert torch.isfinite(y_a.float()).all() and rel < 0.06, rel
+        F.report("C5.moe_block_w8a8_vs_weight_only", tokens=4096, rms_rel=rel)
+        # the launcher's own refusal (nothing enqueued): 32 tokens over 65 groups
+        xq, xs = ops.quantize_fp8_rows(x[:32])
+        idx, w = blk.gate(x[:32])
+        offs, tok, scale, pos = ops.moe_align(idx, w, cfg.n_routed_experts, True)
+        w13_q, w13_s, w2_q, w2_s = blk._fp8
+        assert orig(xq, xs, w13_q, w13_s, offs, tok, 32 * 9) is None
+    finally:
+        ops.grouped_gemm_gateup_silu_fp8a8 = orig
+
+
 def test_c3_paged_attention_full_size(ops):
     """(iv) paged decode attention at B=32, nh=96, nkv=8, ctx=4096 (the no-split instantiation bench.py times) and at
     B=1 ctx=1024 (split + reduce), stand-alone and fused-from-QKV."""
