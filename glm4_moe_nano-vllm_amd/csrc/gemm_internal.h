@@ -150,7 +150,7 @@ __device__ __forceinline__ void glm_locate_block(const int32_t* __restrict__ off
 // Every switch a launch path consults lives in ONE table, filled from the environment ONCE (first use) and changed only
 // through glm_set_option: a launch never reads the environment, so a HIP graph and the eager launches around it cannot see
 // two different settings, and the effective set can be printed (bench.py puts it into its line's `config.options`).
-enum GlmOption { GLM_OPT_TINYM = 0, GLM_OPT_FP8W_NATIVE, GLM_OPT_LARGEM_VARIANT, GLM_OPT_LARGEM_CFG, GLM_OPT_FA_MFMA32, GLM_OPT_FA_ROWS64, GLM_OPT_COUNT };
+enum GlmOption { GLM_OPT_TINYM = 0, GLM_OPT_FP8W_NATIVE, GLM_OPT_LARGEM_VARIANT, GLM_OPT_LARGEM_CFG, GLM_OPT_FA_MFMA32, GLM_OPT_FA_ROWS64, GLM_OPT_FA_PERSIST, GLM_OPT_COUNT };
 int glm_option(int id);
 // Kernels that were built, measured against the shipped ones and LOST (r03: prefill attention on 32x32x16 MFMAs; r04: prefill
 // attention with 64 query rows per wave) are compiled into the STUDY library only (`build.py --study` ->
@@ -163,3 +163,7 @@ int glm_launch_prefill_attn64(const void* q, const void* k, const void* v, const
                               const int32_t* block_tables, int64_t bt_stride, void* out, int64_t B, int max_seqlen_q, int nh, int nkv,
                               int block_size, float scale, hipStream_t st);
 
+// prefill_attn_persist.hip (r05): the contiguous-K/V prefill attention as persistent workgroups (option fa_persist); returns
+// GLM_ERR_UNSUPPORTED without enqueuing anything when a slot's block list does not fit its table
+int glm_launch_prefill_attn_persist(const void* q, const void* k, const void* v, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                                    void* out, int64_t B, int max_seqlen_q, int nh, int nkv, float scale, hipStream_t st);

@@ -91,6 +91,9 @@ __device__ unsigned long long g_fa_stamps[16];
 #define FA_T(i) do {} while (0)
 #endif
 
+#ifndef GLM_FA_STORE16
+#define GLM_FA_STORE16 1   // r05: 16-byte output stores behind a lane-row exchange (0 = the 8-byte stores of r02-r04)
+#endif
 #ifndef GLM_FA_NOSCHED
 #define GLM_FA_NOSCHED 0   // 1 (study): drop the scheduling fences of the unit loops and let hipcc interleave MFMA and VALU itself
 #endif
@@ -966,12 +969,30 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
         if (qi[qt] < lq) {
             const float inv = l > 0.f ? 1.0f / l : 0.f;
             bf16_t* orow = out + ((int64_t)(q0 + qi[qt]) * nh + head) * FA_HD;
+#if GLM_FA_STORE16
+            // r05: a lane holds hd [16 dt + 4 g, +4) of its query row; lane rows g and g ^ 1 exchange one block each
+            // (v_permlane16_swap: odd rows of the first operand <-> even rows of the second), after which an even row holds
+            // hd [16 dt + 4 g, +8) and an odd row hd [16 (dt + 1) + 4 (g - 1), +8): 4 x 16-byte stores instead of 8 x 8
+            // (the store tail of a workgroup is bound by store INSTRUCTIONS, cdna_hip_programming.md T21)
+#pragma unroll
+            for (int dt = 0; dt < 8; dt += 2) {
+                const unsigned a0 = pack2bf(acc[qt][dt][0] * inv, acc[qt][dt][1] * inv);
+                const unsigned a1 = pack2bf(acc[qt][dt][2] * inv, acc[qt][dt][3] * inv);
+                const unsigned b0 = pack2bf(acc[qt][dt + 1][0] * inv, acc[qt][dt + 1][1] * inv);
+                const unsigned b1 = pack2bf(acc[qt][dt + 1][2] * inv, acc[qt][dt + 1][3] * inv);
+                const u32x2_t x = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                const u32x2_t y = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                const int col = 16 * (dt + (g & 1)) + 4 * (g & 2);
+                *reinterpret_cast<u32x4_t*>(orow + col) = u32x4_t{x[0], y[0], x[1], y[1]};
+            }
+#else
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
                 u32x2_t o = {pack2bf(acc[qt][dt][0] * inv, acc[qt][dt][1] * inv),
                              pack2bf(acc[qt][dt][2] * inv, acc[qt][dt][3] * inv)};
                 *reinterpret_cast<u32x2_t*>(orow + 16 * dt + 4 * g) = o;
             }
+#endif
         }
     }
 }
@@ -1390,6 +1411,11 @@ extern "C" int glm_varlen_attn_prefill(const void* q, const void* k, const void*
         return GLM_ERR_UNSUPPORTED;
     }
 #endif
+    if (!paged && glm_option(GLM_OPT_FA_PERSIST) == 1) {
+        const int rc = glm_launch_prefill_attn_persist(q, k, v, cu_seqlens_q, cu_seqlens_k, out, B, max_seqlen_q, nh, nkv, scale,
+                                                       glm_s(stream));
+        if (rc != GLM_ERR_UNSUPPORTED) return rc;  // unsupported = the block list does not fit: the kernel below takes it
+    }
     if (paged)
         hipLaunchKernelGGL((prefill_attn_kernel<true>), grid, dim3(FA_NT), lds, glm_s(stream), (const bf16_t*)q,
                            (const bf16_t*)k, (const bf16_t*)v, cu_seqlens_q, cu_seqlens_k, block_tables,

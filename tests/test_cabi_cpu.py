@@ -75,7 +75,7 @@ def test_options_are_read_once_and_listed(lib_path):
     import os
     from nanovllm import hip_ops
     o = hip_ops.options()
-    assert set(o) == {"tinym", "fp8w_native", "largem_variant", "largem_cfg", "fa_mfma32", "fa_rows64", "fuse_combine_qkv",
+    assert set(o) == {"tinym", "fp8w_native", "largem_variant", "largem_cfg", "fa_mfma32", "fa_rows64", "fa_persist", "fuse_combine_qkv",
                       "fuse_oproj_router", "t1_engine", "defer_qkv_reduce", "fuse_qkv_rope", "ep_fixed", "oneshot_allreduce"}
     assert o["tinym"] == 1 and o["largem_variant"] == -1 and o["oneshot_allreduce"] == 0
     os.environ["GLM4MOE_TINYM"] = "0"
