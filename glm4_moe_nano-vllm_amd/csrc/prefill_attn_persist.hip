@@ -16,9 +16,15 @@
 // Per (query row, key) arithmetic, tile walk and rounding points are prefill_attn_kernel<false>'s: results are bit-identical
 // (tests/test_hip_kernels.py::test_varlen_attn_prefill_persist_bit_identical).
 //
-// Work order: block L of the r04 order (longest first, an XCD keeps its (sequence, kv head) groups) goes to slot
-// (L & 7, (L >> 3) mod S) in even rounds and to the mirrored slot in odd rounds (a "snake" inside each XCD), which
-// keeps the per-slot sums of a longest-first list within one block of each other without a run-time queue.
+// Work order: the r04 order (longest block first, an XCD keeps its (sequence, kv head) groups), handed out at RUN TIME: a
+// workgroup's first block is its slot's, every further one comes from a counter per XCD group (one atomic per block,
+// issued two blocks ahead by wave 0 and published through LDS behind two of the tile barriers).  A first form with static
+// per-slot lists (perfectly balanced in tiles) lost 4-9 %: the two workgroups of a CU do NOT share it evenly — the one
+// that arrived first finished 20-25 % earlier in every CU (profiles/r05/prefill_attn_persist_static_stamps.txt) and its
+// partner then ran the rest alone at one wave per SIMD.  With one-block workgroups the hardware dispatcher hides that; a
+// persistent form has to do the dispatcher's job itself.
+// Rows of a 128-row block are dealt to the waves as two 16-row tiles 64 rows apart (wave w: rows 16 w .. and 64 + 16 w ..),
+// so that the two half-dead tiles on the causal diagonal cost every wave the same (r04: waves 0, 1 idle through the last tile).
 #include "common.h"
 #include "gemm_internal.h"
 #include <type_traits>
@@ -76,7 +82,7 @@ struct FapCur {   // a stream tile to stage: source pointers of its first row; l
 __global__ __launch_bounds__(P_NT, 2) void prefill_attn_persist_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k, bf16_t* __restrict__ out, int nh, int nkv,
-    float scale_log2e, int nqblk, int nseq, int xcd_groups, int total, int nrounds) {
+    float scale_log2e, int nqblk, int nseq, int xcd_groups, int total, unsigned* __restrict__ ctr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,62 +94,87 @@ __global__ __launch_bounds__(P_NT, 2) void prefill_attn_persist_kernel(
     FAP_T(-1);
 #endif
 
-    // ---- slot → blocks: the slot's whole list is worked out ONCE, by all threads in parallel, into a table behind the K/V
-    // ring (8 ints per round); a block switch is then one LDS read instead of ~10 live scalars, four integer divisions
-    // and two dependent scalar loads (a first form that decoded in the loop spilled 66 scalar registers)
-    int* tab = reinterpret_cast<int*>(smem + 2 * P_STAGE);
+    // ---- blocks: descriptors live in a 4-entry ring in LDS (8 ints: q0, lq, k0, lk, head, kvh, qbase, valid); block n of this
+    // workgroup is entry n & 3.  Wave 0 produces them — index from the XCD group's counter, decoded with vector
+    // arithmetic only (the constants come from LDS, cu_seqlens too): nothing of this occupies a scalar register across
+    // the tile loops (a first form that decoded on the scalar unit spilled 66 of them).
+    int* tab = reinterpret_cast<int*>(smem + 2 * P_STAGE);  // [4][8]
+    int* cst = tab + 32;                                     // [16]
+    int* cuq = cst + 16;                                     // [nseq + 1]
+    int* cuk = cuq + nseq + 1;                               // [nseq + 1]
+    const int ng = xcd_groups > 0 ? 8 : 1;
     {
-        const int ng = xcd_groups > 0 ? 8 : 1;
-        const int xs = (int)blockIdx.x % ng, ss = (int)blockIdx.x / ng;
-        const int S = (int)gridDim.x / ng, nper = total / ng;
-        for (int j = tid; j < nrounds; j += P_NT) {
-            const int sp = (!GLM_FAP_NOSNAKE && (j & 1)) ? S - 1 - ss : ss;
-            const int jl = j * S + sp;
-            int e[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // q0, lq, k0, lk, head, kvh, qbase, valid
-            if (jl < nper) {
-                int qblk, head, b;
-                if (xcd_groups > 0) {
-                    const int per_q = xcd_groups * hpg;  // blocks per query-block index on one XCD
-                    const int sidx = jl / per_q, r = jl - sidx * per_q;
-                    const int group = (r / hpg) * 8 + xs;  // (sequence, kv head) pair
-                    qblk = nqblk - 1 - sidx;
-                    b = group / nkv;
-                    head = (group % nkv) * hpg + r % hpg;
-                } else {
-                    const int per_q = nh * nseq;
-                    const int sidx = jl / per_q, r = jl - sidx * per_q;
-                    qblk = nqblk - 1 - sidx;
-                    b = r / nh;
-                    head = r % nh;
-                }
-                const int q0 = cu_q[b], lq = cu_q[b + 1] - q0;
-                const int k0 = cu_k[b], lk = cu_k[b + 1] - k0;
-                e[0] = q0; e[1] = lq; e[2] = k0; e[3] = lk; e[4] = head; e[5] = head / hpg; e[6] = qblk * P_BQ;
-                e[7] = qblk * P_BQ < lq;  // 0: a block past this sequence's last query row
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) tab[j * 8 + i] = e[i];
+        for (int i = tid; i <= nseq; i += P_NT) {
+            cuq[i] = cu_q[i];
+            cuk[i] = cu_k[i];
+        }
+        if (tid == 0) {
+            cst[0] = nqblk; cst[1] = nh * nseq; cst[2] = xcd_groups; cst[3] = hpg; cst[4] = nkv; cst[5] = nh;
+            cst[6] = total / ng;                  // blocks of one XCD group
+            cst[7] = (int)gridDim.x / ng;         // slots of one XCD group = the statically assigned first blocks
+            cst[8] = (int)blockIdx.x % ng;
         }
         __syncthreads();
     }
-    // the first non-empty block at or behind table entry j (j is left there); valid = 0 when there is none
-    auto next_item = [&](int& j) -> FapItem {
-        FapItem it;
-        it.valid = 0;
-        it.q0 = it.lq = it.k0 = it.lk = it.head = it.kvh = it.qbase = 0;
-        for (; j < nrounds; ++j) {
-            const int w = tab[j * 8 + (lane & 7)];
-            if (__builtin_amdgcn_readlane(w, 7) == 0) continue;
-            it.valid = 1;
-            it.q0 = __builtin_amdgcn_readlane(w, 0);
-            it.lq = __builtin_amdgcn_readlane(w, 1);
-            it.k0 = __builtin_amdgcn_readlane(w, 2);
-            it.lk = __builtin_amdgcn_readlane(w, 3);
-            it.head = __builtin_amdgcn_readlane(w, 4);
-            it.kvh = __builtin_amdgcn_readlane(w, 5);
-            it.qbase = __builtin_amdgcn_readlane(w, 6);
-            break;
+    unsigned* myctr = ctr + (int)blockIdx.x % ng;
+    // list position jl (a per-lane value as far as the compiler knows: vector arithmetic) → ring entry `slot`
+    auto decode_to = [&](int jl, int slot) {
+        const int c_nqblk = cst[0], c_perq1 = cst[1], c_xg = cst[2], c_hpg = cst[3], c_nkv = cst[4], c_nh = cst[5], c_nper = cst[6],
+                  c_xs = cst[8];
+        int e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (jl < c_nper) {
+            int qblk, head, b;
+            if (c_xg > 0) {
+                const int per_q = c_xg * c_hpg;  // blocks per query-block index on one XCD
+                const int sidx = jl / per_q, r = jl - sidx * per_q;
+                const int group = (r / c_hpg) * 8 + c_xs;  // (sequence, kv head) pair
+                qblk = c_nqblk - 1 - sidx;
+                b = group / c_nkv;
+                head = (group % c_nkv) * c_hpg + r % c_hpg;
+            } else {
+                const int sidx = jl / c_perq1, r = jl - sidx * c_perq1;
+                qblk = c_nqblk - 1 - sidx;
+                b = r / c_nh;
+                head = r % c_nh;
+            }
+            const int q0 = cuq[b], lq = cuq[b + 1] - q0;
+            const int k0 = cuk[b], lk = cuk[b + 1] - k0;
+            e[0] = q0; e[1] = lq; e[2] = k0; e[3] = lk; e[4] = head; e[5] = head / c_hpg; e[6] = qblk * P_BQ;
+            e[7] = qblk * P_BQ < lq ? 1 : 2;  // 2: a block past this sequence's last query row (skipped)
         }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tab[slot * 8 + i] = e[i];
+        }
+    };
+    // draw list positions until one holds a block with rows (or the list ends) and publish it as entry `slot`; wave 0 only.
+    // `first` = a position already drawn (the caller's atomic, in flight across a tile)
+    auto fetch_to = [&](unsigned first, int slot) {
+        unsigned f = first;
+        for (;;) {
+            const int jl = cst[7] + (int)f;
+            decode_to(jl, slot);
+            const int st = __builtin_amdgcn_readfirstlane(tab[slot * 8 + 7]);
+            if (st != 2) break;  // a block with rows, or the end of the list (0)
+            f = __hip_atomic_fetch_add(myctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ragged batches only
+        }
+    };
+    auto draw = [&]() -> unsigned {  // lane 0's value counts; one atomic per wave
+        unsigned f = 0;
+        if (lane == 0) f = __hip_atomic_fetch_add(myctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __shfl(f, 0, 64);
+    };
+    auto read_entry = [&](int slot) -> FapItem {
+        FapItem it;
+        const int w = tab[slot * 8 + (lane & 7)];
+        it.q0 = __builtin_amdgcn_readlane(w, 0);
+        it.lq = __builtin_amdgcn_readlane(w, 1);
+        it.k0 = __builtin_amdgcn_readlane(w, 2);
+        it.lk = __builtin_amdgcn_readlane(w, 3);
+        it.head = __builtin_amdgcn_readlane(w, 4);
+        it.kvh = __builtin_amdgcn_readlane(w, 5);
+        it.qbase = __builtin_amdgcn_readlane(w, 6);
+        it.valid = __builtin_amdgcn_readlane(w, 7) == 1;
         return it;
     };
     auto item_ntiles = [&](const FapItem& it) -> int {
@@ -151,12 +182,31 @@ __global__ __launch_bounds__(P_NT, 2) void prefill_attn_persist_kernel(
         const int kend = min(it.lk, min(it.lq, it.qbase + P_BQ) + off);
         return kend > 0 ? (kend + P_BK - 1) / P_BK : 0;
     };
-
-    int jr = 0;
-    FapItem it = next_item(jr);
-    if (!it.valid) return;  // uniform: this slot has nothing to do
-    int jn = jr + 1;
-    FapItem nx = next_item(jn);
+    // this workgroup's first block: its slot's list position, or — a block without rows — the first drawn one that has rows
+    if (wid == 0) {
+        decode_to((int)blockIdx.x / ng + (lane & 0), 0);
+        if (__builtin_amdgcn_readfirstlane(tab[7]) == 2) fetch_to(draw(), 0);
+        fetch_to(draw(), 1);
+    }
+    __syncthreads();
+    // the last workgroup to leave puts the counters back to zero for the next launch on this counter set
+    auto leave = [&]() {
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(ctr + 8, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == gridDim.x - 1) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) __hip_atomic_store(ctr + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    int nblk = 0;  // index of the block being computed (ring entry nblk & 3)
+    FapItem it = read_entry(0);
+    FapItem nx = read_entry(1);
+    unsigned pend = 0;  // wave 0: the list position drawn for block nblk + 2
+    if (!it.valid) {  // uniform: the list was exhausted before this workgroup got a block
+        leave();
+        return;
+    }
 
     // ---- per-lane constants -----------------------------------------------------------------------------------------
     const int64_t row_bytes = (int64_t)nkv * P_ROWB;
@@ -222,11 +272,11 @@ __global__ __launch_bounds__(P_NT, 2) void prefill_attn_persist_kernel(
     u32x2_t vf[8][2];
     f32x4_t sa[2], sb[2];
 
-    // Q^T fragments of block `b`: lane (c, g), tile qt = query row qbase + 32 wid + 16 qt + c, k-step ks → hd [32 ks + 8 g, +8)
+    // Q^T fragments of block `b`: lane (c, g), tile qt = query row qbase + 16 wid + 64 qt + c, k-step ks → hd [32 ks + 8 g, +8)
     auto load_q = [&](const FapItem& b) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            const int row = b.qbase + 32 * wid + 16 * qt + c;
+            const int row = b.qbase + 16 * wid + 64 * qt + c;
             const bool ok = row < b.lq;
             const bf16_t* qrow = q + ((int64_t)(b.q0 + (ok ? row : 0)) * nh + b.head) * P_HD;
 #pragma unroll
@@ -269,7 +319,7 @@ __global__ __launch_bounds__(P_NT, 2) void prefill_attn_persist_kernel(
     // (lazy maximum: the reference point only has to keep exp2 in range; exact row maximum on the slow path)
     auto softmax = [&](f32x4_t (&s)[2], int kbase, int qt, auto tkc) -> bf16x8_t {
         constexpr int TK = (int)decltype(tkc)::value;  // 0 general tile, 2 strict interior tile (unmasked, not the block's first)
-        const int row_first = qbase + 32 * wid + 16 * qt;
+        const int row_first = qbase + 16 * wid + 64 * qt;
         const bool need_mask = TK >= 1 ? false : (kbase + 31 > row_first + off || kbase + 31 >= lk);
         if (need_mask) {
 #pragma unroll
@@ -346,7 +396,7 @@ __global__ __launch_bounds__(P_NT, 2) void prefill_attn_persist_kernel(
     };
     // a unit whose 32 keys are all past the block's last visible key or past the causal diagonal of its 16 query rows is
     // skipped (wave-uniform).  kbase < kend also covers the padding tiles of a block with fewer than two real tiles.
-    auto live = [&](int kbase, int qt) -> bool { return kbase < kend && kbase <= qbase + 32 * wid + 16 * qt + 15 + off; };
+    auto live = [&](int kbase, int qt) -> bool { return kbase < kend && kbase <= qbase + 16 * wid + 64 * qt + 15 + off; };
 
     // stream tile `ts` counted from the current block's first tile: ts < nst → this block, else the next one
     auto cursor = [&](int ts) -> FapCur {
@@ -471,7 +521,7 @@ __global__ __launch_bounds__(P_NT, 2) void prefill_attn_persist_kernel(
             acc_l[qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             m_run[qt] = -INFINITY;
             m_thr[qt] = -INFINITY;
-            qi[qt] = qbase + 32 * wid + 16 * qt + c;
+            qi[qt] = qbase + 16 * wid + 64 * qt + c;
             jmax[qt] = qi[qt] + off;
         }
         asm volatile("" : "+v"(qf[0][0]), "+v"(qf[0][1]), "+v"(qf[0][2]), "+v"(qf[0][3]), "+v"(qf[1][0]), "+v"(qf[1][1]),
@@ -485,18 +535,26 @@ __global__ __launch_bounds__(P_NT, 2) void prefill_attn_persist_kernel(
         if (live(0, 0)) s_mfma(sa, 0);
         FAP_FENCE();
 
+        // wave 0 draws the list position of the block after next now; it is decoded behind at least one tile (the draw has then
+        // returned: every tile waits for vmcnt(0) in front of its barrier) and read by all waves at the end of this block,
+        // behind at least one more barrier
+        if (wid == 0 && nx.valid) pend = draw();
+
         // interior tiles of THIS wave: every key of the tile is visible to every one of the wave's 32 rows and inside the sequence
-        const int r0w = qbase + 32 * wid;
+        const int r0w = qbase + 16 * wid;  // the wave's first row (its second tile starts 64 rows further)
         int n_int = min((r0w + off + 1) >> 6, lk >> 6);
         n_int = max(0, min(n_int, ntiles));
-        const int n1 = min(n_int, ntiles - 3);  // strict interior range [1, n1): tiles t + 1, t + 2 exist, are full, same block
+        // predicate-free range [first block: 1, else 0 .. n1): tiles t + 1 and t + 2 belong to this block and are full tiles.  (A
+        // block's first tile needs no special case: its rows have no reference point yet, so the lazy-maximum vote fails by
+        // itself and the first unit takes the exact path.)
+        const int n1 = min(n_int, ntiles - 2 - (ntiles * P_BK > lk ? 1 : 0));
         int t = 0;
         auto general = [&](int tt) {
             const FapCur A = cursor(tt + 1), B = cursor(tt + 2);
             const bool last = tt + 1 >= nst;
             tile(K0{}, tt, (par + tt) & 1, A, B, !last || nx.valid, first_item && tt == 0, last && nx.valid);
         };
-        general(t++);
+        if (first_item) general(t++);
         FAP_T(4);
         if (t < n1) {
             FapCur A = cursor(t + 1), B = cursor(t + 2);
@@ -511,6 +569,8 @@ __global__ __launch_bounds__(P_NT, 2) void prefill_attn_persist_kernel(
             }
         }
         FAP_T(5);
+        if (t == 0) general(t++);  // a short block: still one tile between the draw and its use
+        if (wid == 0 && nx.valid) fetch_to(pend, (nblk + 2) & 3);  // at least one tile (one barrier) follows: t <= nst - 1
         for (; t < nst; ++t) general(t);
         FAP_T(4);
 
@@ -537,9 +597,8 @@ __global__ __launch_bounds__(P_NT, 2) void prefill_attn_persist_kernel(
         if (!nx.valid) break;
         par = (par + nst) & 1;
         it = nx;
-        jr = jn;
-        jn = jr + 1;
-        nx = next_item(jn);
+        nx = read_entry((nblk + 2) & 3);
+        ++nblk;
         derive();
         first_item = false;
         FAP_T(6);
@@ -557,45 +616,62 @@ __global__ __launch_bounds__(P_NT, 2) void prefill_attn_persist_kernel(
         for (int i = 2; i < 8; ++i) g_fap_stamps[blockIdx.x][i] = tacc[i];
     }
 #endif
+    leave();
 #undef FAP_READ_K
 #undef FAP_READ_V
 #undef FAP_K_REGS
 #undef FAP_V_REGS
 }
 
+// counters of the run-time block lists: [set][0..7] next list position per XCD group, [8] workgroups that have left.  A
+// launch takes the next set (round-robin), so launches on different streams do not share one; the last workgroup of a
+// launch zeroes its set.  (Two launches 64 apart in issue order that are STILL both in flight would share a set — not a
+// situation a prefill step can produce.)
+constexpr int P_CTR_SETS = 64;
+__device__ unsigned g_fap_ctr[P_CTR_SETS][16];
+
 }  // namespace
 
 // arguments validated by glm_varlen_attn_prefill (prefill_attn.hip); contiguous K/V only.  GLM_ERR_UNSUPPORTED (nothing
-// enqueued, no error text) when a slot's block list would not fit its table: the caller then takes the one-block-per-workgroup
-// kernel.
-constexpr int P_MAX_ROUNDS = 480;  // 15 KiB of table behind the 64-KiB ring: two workgroups per CU stay resident
+// enqueued, no error text) for more sequences than the LDS copy of cu_seqlens holds: the caller then takes the
+// one-block-per-workgroup kernel.
+constexpr int P_MAX_SEQS = 1024;
 int glm_launch_prefill_attn_persist(const void* q, const void* k, const void* v, const int32_t* cu_seqlens_q,
                                     const int32_t* cu_seqlens_k, void* out, int64_t B, int max_seqlen_q, int nh, int nkv,
                                     float scale, hipStream_t st) {
     static int n_cu[GLM_MAX_DEVICES] = {};
+    static unsigned* ctr_base[GLM_MAX_DEVICES] = {};
+    static unsigned launch_seq = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GLM_MAX_DEVICES) dev = 0;
     if (n_cu[dev] == 0) {
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        void* sym = nullptr;
+        if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_fap_ctr)) != hipSuccess || sym == nullptr) {
+            glm_set_error("glm_varlen_attn_prefill(persistent): no address for the block counters");
+            return GLM_ERR_LAUNCH;
+        }
+        ctr_base[dev] = (unsigned*)sym;
         n_cu[dev] = n;
     }
+    if (B > P_MAX_SEQS) return GLM_ERR_UNSUPPORTED;
     const int nqblk = (max_seqlen_q + P_BQ - 1) / P_BQ;
     const int64_t total = (int64_t)nqblk * nh * B;
     if (total >= (int64_t)1 << 31) return GLM_ERR_UNSUPPORTED;
     const int xcd_groups = (B * nkv) % 8 == 0 ? (int)(B * nkv / 8) : 0;
     const int ng = xcd_groups > 0 ? 8 : 1;
-    int64_t slots = 2 * (int64_t)n_cu[dev];  // two workgroups (64 KiB of LDS + the table, 256 registers) per CU
+    int64_t slots = 2 * (int64_t)n_cu[dev];  // two workgroups (64 KiB of LDS + descriptors, 256 registers) per CU
     slots = slots / ng * ng;
     const int64_t G = total < slots ? total : slots;  // total is a multiple of 8 whenever xcd_groups > 0
-    const int64_t S = G / ng, nper = total / ng;
-    const int64_t nrounds = (nper + S - 1) / S;
-    if (nrounds > P_MAX_ROUNDS) return GLM_ERR_UNSUPPORTED;
-    GLM_SET_MAX_LDS(prefill_attn_persist_kernel, 2 * P_STAGE + P_MAX_ROUNDS * 32, "glm_varlen_attn_prefill(persistent)");
+    const size_t lds = 2 * P_STAGE + (32 + 16 + 2 * ((size_t)B + 1)) * sizeof(int);
+    GLM_SET_MAX_LDS(prefill_attn_persist_kernel, 2 * P_STAGE + (32 + 16 + 2 * (P_MAX_SEQS + 1)) * sizeof(int),
+                    "glm_varlen_attn_prefill(persistent)");
+    unsigned* ctr = ctr_base[dev] + 16 * (__atomic_fetch_add(&launch_seq, 1u, __ATOMIC_RELAXED) % P_CTR_SETS);
     const float sl2 = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(prefill_attn_persist_kernel, dim3((unsigned)G), dim3(P_NT), 2 * P_STAGE + (size_t)nrounds * 32, st,
-                       (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, cu_seqlens_q, cu_seqlens_k, (bf16_t*)out, nh,
-                       nkv, sl2, nqblk, (int)B, xcd_groups, (int)total, (int)nrounds);
+    hipLaunchKernelGGL(prefill_attn_persist_kernel, dim3((unsigned)G), dim3(P_NT), lds, st, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, cu_seqlens_q, cu_seqlens_k, (bf16_t*)out, nh, nkv, sl2, nqblk, (int)B, xcd_groups,
+                       (int)total, ctr);
     GLM_CHECK_LAUNCH("glm_varlen_attn_prefill(persistent)");
     return GLM_OK;
 }
