@@ -19,10 +19,10 @@ OBJ = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libglm4moe_hip.so")
 ARCH = "gfx950"
-SOURCES = ["api", "elementwise", "moe_misc", "paged_attn", "prefill_attn", "prefill_attn_persist", "gemm_smallm", "gemm_tinym", "gemm_largem",
+SOURCES = ["api", "elementwise", "moe_misc", "paged_attn", "prefill_attn", "gemm_smallm", "gemm_tinym", "gemm_largem",
            "decode_engine", "oneshot_allreduce"]
 # kernels that were measured against the shipped ones and lost: only in the study library (`--study`), with their tests
-STUDY_SOURCES = ["prefill_attn64"]
+STUDY_SOURCES = ["prefill_attn64", "prefill_attn_persist"]
 STUDY_TAG = "_study"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}",
          "-Wno-unused-result"]

@@ -30,7 +30,7 @@ const OptDesc k_opts[GLM_OPT_COUNT] = {
     {"largem_cfg", "GLM_LARGEM_CFG", 0},           // 0 = by shape, 1 = 128-row blocks (A), 2 = 256-row blocks (B)
     {"fa_mfma32", "GLM_FA_MFMA32", -1},            // -1 = the build's default, 0 = 16x16x32 kernel, 1 = 32x32x16 kernel
     {"fa_rows64", "GLM_FA_ROWS64", 0},             // 1 = prefill attention with 64 query rows per wave (prefill_attn64.hip)
-    {"fa_persist", "GLM_FA_PERSIST", 0},           // 1 = contiguous-K/V prefill attention as persistent workgroups (prefill_attn_persist.hip)
+    {"fa_persist", "GLM_FA_PERSIST", 0},           // 1 = prefill attention as persistent workgroups (prefill_attn_persist.hip; study library)
 };
 int g_opt[GLM_OPT_COUNT];
 bool g_opt_init = false;

@@ -84,6 +84,17 @@
 #define GLM_FA_DEFAULT_MFMA32 0  // kernel when GLM_FA_MFMA32 is unset: 0 = 16x16x32 (r02), 1 = 32x32x16
 #endif
 constexpr int FA_DEFAULT_MFMA32 = GLM_FA_DEFAULT_MFMA32;
+// GLM_FA_WGSTAMP=1 (timing study only): every workgroup's wave 0 records s_memrealtime (100 MHz) at entry, behind the start-up
+// barrier, behind the tile loop and behind the output stores
+#ifndef GLM_FA_WGSTAMP
+#define GLM_FA_WGSTAMP 0
+#endif
+#if GLM_FA_WGSTAMP
+__device__ unsigned long long g_fa_wgstamps[16384][4];
+#define FA_WG(i) do { if (tid == 0 && blockIdx.x < 16384) g_fa_wgstamps[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FA_WG(i) do {} while (0)
+#endif
 #if GLM_FA_STAMP
 __device__ unsigned long long g_fa_stamps[16];
 #define FA_T(i) do { unsigned long long t_ = __builtin_readcyclecounter(); if (i) tacc[(i) - 1] += t_ - tprev; tprev = t_; } while (0)
@@ -91,6 +102,15 @@ __device__ unsigned long long g_fa_stamps[16];
 #define FA_T(i) do {} while (0)
 #endif
 
+// r05 (r04 loop only): 1 = (a) a wave's two 16-row query tiles lie 64 rows apart (rows 16 w .. and 64 + 16 w ..) instead of
+// back to back, so that the two half-dead tiles on the causal diagonal cost every wave the same (before: waves 0, 1 sat out
+// the last tile); (b) the predicate-free loop starts at the block's FIRST tile (its rows have no reference point yet, so
+// the lazy-maximum vote fails by itself and the first unit takes the exact path; the start-up stages pieces 0, 1 of tile 1
+// only and tile 0 stages pieces 2, 3 like any other tile) and runs up to the diagonal whenever the sequence's last tile is
+// a full one: two general tiles per block instead of four.  Same arithmetic per (row, key): bit-identical to 0.
+#ifndef GLM_FA_R05
+#define GLM_FA_R05 (GLM_FA_LOOP == 1 && !GLM_FA_STAMP && !GLM_FA_GENERIC && GLM_FA_NW == 4 && !GLM_FA_EDGE)
+#endif
 #ifndef GLM_FA_STORE16
 #define GLM_FA_STORE16 1   // r05: 16-byte output stores behind a lane-row exchange (0 = the 8-byte stores of r02-r04)
 #endif
@@ -114,6 +134,14 @@ constexpr int FA_PPW = 16 / FA_NW;         // 1 KiB staging pieces per wave, for
 constexpr int FA_TILE = FA_BK * FA_ROWB;   // 16 KiB per K or V tile
 constexpr int FA_STAGE = 2 * FA_TILE;
 constexpr int FA_MAX_BT = 4096;
+// first row (inside the workgroup's 128-row block) of query tile qt of wave w
+__device__ __forceinline__ constexpr int fa_row0(int w, int qt) {
+#if GLM_FA_R05
+    return 16 * w + 64 * qt;
+#else
+    return (16 * FA_QT) * w + 16 * qt;
+#endif
+}
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
@@ -177,6 +205,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
         }
     }
     const int tid = threadIdx.x, lane = tid & 63;
+    FA_WG(0);
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
     const int q0 = cu_q[b], lq = cu_q[b + 1] - q0;
@@ -199,7 +228,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
     bf16x8_t qf[FA_QT][4];
 #pragma unroll
     for (int qt = 0; qt < FA_QT; ++qt) {
-        qi[qt] = qbase + (16 * FA_QT) * wid + 16 * qt + c;
+        qi[qt] = qbase + fa_row0(wid, qt) + c;
         const bool ok = qi[qt] < lq;
         const bf16_t* qrow = q + ((int64_t)(q0 + (ok ? qi[qt] : 0)) * nh + head) * FA_HD;
 #pragma unroll
@@ -375,7 +404,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
     auto softmax = [&](f32x4_t (&s)[2], int kbase, int qt, auto interior_c) -> bf16x8_t {
         // masking is only needed on slabs that touch the causal diagonal or the sequence end for this
         // query tile: the test is wave-uniform and false for almost every slab (and known false on an interior tile)
-        const int row_first = qbase + (16 * FA_QT) * wid + 16 * qt;
+        const int row_first = qbase + fa_row0(wid, qt);
         // interior_c: 0 general tile, 1 unmasked tile (every key visible to every row of the wave), 2 strict interior tile
         // (unmasked and not the wave's first tile)
         constexpr int TK = (int)decltype(interior_c)::value;
@@ -702,13 +731,21 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
         f32x4_t sa[2], sb[2];  // S of the unit being softmaxed / of the next unit
         stage(0, 0);
         if (ntiles > 1) {
+#if GLM_FA_R05
+            // pieces 0, 1 of tile 1; tile 0 issues pieces 2, 3 in its first two units like every later tile
+            stage_slot(1, 1, 0);
+            stage_slot(1, 1, 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#else
             stage(1, 1);
             if (FA_PPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#endif
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
+        FA_WG(1);
         FA_READ_K(0);
         asm volatile("s_waitcnt lgkmcnt(0)" : FA_K_REGS : : "memory");
         s_mfma(sa, 0);
@@ -716,13 +753,13 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
         // is skipped; wave-uniform.  Only the last tiles of a workgroup have such units.
         auto live = [&](int kbase, int qt) -> bool {
             if (GLM_FA_ABLATE & 64) return true;
-            return kbase <= qbase + (16 * FA_QT) * wid + 16 * qt + 15 + off && kbase < lk;
+            return kbase <= qbase + fa_row0(wid, qt) + 15 + off && kbase < lk;
         };
 #if GLM_FA_LOOP == 1 && !GLM_FA_STAMP
         // ---- r04 loop ----
         // interior tiles of THIS wave: every key of the tile is visible to every one of the wave's 32 rows and inside the
         // sequence (t*64 + 63 <= first row + off, t*64 + 63 < lk).  They come first; the diagonal / last tiles follow.
-        const int r0w = qbase + (16 * FA_QT) * wid;
+        const int r0w = qbase + fa_row0(wid, 0);  // the wave's first row
         int n_int = min((r0w + off + 1) >> 6, lk >> 6);
         n_int = max(0, min(n_int, ntiles));
         // running staging sources (contiguous K/V): byte offset of the tile that slots 2,3 of the current tile stage (t + 1);
@@ -767,7 +804,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
             const int kb0 = t * FA_BK;
             const bool more = INT ? true : t + 1 < ntiles;
             const bool more2 = INT ? true : t + 2 < ntiles;
-            const bool first = INT ? false : t < 1;
+            const bool first = (INT || GLM_FA_R05) ? false : t < 1;
             auto lv = [&](int kbase, int qt) -> bool { return TK >= 1 ? true : live(kbase, qt); };
             bf16x8_t pf;
             // ---- unit (slab 0, q0)
@@ -854,12 +891,18 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
             using K0 = std::integral_constant<int, 0>;
             using K1 = std::integral_constant<int, 1>;
             using K2 = std::integral_constant<int, 2>;
+#if GLM_FA_R05
+            // predicate-free range [0, n1): tiles t + 1 and t + 2 exist and are full tiles (the sequence's last tile may be partial)
+            const int n1 = min(n_int, ntiles - 2 - (ntiles * FA_BK > lk ? 1 : 0));
+            int t = 0;
+#else
             const int n1 = min(n_int, ntiles - 3);
             int t = 0;
             if (ntiles > 0) {
                 if (GLM_FA_EDGE == 2 && n_int >= 1) tile(K1{}, t++);  // (a third copy of the body in front of the loop: spills)
                 else tile(K0{}, t++);
             }
+#endif
             for (; t < n1; ++t) tile(K2{}, t);
             if (GLM_FA_EDGE)
                 for (; t < n_int; ++t) tile(K1{}, t);
@@ -962,6 +1005,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
 #undef FA_READ_V
 #undef FA_K_REGS
 #undef FA_V_REGS
+    FA_WG(2);
 
 #pragma unroll
     for (int qt = 0; qt < FA_QT; ++qt) {
@@ -995,6 +1039,10 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
 #endif
         }
     }
+#if GLM_FA_WGSTAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FA_WG(3);
+#endif
 }
 
 
@@ -1404,18 +1452,20 @@ extern "C" int glm_varlen_attn_prefill(const void* q, const void* k, const void*
         GLM_CHECK_LAUNCH("glm_varlen_attn_prefill");
         return GLM_OK;
     }
+    // option fa_persist = 1 (r05): persistent workgroups with a run-time block queue (prefill_attn_persist.hip; contiguous K/V).
+    // Bit-identical; measured at parity (4 x 4096) to -12 % (64 x 256) against the kernel below: DESIGN.md 4.3
+    if (!paged && glm_option(GLM_OPT_FA_PERSIST) == 1) {
+        const int rc = glm_launch_prefill_attn_persist(q, k, v, cu_seqlens_q, cu_seqlens_k, out, B, max_seqlen_q, nh, nkv, scale,
+                                                       glm_s(stream));
+        if (rc != GLM_ERR_UNSUPPORTED) return rc;  // unsupported = too many sequences for its LDS tables: the kernel below takes it
+    }
 #else
-    if (glm_option(GLM_OPT_FA_ROWS64) == 1 || glm_option(GLM_OPT_FA_MFMA32) == 1) {
-        glm_set_error("glm_varlen_attn_prefill: options fa_rows64 / fa_mfma32 select study kernels (measured slower, DESIGN.md 4.3); "
+    if (glm_option(GLM_OPT_FA_ROWS64) == 1 || glm_option(GLM_OPT_FA_MFMA32) == 1 || glm_option(GLM_OPT_FA_PERSIST) == 1) {
+        glm_set_error("glm_varlen_attn_prefill: options fa_rows64 / fa_mfma32 / fa_persist select study kernels (measured slower or no faster, DESIGN.md 4.3); "
                       "this is the product library — build and load lib/libglm4moe_hip_study.so (build.py --study)");
         return GLM_ERR_UNSUPPORTED;
     }
 #endif
-    if (!paged && glm_option(GLM_OPT_FA_PERSIST) == 1) {
-        const int rc = glm_launch_prefill_attn_persist(q, k, v, cu_seqlens_q, cu_seqlens_k, out, B, max_seqlen_q, nh, nkv, scale,
-                                                       glm_s(stream));
-        if (rc != GLM_ERR_UNSUPPORTED) return rc;  // unsupported = the block list does not fit: the kernel below takes it
-    }
     if (paged)
         hipLaunchKernelGGL((prefill_attn_kernel<true>), grid, dim3(FA_NT), lds, glm_s(stream), (const bf16_t*)q,
                            (const bf16_t*)k, (const bf16_t*)v, cu_seqlens_q, cu_seqlens_k, block_tables,
@@ -1439,6 +1489,11 @@ extern "C" int glm_debug_prefill_attn_occupancy(int lds_bytes) {
     return e == hipSuccess ? nb : -(int)e;
 }
 
+#if GLM_FA_WGSTAMP
+extern "C" int glm_debug_prefill_attn_wgstamps(unsigned long long* out /* [16384][4] */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fa_wgstamps), sizeof(unsigned long long) * 16384 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
 #if GLM_FA_STAMP
 // timing study only: per-segment cycle sums of wave 0 of workgroup 0 (the longest one), [16]
 extern "C" int glm_debug_prefill_attn_stamps(unsigned long long* out16) {

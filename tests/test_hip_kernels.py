@@ -1066,49 +1066,15 @@ def test_varlen_attn_prefill(ops, lens_q, lens_k, nh, nkv, paged):
     assert_mixed(out, ref, 1.6e-2, 4e-3, f"prefill attn q={lens_q} k={lens_k}")
 
 
-@pytest.mark.parametrize("lens_q,lens_k,nh,nkv", [
-    ([21, 16], [21, 16], 4, 2), ([64], [64], 2, 1), ([65, 1, 200], [65, 1, 200], 12, 2),
-    ([300, 17, 513, 64], [300, 17, 513, 64], 16, 4),            # XCD-grouped order, several blocks per sequence
-    ([5, 40], [300, 296], 4, 2), ([130], [513], 8, 8),          # fewer queries than keys (contiguous prefix)
-    ([200, 70], [40, 70], 4, 2),                                # more queries than keys: rows that see nothing
-    ([1024] * 5, [1024] * 5, 16, 2),                            # 640 blocks on 512 slots: two rounds, plain order
-    ([2048, 100, 1, 700] * 2, [2048, 100, 1, 700] * 2, 8, 4),   # 1024 blocks, XCD order, ragged: empty blocks skipped
-    ([4096, 3000], [4096, 3000], 32, 8)])                       # four rounds per slot (bit-identity only)
-def test_varlen_attn_prefill_persist_bit_identical(ops, opt_guard, lens_q, lens_k, nh, nkv):
-    """r05: the persistent-workgroup form of the contiguous-K/V prefill attention (option fa_persist,
-    csrc/prefill_attn_persist.hip) — blocks walked by resident workgroups, K/V tiles of consecutive blocks as one stream
-    through the LDS ring — does the same arithmetic per (query row, key) as the one-block-per-workgroup kernel: outputs
-    are bit-identical; the smaller cases are checked against the oracle as well (attention.py:97-100)."""
-    g = torch.Generator().manual_seed(sum(lens_k) + nh)
-    hd = 128
-    q = torch.randn(sum(lens_q), nh, hd, generator=g).to(BF)
-    k = torch.randn(sum(lens_k), nkv, hd, generator=g).to(BF)
-    v = torch.randn(sum(lens_k), nkv, hd, generator=g).to(BF)
-    cu_q = torch.tensor([0] + list(torch.tensor(lens_q).cumsum(0)), dtype=torch.int32)
-    cu_k = torch.tensor([0] + list(torch.tensor(lens_k).cumsum(0)), dtype=torch.int32)
-    scale = hd ** -0.5
-    args = (dev(q), dev(k), dev(v), dev(cu_q), dev(cu_k), max(lens_q), scale)
-    opt_guard("fa_persist", 0)
-    base = ops.varlen_attn_prefill(*args)
-    opt_guard("fa_persist", 1)
-    outs = [ops.varlen_attn_prefill(*args) for _ in range(2)]
-    torch.cuda.synchronize()
-    for o in outs:
-        assert torch.isfinite(o.float()).all()
-        assert torch.equal(o, base), f"persistent prefill attention differs from the default kernel: q={lens_q} k={lens_k}"
-    if sum(a * b for a, b in zip(lens_q, lens_k)) * nh <= 2.5e8:
-        ref = O.attn_prefill_varlen(q, k, v, cu_q, cu_k, scale)
-        assert_mixed(outs[0], ref, 1.6e-2, 4e-3, f"persistent prefill attn q={lens_q} k={lens_k}")
-
-
 def test_study_kernel_options_are_refused_by_the_product_library(ops, opt_guard):
-    """r05 housekeeping: the measured-and-lost prefill attention kernels (32x32x16 MFMAs, 64 query rows per wave) live in the
+    """r05 housekeeping: the measured-and-lost prefill attention kernels (32x32x16 MFMAs, 64 query rows per wave, persistent
+    workgroups) live in the
     study library only (build.py --study; tests/study_kernels.py runs there).  The product library refuses their options
     loudly instead of shipping them."""
     q = dev(rnd(33, 8, 128, seed=1))
     k = dev(rnd(33, 2, 128, seed=2))
     cu = dev(torch.tensor([0, 33], dtype=torch.int32))
-    for name in ("fa_mfma32", "fa_rows64"):
+    for name in ("fa_mfma32", "fa_rows64", "fa_persist"):
         with ops.option(name, 1):
             with pytest.raises(RuntimeError, match="study"):
                 ops.varlen_attn_prefill(q, k, k, cu, cu, 33, 128 ** -0.5)

@@ -1,5 +1,5 @@
 """r05: where the persistent prefill attention (option fa_persist) spends a slot's time, and how evenly the slots finish.
-Needs the stamp variant: python glm4_moe_nano-vllm_amd/build.py --variant _fapst GLM_FAP_STAMP=1 ;
+Needs the stamp variant: python glm4_moe_nano-vllm_amd/build.py --variant _fapst GLM_STUDY_KERNELS=1 GLM_FAP_STAMP=1 ;
 GLM4MOE_HIP_LIB=.../libglm4moe_hip_fapst.so GLM_FA_PERSIST=1 python tools/fap_stamps.py [B S]"""
 import ctypes, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
