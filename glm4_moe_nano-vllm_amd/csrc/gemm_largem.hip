@@ -123,6 +123,9 @@ __device__ const u32x4_t g_zero_page_lm[4] = {};
 #if GLM_LM_STAMP
 __device__ unsigned long long g_lm_stamps[2][8];
 __device__ unsigned long long g_lm_tile_stamps[8];  // workgroup 8, wave 0: cycles per tile switch segment, [7] = tiles
+// r05: workgroup 8, wave 0, product quadrant loop: cycles by K-tile POSITION summed over the workgroup's tiles — [0..5] the first
+// six K tiles of an output tile, [6..11] the last six (11 = the last), [12] every other one; [13..25] the counts
+__device__ unsigned long long g_lm_kt_stamps[26];
 #define LM_TS(i) do { unsigned long long t_ = __builtin_readcyclecounter(); if (i) ts_acc[(i) - 1] += t_ - ts_prev; ts_prev = t_; } while (0)
 #define LM_T(i) do { if (GLM_LM_STAMP) { unsigned long long t_ = __builtin_readcyclecounter(); if (i) tacc[i - 1] += t_ - tprev; tprev = t_; } } while (0)
 #else
@@ -192,7 +195,21 @@ constexpr int LM_LEAN = 1, LM_WIDEST = 2, LM_NOSTORE = 4, LM_DMA2 = 8, LM_DMA4 =
               LM_DEEP = 2048,  // 5-stage ring (all 160 KiB of LDS): one more K tile of prefetch distance
               LM_PH8 = 4096,   // CfgC: BK = 64, two buffers, four 16-MFMA phases per K tile (needs LM_LEAN)
               LM_P3X = 8192, LM_QW = 16384, LM_RPRE = 32768, LM_RFIRST = 65536, LM_MIR = 131072,  // schedules of that loop (described there)
-              LM_PARK = 262144;  // part of the epilogue's stores deferred into the next tile's K loop through LDS
+              LM_PARK = 262144,  // part of the epilogue's stores deferred into the next tile's K loop through LDS
+              LM_CONT = 524288;  // r05: the K tiles of consecutive output tiles form ONE stream through the two buffers (below)
+//   LM_CONT   (grouped gate|up / down on the product quadrant loop, bf16 weights, even K-tile count) the operand pieces of
+//             the NEXT output tile's K tiles 0 and 1 are issued from the last two K tiles of the current one, in the places
+//             where the loop would issue W(kt+2) and X(kt+1) if the tile went on: the per-tile ring fill, its full drain at
+//             the top of a tile (r05 stamps: 4.4k cycles per tile, a chip-wide burst: every workgroup switches tiles at the
+//             same time) and the source set-up in front of the epilogue disappear; the epilogue runs between K tile nk - 1
+//             and K tile 0' with W(1') in flight.  The next tile is looked up (tile table) and its gathered source rows are
+//             loaded at the START of the current tile; the per-row scales of the finished tile are requested in front of
+//             the last W pieces.  Same MFMAs in the same order: bit-identical.  MEASURED r05 (study builds only): gate|up 2685
+//             against 2630 us, down 1565 against 1522 us at T = 16384.  The stamps by K-tile position say why: the 4.4k cycles
+//             did not go away, they moved into K tile 0' (8.1-9.0k cycles against 4.0k for every other K tile) — what the
+//             top-of-tile wait drains is not the ring fill but the finished tile's STORES (every workgroup reaches its
+//             epilogue at the same time: a chip-wide write burst), and with one VM counter for loads and stores the first
+//             counted wait behind the epilogue has to let them retire whatever it is waiting for.
 //   LM_EPIORD the epilogue's global LOADS (per-row scales) are issued before the next tile's ring fill, so that waiting
 //             for them does not drain the fill; and the wait that opens a tile leaves the previous tile's stores in
 //             flight (vmcnt counts in issue order and the fill was issued before them) whenever their number is
@@ -285,6 +302,8 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
     // its phase-3 wait), while the store path is otherwise idle.  The tile search then borrows the tail of buffer 1.
     constexpr bool PARK = C::PH8 && (VAR & LM_PARK) != 0 && (VAR & LM_WIDEST) != 0 && (VAR & LM_NOSTORE) == 0;
     constexpr int PARK_N = 4;
+    constexpr bool CONT = (VAR & LM_CONT) != 0 && C::PH8 && (VAR & LM_QW) != 0 && (VAR & LM_RFIRST) != 0 && (VAR & LM_P3X) == 0 &&
+                          !PARK && !C::A8 && !C::W8 && !WSCALE && MODE != GEMM_PLAIN && (VAR & LM_EPIORD) != 0;
     int* sh = reinterpret_cast<int*>(smem + C::NSTAGE * C::STAGE - ((C::ALIAS_SH || PARK) ? 16 : 0));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -372,7 +391,12 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
     unsigned wvo[C::W_DMA], xvo[C::X_DMA];  // LEAN: byte offsets of this lane's chunk at k = 0
     __amdgpu_buffer_rsrc_t wrs, xrs;
     if (LEAN) xrs = make_rsrc(p.x);
-    auto setup_sources = [&]() {
+    // (CONT) the next tile, found at the start of the current one: tile-table entry, list position, gathered source rows
+    bool nxt = false;
+    int n_grp = -1, n_m0 = 0, n_mcnt = 0, n_ntile = 0, n_pos = 0, n_ti = 0;
+    int nsrow[C::X_DMA];
+    auto setup_sources = [&](auto prec) {
+        constexpr bool PRE = decltype(prec)::value;  // the source rows come from nsrow[] (loaded a tile ago)
         if (LEAN) {
             // descriptor of the group's weights (wave-uniform; grp came through LDS, so make that provable)
             const int64_t goff = (int64_t)__builtin_amdgcn_readfirstlane(grp) * p.w_gstride;
@@ -393,7 +417,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
                 const int row = (wid * C::X_DMA + i) * C::RPI + lane / C::CPR;
                 const int ch = (lane % C::CPR) ^ C::swz(row);
                 const int mr = row < mcnt ? row : 0;
-                const int srow = p.src ? p.src[m0 + mr] : m0 + mr;
+                const int srow = PRE ? nsrow[i] : (p.src ? p.src[m0 + mr] : m0 + mr);
                 if constexpr (C::A8) xvo[i] = (unsigned)(srow * (int)p.ldx + ch * 16);  // fp8 activations: ldx in bytes
                 else xvo[i] = (unsigned)(srow * (int)p.ldx + ch * 8) * 2u;
             }
@@ -576,8 +600,9 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
     if constexpr ((VAR & LM_DESYNC) != 0) {
         for (int i = 0; i < (int)(blockIdx.x & 7) * (GLM_LM_DESYNC_CYCLES / 1024); ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 clocks
     }
-    setup_sources();
+    setup_sources(std::false_type{});
     fill_ring();
+    bool cont_in = false;  // (CONT) this tile's first K tiles were put in flight by the previous tile's K loop
 #if GLM_LM_STAMP
     unsigned long long ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ts_prev = 0;
 #endif
@@ -590,6 +615,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < C::MT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        float sc_pre[C::MT];  // per-row scales of this tile (down projection), loaded before its epilogue (LM_EPIORD)
 
         // ---- main loop: two phases per K tile, waves 4-7 run ONE BARRIER BEHIND waves 0-3 ----
         //   phase 1: LDS fragment reads of tile kt + DMA issue of tile kt+DIST + counted wait for
@@ -605,6 +631,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         //        B1(kt-1).
         // The ring fill was issued before the previous tile's epilogue stores, and stores retire out of order with
         // loads, so the first wait of a tile is a full drain (the stores are long acknowledged by then).
+        if (!(CONT && cont_in)) {
         if constexpr ((VAR & LM_EPIORD) != 0) {
             // pending_stores = store instructions this wave issued after the ring fill (0 when not known exactly)
             if (pending_stores == LM_STORES_FULL) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LM_STORES_FULL) : "memory");
@@ -615,6 +642,42 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();                 // every share of the first DIST tiles landed
+        }
+        // (CONT && cont_in: every wave waited for its own pieces of K tile 0 in phase 3 of the previous tile's last K tile and
+        // has passed workgroup barriers since; W of K tile 1 is in flight, as behind fill_ring)
+        if constexpr (CONT) {
+            // the next tile of this workgroup's list, if the table holds it, and its gathered source rows: consumed two K
+            // tiles before the end of this tile's K loop
+            nxt = false;
+            if ((nk & 1) == 0 && nk >= 4) {
+                int pp = pos + pstep, tt = ti + 1;
+                while (pp < chunk_len && tt < TAB_N) {
+                    u32x4_t e;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(tab_addr + tt * 16) : "memory");
+                    const int g_ = __builtin_amdgcn_readfirstlane((int)e[0]);
+                    if (g_ >= 0) {
+                        nxt = true;
+                        n_grp = g_;
+                        n_m0 = __builtin_amdgcn_readfirstlane((int)e[1]);
+                        n_mcnt = __builtin_amdgcn_readfirstlane((int)e[2]);
+                        n_ntile = __builtin_amdgcn_readfirstlane((int)e[3]);
+                        n_pos = pp;
+                        n_ti = tt;
+                        break;
+                    }
+                    pp += pstep;
+                    ++tt;
+                }
+            }
+            if (nxt) {
+#pragma unroll
+                for (int i = 0; i < C::X_DMA; ++i) {
+                    const int row = (wid * C::X_DMA + i) * C::RPI + lane / C::CPR;
+                    const int mr = row < n_mcnt ? row : 0;
+                    nsrow[i] = p.src ? p.src[n_m0 + mr] : n_m0 + mr;
+                }
+            }
+        }
         LM_TS(1);  // 0: top-of-tile wait + barrier
         if constexpr (C::PH8) {
         // ---- CfgC: four phases per K tile, each = load interval | barrier | 16 MFMAs | barrier; waves 4-7 run one
@@ -744,8 +807,9 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         };
         auto dma2 = [&](int slot, int kt_, auto j0c) {
             constexpr int j0 = decltype(j0c)::value;
-            stage_one(slot, kt_, std::integral_constant<int, j0>{});
-            stage_one(slot, kt_, std::integral_constant<int, j0 + 1>{});
+            const int kk = (CONT && kt_ >= nk) ? kt_ - nk : kt_;  // (CONT) past the end: K tile 0 / 1 of the NEXT output tile
+            stage_one(slot, kk, std::integral_constant<int, j0>{});
+            stage_one(slot, kk, std::integral_constant<int, j0 + 1>{});
         };
         using I0 = std::integral_constant<int, 0>;
         using I2 = std::integral_constant<int, 2>;
@@ -959,11 +1023,13 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         static_assert(!C::A8 || (QW && !P3X && !PARK), "fp8 x fp8: wired into the product quadrant loop");
 #if GLM_LM_STAMP
         unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+        unsigned long long kt_t0 = __builtin_readcyclecounter();
 #endif
         for (int kt = 0; kt < nk; ++kt) {
             const int b = kt & 1;
             const unsigned so = b * C::STAGE;
-            const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
+            // (CONT) with a next tile in hand the stream goes on past this tile's last K tile
+            const bool has1 = kt + 1 < nk || (CONT && nxt), has2 = kt + 2 < nk || (CONT && nxt);
             auto mid = [&]() { __builtin_amdgcn_sched_barrier(0); };
             ksh = (kt & 3) * 8;
             // ---- phase 0
@@ -1019,6 +1085,30 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             else quad(I2{}, I2{}, I0{}, I4{}, I0{});
             __builtin_amdgcn_s_barrier();
             // ---- phase 2
+            if constexpr (CONT) {
+                if (nxt && kt == nk - 2) {
+                    // X(nk - 1) has been issued (phases 0, 1): from here on every piece belongs to the next output tile —
+                    // W(0') now and in phase 3, X(0') and W(1') from the last K tile
+                    grp = n_grp;
+                    m0 = n_m0;
+                    mcnt = n_mcnt;
+                    ntile = n_ntile;
+                    pos = n_pos;
+                    ti = n_ti;
+                    setup_sources(std::true_type{});
+                }
+                if constexpr (MODE == GEMM_DOWN) {
+                    if (nxt && kt == nk - 1) {
+                        // the finished tile's per-row scales, in front of W(1'): they return before the counted wait of phase 3
+                        const bool sc_on = grp_c < p.n_scaled;
+#pragma unroll
+                        for (int mt = 0; mt < C::MT; ++mt) {
+                            const int row = wm * (C::BM / 2) + 16 * mt + c;
+                            sc_pre[mt] = (sc_on && row < mcnt_c) ? bf2f(p.scale[m0_c + row]) : 1.0f;
+                        }
+                    }
+                }
+            }
             auto dma2_ = [&]() { if (has2) dma2(b, kt + 2, I0{}); };
             if (!RF) dma2_();
             if constexpr (QW) rd_x(so, I4{}, I2{}, I0{});
@@ -1057,6 +1147,17 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             else quad(I0{}, I2{}, I4{}, I4{}, I0{});
             __builtin_amdgcn_s_barrier();
             LM_T(6);  // 5: phases 1-3
+#if GLM_LM_STAMP
+            if (blockIdx.x == 8 && wid == 0) {
+                const unsigned long long t1_ = __builtin_readcyclecounter();
+                const int idx_ = kt < 6 ? kt : (nk - 1 - kt < 6 ? 11 - (nk - 1 - kt) : 12);
+                if (lane == 0) {
+                    g_lm_kt_stamps[idx_] += t1_ - kt_t0;
+                    g_lm_kt_stamps[13 + idx_] += 1;
+                }
+                kt_t0 = t1_;
+            }
+#endif
         }
 #if GLM_LM_STAMP
         if (blockIdx.x == 8 && lane == 0 && (wid == 0 || wid == 4)) {
@@ -1221,8 +1322,9 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
 
         // per-row scales of the finished tile: requested before the ring fill (waiting for a load issued after the fill
         // would drain the fill first)
-        float sc_pre[C::MT];
+        const bool cont_out = CONT && nxt;  // the next tile's K tiles 0 and 1 are in flight already
         if constexpr ((VAR & LM_EPIORD) != 0 && MODE == GEMM_DOWN) {
+            if (!cont_out) {
             const bool sc_on = grp_c < p.n_scaled;
 #pragma unroll
             for (int mt = 0; mt < C::MT; ++mt) {
@@ -1231,12 +1333,16 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
             }
 #pragma unroll
             for (int mt = 0; mt < C::MT; ++mt) asm volatile("" : "+v"(sc_pre[mt]));  // the loads stay above the fill
+            }
         }
         // ---- next tile: every wave is past its last LDS read, so the ring can be refilled right away ----
         LM_TS(2);  // 1: K loop
-        pos += pstep;
-        ++ti;
-        const bool more = find_tile();
+        bool more = true;
+        if (!cont_out) {
+            pos += pstep;
+            ++ti;
+            more = find_tile();
+        }
         LM_TS(3);  // 2: tile search
         // A8 (r05): the epilogue of the fp8 x fp8 kernels LOADS (weight-row scales, token scales) and vector-memory results
         // return in issue order — behind the ring fill they cost a whole fill latency per tile (stamps of the first form:
@@ -1244,12 +1350,12 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         // profiles/r05/largem_stamps_fp8a8_first_form.txt).  There the next tile's fill is issued once the first 16-row
         // block of the epilogue has its loads back, i.e. behind them and in front of the bulk of the stores.
         constexpr bool LATE_FILL = C::A8;
-        if (more) {
-            setup_sources();   // (its own loads — the gathered source rows — go out here, in front of the epilogue's)
+        if (more && !cont_out) {
+            setup_sources(std::false_type{});   // (its own loads — the gathered source rows — go out here, in front of the epilogue's)
             LM_TS(4);  // 3: source set-up
         }
         auto start_next = [&]() {
-            if (more) {
+            if (more && !cont_out) {
                 fill_ring();
                 LM_TS(5);  // 4: ring fill issue
             }
@@ -1518,6 +1624,7 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         }
 #endif
         if (!more) break;
+        cont_in = cont_out;
     }
 }
 
@@ -1616,6 +1723,7 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
     switch (var) {
         GLM_LM_CASE(86787);  // THE product loop: quadrant phases (LM_QW | LM_RFIRST | LM_NOPRIO) with LM_EPIORD
 #if GLM_LM_STUDY  // the steps that led there (profiles/r02/largem_ab_*.json); study builds only
+        GLM_LM_CASE(611075); // 86787 with LM_CONT (r05): bit-identical, 2-3 % slower (profiles/r05/largem_cont_*.txt)
         GLM_LM_CASE(3);
         GLM_LM_CASE(4099);  // lean + wide + quadrant phases on two 64-KiB buffers (CfgC)
         GLM_LM_CASE(12291); // ... with the DMA of phase 0 moved to phase 3
@@ -1729,6 +1837,13 @@ extern "C" int glm_debug_largem_stamps(unsigned long long* out16) {
     return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lm_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
 }
 // same: [0..5] = top-of-tile wait, K loop, tile search, source set-up, ring fill issue, epilogue; [7] = tiles
+extern "C" int glm_debug_largem_kt_stamps(unsigned long long* out26, int reset) {
+    if (reset) {
+        unsigned long long z[26] = {};
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_lm_kt_stamps), z, sizeof(z)) == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyFromSymbol(out26, HIP_SYMBOL(g_lm_kt_stamps), sizeof(unsigned long long) * 26) == hipSuccess ? 0 : -1;
+}
 extern "C" int glm_debug_largem_tile_stamps(unsigned long long* out8) {
     return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lm_tile_stamps), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
 }

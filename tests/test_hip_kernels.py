@@ -974,6 +974,51 @@ def test_qkv_gemm_with_rope_store_epilogue(ops, T, nh, nkv, K, with_cache, need_
                                     dev(slots[: T - 1]), need_kv)
 
 
+@pytest.mark.parametrize("K,counts", [(256, [2048, 1500, 3000, 1000, 6000]), (512, [5000, 0, 257, 4096, 3000]),
+                                      (320, [4000, 4000, 4000, 4000]), (128, [3000, 5000, 2000])])
+def test_gemm_large_m_several_tiles_per_workgroup(ops, K, counts):
+    """r05: ~500 output tiles on 256 persistent workgroups — the tile switch of the product loop (tile table, ring fill in
+    front of the epilogue, store-count wait at the top of the next tile) runs once or twice in every workgroup, with even
+    (4, 8) and odd (5) K-tile counts and a two-tile K loop.  Bit for bit against variant 0, three launches each (a late or
+    misdirected DMA piece would show as a rare wrong tile); one group also against the oracle (mlp.py:49-54).  In a STUDY
+    build variant 611075 adds LM_CONT (the next tile's first K tiles issued from the current tile's last two: measured
+    2-3 % slower, csrc/gemm_largem.hip); the product library maps the number to variant 0."""
+    I, N2 = 1024, 2048
+    E, R = len(counts) - 1, sum(counts)
+    offs = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32)
+    g = torch.Generator().manual_seed(K)
+    T = 3000
+    tok = torch.randint(0, T, (R,), generator=g, dtype=torch.int32)
+    x = rnd(T, K, seed=K + 1)
+    w13 = rnd(E + 1, 2 * I, K, seed=K + 2, scale=K ** -0.5)
+    scale = (torch.rand(R, generator=g) + 0.1).to(BF)
+    act_in = rnd(R, K, seed=K + 3)
+    w2 = rnd(E + 1, N2, K, seed=K + 4, scale=K ** -0.5)
+    xd, w13d, offd, tokd, actd, w2d, scd = dev(x), dev(w13), dev(offs), dev(tok), dev(act_in), dev(w2), dev(scale)
+
+    def run():
+        a = ops.grouped_gemm_gateup_silu(xd, w13d, offd, tokd, R)
+        y = ops.grouped_gemm_down(actd, w2d, offd, scd, E)
+        torch.cuda.synchronize()
+        return a, y
+
+    with largem_variant(0):
+        ref = run()
+    with largem_variant(86787):
+        base = run()
+    assert torch.equal(base[0], ref[0]) and torch.equal(base[1], ref[1])
+    for v in (611075, -1):
+        with largem_variant(v):
+            for _ in range(3):
+                got = run()
+                assert torch.equal(got[0], ref[0]), f"gate|up: variant {v} differs from variant 0 (K={K} counts={counts})"
+                assert torch.equal(got[1], ref[1]), f"down: variant {v} differs from variant 0 (K={K} counts={counts})"
+    e = E
+    rows = slice(int(offs[e]), int(offs[e]) + min(300, counts[e]))
+    a_ref = O.silu_and_mul(O.linear(x[tok[rows].long()], w13[e]))
+    assert_close_bf16(got[0][rows].cpu(), a_ref, 3, 0.06, atol=1e-3, what=f"act K={K} group {e}")
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_gemm_large_m_quadrant_loop_random_shapes(ops, seed):
     """Random ragged groupings (empty groups, single-row groups, partial row blocks and column tiles), random K in whole

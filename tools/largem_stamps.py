@@ -27,8 +27,18 @@ if os.environ.get("GLM_LARGEM_VARIANT", "").strip() in ("", "-1") or int(os.envi
     names = ["p0 read+dma issue", "p0 lds wait", "p0 barrier a", "p0 mfma", "p0 barrier b", "phases 1-3", "-"]
 f2 = getattr(lib, "glm_debug_largem_tile_stamps", None)
 tnames = ["top-of-tile wait", "K loop", "tile search", "source set-up", "ring fill issue", "epilogue"]
+f3 = getattr(lib, "glm_debug_largem_kt_stamps", None)
+if f3 is not None:
+    f3.restype = ctypes.c_int; f3.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 def show(tag):
     torch.cuda.synchronize()
+    if f3 is not None:   # r05: cycles by K-tile position inside an output tile (the K tile that follows a tile switch = 0)
+        b26 = (ctypes.c_ulonglong * 26)()
+        if f3(b26, 0) == 0 and b26[13]:
+            lab = [f"kt {i}" for i in range(6)] + [f"kt nk-{6 - i}" for i in range(6)] + ["others"]
+            print(f"{tag} cycles per K tile by position (workgroup 8, wave 0): " +
+                  ", ".join(f"{lab[i]} {b26[i] / b26[13 + i]:.0f}" for i in range(13) if b26[13 + i]))
+        f3(b26, 1)
     if f2 is not None:
         f2.restype = ctypes.c_int; f2.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
         b8 = (ctypes.c_ulonglong * 8)()
@@ -42,8 +52,11 @@ def show(tag):
         tot = sum(buf[g * 8 + i] for i in range(7))
         print(f"{tag} wave {4*g}: K tiles {nk}, cycles/tile {tot/max(nk,1):.0f}: " +
               ", ".join(f"{names[i]} {buf[g*8+i]/max(nk,1):.0f}" for i in range(7)))
+if f3 is not None:
+    torch.cuda.synchronize(); f3((ctypes.c_ulonglong * 26)(), 1)
 act = ops.grouped_gemm_gateup_silu(x, w13, offs, tok, R); show("gate|up")
 ops.grouped_gemm_down(act, w2, offs, scale, E); show("down")
+if os.environ.get("LM_STAMPS_BF16_ONLY"): sys.exit(0)
 # r05: the same for the W8A8 pair on the block-scaled fp8 MFMA
 layer.mlp.expert_weight_dtype = "fp8_e4m3"; layer.mlp.quantize_experts_fp8()
 w13_q, w13_s, w2_q, w2_s = layer.mlp._fp8
