@@ -214,6 +214,9 @@ constexpr int LM_LEAN = 1, LM_WIDEST = 2, LM_NOSTORE = 4, LM_DMA2 = 8, LM_DMA4 =
 //             for them does not drain the fill; and the wait that opens a tile leaves the previous tile's stores in
 //             flight (vmcnt counts in issue order and the fill was issued before them) whenever their number is
 //             known exactly — full tiles.
+#ifndef GLM_LM_DESYNC_MODE
+#define GLM_LM_DESYNC_MODE 0  // 0: r02, one step of GLM_LM_DESYNC_CYCLES per XCD; 1: r05, every workgroup its own phase of one tile time
+#endif
 #ifndef GLM_LM_DESYNC_CYCLES
 #define GLM_LM_DESYNC_CYCLES 5120  // per XCD step, shader clocks (~2.5 us)
 #endif
@@ -598,7 +601,18 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
     };
     if (!find_tile()) return;
     if constexpr ((VAR & LM_DESYNC) != 0) {
+#if GLM_LM_DESYNC_MODE == 1
+        // r05 (study): the 32 workgroups of an XCD spread evenly over ONE output tile's time (K loop ~2600 clocks per K tile +
+        // ~11k of tile switch), XCDs interleaved by a 1/256 step: no two workgroups of the chip reach their epilogue together.
+        // Measured (profiles/r05/largem_desync_per_workgroup_ab.txt): gate|up 2810 against 2650 us, down 1540 against 1530 us —
+        // the start delay (up to one tile of 28-41) and the lost co-scheduling of tiles that share operand panels through an
+        // XCD's L2 cost more than the smoothed write burst returns.
+        const int tile_clocks = nk * 2600 + 11000;
+        const int slot = (((int)blockIdx.x >> 3) & 31) * 8 + ((int)blockIdx.x & 7);
+        for (int i = 0; i < (int)((long long)slot * tile_clocks / 256 / 1024); ++i) __builtin_amdgcn_s_sleep(16);
+#else
         for (int i = 0; i < (int)(blockIdx.x & 7) * (GLM_LM_DESYNC_CYCLES / 1024); ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 clocks
+#endif
     }
     setup_sources(std::false_type{});
     fill_ring();
@@ -1349,6 +1363,9 @@ __global__ __launch_bounds__(512) void gemm_largem_kernel(const GemmParams p, in
         // epilogue 23.5k cycles against 6.0k for bf16, and the late stores then drain into the next tile's short K loop:
         // profiles/r05/largem_stamps_fp8a8_first_form.txt).  There the next tile's fill is issued once the first 16-row
         // block of the epilogue has its loads back, i.e. behind them and in front of the bulk of the stores.
+        // (r05, also measured: the scale vectors as LDS-DMA pieces of the ring fill, no global load in the epilogue, the fill in
+        // front of it as in the bf16 kernel — pair 1817 against 1819 TFLOP/s, profiles/r05/fp8a8_probe_lds_scales_form.txt: the
+        // dependent loads are not what a tile switch waits for either; not kept.)
         constexpr bool LATE_FILL = C::A8;
         if (more && !cont_out) {
             setup_sources(std::false_type{});   // (its own loads — the gathered source rows — go out here, in front of the epilogue's)
@@ -1724,6 +1741,7 @@ int launch_largem(const GemmParams& p, hipStream_t st) {
         GLM_LM_CASE(86787);  // THE product loop: quadrant phases (LM_QW | LM_RFIRST | LM_NOPRIO) with LM_EPIORD
 #if GLM_LM_STUDY  // the steps that led there (profiles/r02/largem_ab_*.json); study builds only
         GLM_LM_CASE(611075); // 86787 with LM_CONT (r05): bit-identical, 2-3 % slower (profiles/r05/largem_cont_*.txt)
+        GLM_LM_CASE(86851);  // 86787 with LM_DESYNC (r05: -DGLM_LM_DESYNC_MODE=1 = every workgroup its own phase; slower)
         GLM_LM_CASE(3);
         GLM_LM_CASE(4099);  // lean + wide + quadrant phases on two 64-KiB buffers (CfgC)
         GLM_LM_CASE(12291); // ... with the DMA of phase 0 moved to phase 3

@@ -11,8 +11,14 @@ mkdir -p $OUT
 cd /tmp
 KNOB=${PMC_FA_KNOB:-GLM_FA_MFMA32}
 LABEL=${PMC_FA_LABEL:-32x32x16 (opt-in)}
+# r05: PMC_FA_LIB0 / PMC_FA_LIB1 = two LIBRARIES instead of a knob (e.g. lib/libglm4moe_hip_r04.so built with -DGLM_FA_R05=0
+# -DGLM_FA_STORE16=0 against the product library): k0 runs on LIB0, k1 on LIB1
 for k in 0 1; do
-  export $KNOB=$k
+  if [ -n "$PMC_FA_LIB1" ]; then
+    if [ $k = 0 ]; then export GLM4MOE_HIP_LIB=$PMC_FA_LIB0; else export GLM4MOE_HIP_LIB=$PMC_FA_LIB1; fi
+  else
+    export $KNOB=$k
+  fi
   for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
              "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
