@@ -107,12 +107,19 @@ def _attend(q, k, v, scale: float, causal_offset: int | None):
     kf = k.to(torch.float32).transpose(0, 1).repeat_interleave(rep, 0)  # [nh,Tk,hd]
     vf = v.to(torch.float32).transpose(0, 1).repeat_interleave(rep, 0)
     s = torch.matmul(qf, kf.transpose(1, 2)) * scale
+    dead = None
     if causal_offset is not None:
         Tq, Tk = q.shape[0], k.shape[0]
         i = torch.arange(Tq).unsqueeze(1)
         j = torch.arange(Tk).unsqueeze(0)
         s = s.masked_fill(j > i + causal_offset, float("-inf"))
+        dead = (j > i + causal_offset).all(dim=-1) if Tk > 0 else torch.ones(Tq, dtype=torch.bool)
     p = torch.softmax(s, dim=-1)
+    if dead is not None and bool(dead.any()):
+        # more queries than keys: flash-attn's published rule for the bottom-right aligned mask (its README, "2.1: change
+        # behavior of causal flag") — a row whose mask is all zero gives an all-zero output row, not the NaN of a softmax
+        # over nothing.  (The reference never issues such a call; the kernels are tested on it.)
+        p = p.masked_fill(dead.view(1, -1, 1), 0.0)
     return torch.matmul(p, vf).transpose(0, 1).to(q.dtype)              # [Tq,nh,hd]
 
 

@@ -62,6 +62,10 @@ def rnd(*shape, seed=0, scale=1.0, dtype=BF):
 
 def assert_mixed(a, e, rtol, atol, what=""):
     a, e = a.detach().cpu().float(), e.detach().cpu().float()
+    assert a.shape == e.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(e.shape)}"
+    # a NaN on either side compares False below and would pass unseen (r05: the attention stand-in's softmax over nothing)
+    assert bool(torch.isfinite(e).all()), f"{what}: the expected values hold {int((~torch.isfinite(e)).sum())} non-finite elements"
+    assert bool(torch.isfinite(a).all()), f"{what}: {int((~torch.isfinite(a)).sum())} non-finite elements"
     err = (a - e).abs()
     lim = atol + rtol * e.abs()
     bad = err > lim
@@ -1087,7 +1091,12 @@ def test_moe_block_large_t(ops, T, E, k, H, I):
     ([300], [300], 24, 2, False), ([5, 40], [300, 296], 4, 2, True), ([130], [513], 8, 8, True),
     # (sequences x kv heads) divisible by 8: the XCD-grouped workgroup order; several query blocks per sequence
     ([300, 17, 513, 64], [300, 17, 513, 64], 16, 4, False), ([700, 260], [700, 260], 8, 4, False),
-    ([100, 50], [612, 306], 16, 4, True), ([1025], [1025], 12, 1, False)])
+    ([100, 50], [612, 306], 16, 4, True), ([1025], [1025], 12, 1, False),
+    # r05: contiguous K/V with fewer queries than keys (a prefix already in K/V) and with MORE queries than keys (bottom-right
+    # aligned mask: the first rows see nothing and come out as zeros); a two-block sequence whose last tile is partial next
+    # to one whose tiles are all full (the predicate-free loop's range ends one tile earlier in the first)
+    ([5, 40], [300, 296], 4, 2, False), ([200, 70], [40, 70], 4, 2, False), ([250, 256], [250, 256], 8, 2, False),
+    ([0, 33], [0, 33], 4, 2, False)])
 def test_varlen_attn_prefill(ops, lens_q, lens_k, nh, nkv, paged):
     g = torch.Generator().manual_seed(sum(lens_k) + nh)
     hd, bs = 128, 256

@@ -53,6 +53,8 @@ def assert_close_bf16(actual, expected, max_ulp=1, frac_inexact=0.02, atol=0.0, 
     the elements differ at all."""
     a, e = actual.detach().cpu(), expected.detach().cpu()
     assert a.shape == e.shape, f"{what}: shape {a.shape} vs {e.shape}"
+    # a NaN compares False in the atol clause below and would pass unseen
+    assert bool(torch.isfinite(e.float()).all()) and bool(torch.isfinite(a.float()).all()), f"{what}: non-finite elements"
     d = bf16_ulp_diff(a, e)
     bad = (d > max_ulp) & ((a.float() - e.float()).abs() > atol)
     assert not bool(bad.any()), (
