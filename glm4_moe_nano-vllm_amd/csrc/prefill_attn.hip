@@ -111,6 +111,9 @@ __device__ unsigned long long g_fa_stamps[16];
 #ifndef GLM_FA_R05
 #define GLM_FA_R05 (GLM_FA_LOOP == 1 && !GLM_FA_STAMP && !GLM_FA_GENERIC && GLM_FA_NW == 4 && !GLM_FA_EDGE)
 #endif
+#ifndef GLM_FA_PKFMA
+#define GLM_FA_PKFMA 0   // 1 (measured r05, not kept): the eight s * c - m of a unit as four v_pk_fma_f32 — 14 fewer vector instructions per
+#endif                   // tile and 1.3 % (4 x 4096) / 2.1 % (1 x 16384) SLOWER, three interleaved rounds (profiles/r05/prefill_attn_pkfma_ab.txt)
 #ifndef GLM_FA_STORE16
 #define GLM_FA_STORE16 1   // r05: 16-byte output stores behind a lane-row exchange (0 = the 8-byte stores of r02-r04)
 #endif
@@ -552,6 +555,20 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
             m_thr[qt] = m_new + 8.0f;
         }
         bf16x8_t pf;
+#if GLM_FA_PKFMA
+        // r05: the eight s * c - m as four packed fp32 FMAs (v_pk_fma_f32: the same IEEE fma per element, half the issue slots)
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const f32x2_t c2 = {scale_log2e, scale_log2e}, nm2 = {-m_use, -m_use};
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                const f32x2_t sv = {s[tt][r], s[tt][r + 1]};
+                const f32x2_t arg = __builtin_elementwise_fma(sv, c2, nm2);
+                pf[4 * tt + r] = (__bf16)((GLM_FA_ABLATE & 1) ? arg[0] : __builtin_amdgcn_exp2f(arg[0]));
+                pf[4 * tt + r + 1] = (__bf16)((GLM_FA_ABLATE & 1) ? arg[1] : __builtin_amdgcn_exp2f(arg[1]));
+            }
+#else
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -560,6 +577,7 @@ __global__ __launch_bounds__(FA_NT, (FA_QT >= 4 ? 1 : 2)) void prefill_attn_kern
                 const float pv = (GLM_FA_ABLATE & 1) ? arg : __builtin_amdgcn_exp2f(arg);
                 pf[4 * tt + r] = (__bf16)pv;
             }
+#endif
 #endif
         return pf;
     };
